@@ -1,0 +1,194 @@
+"""ctypes view of include/blance_hip.h (the C-ABI structs and status codes).
+
+Kept field-for-field in sync with the header; tests/test_abi.py checks the
+struct sizes against the sizes the C compiler reports.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+
+OK = 0
+ERR_BAD_ARG = -1
+ERR_UNSUPPORTED = -2
+ERR_CAPACITY = -3
+ERR_DEVICE = -4
+ERR_NO_DEVICE = -5
+ERR_COMM = -6
+
+LIST_ABSENT, LIST_NIL, LIST_SET = 0, 1, 2
+BOOSTER_NONE, BOOSTER_CBGT = 0, 1
+ENGINE_AUTO, ENGINE_SEQUENTIAL = 0, 1
+
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_nodes_ext", C.c_int32), ("n_states", C.c_int32),
+        ("n_parts", C.c_int32), ("n_prev", C.c_int32), ("n_loads", C.c_int32),
+        ("n_rules", C.c_int32), ("n_vertices", C.c_int32), ("max_iterations", C.c_int32),
+        ("partition_weights_nil", C.c_int32), ("nodes_to_add_nil", C.c_int32),
+        ("hierarchy_rules_nil", C.c_int32), ("booster_kind", C.c_int32), ("top_state", C.c_int32),
+        ("state_priority", _i32p), ("state_constraints", _i32p), ("state_stickiness", _i32p),
+        ("state_has_stickiness", _u8p),
+        ("node_removed", _u8p), ("node_added", _u8p), ("node_weight", _i32p),
+        ("node_has_weight", _u8p),
+        ("part_order", _i32p), ("part_weight", _i32p), ("part_has_weight", _u8p),
+        ("part_in_prev", _u8p), ("part_prev_never_equal", _u8p),
+        ("assign_off", _i32p), ("assign_nodes", _i32p), ("assign_kind", _u8p),
+        ("prev_off", _i32p), ("prev_nodes", _i32p), ("prev_kind", _u8p),
+        ("load_state", _i32p), ("load_node", _i32p), ("load_weight", _i32p),
+        ("load_first_sweep_only", _u8p),
+        ("rule_off", _i32p), ("rule_inc", _i32p), ("rule_exc", _i32p),
+        ("vertex_empty", C.c_int32),
+        ("vertex_parent", _i32p), ("vertex_leaf_lo", _i32p), ("vertex_leaf_hi", _i32p),
+        ("node_leaf_pos", _i32p),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("out_off", _i32p), ("out_nodes", _i32p), ("out_kind", _u8p), ("out_capacity", C.c_int64),
+        ("warn_part", _i32p), ("warn_state", _i32p), ("warn_capacity", C.c_int64),
+        ("n_warnings", C.c_int64),
+        ("iterations", C.c_int32), ("converged", C.c_int32),
+        ("device_ms", C.c_double), ("total_ms", C.c_double),
+        ("steps_total", C.c_int64), ("steps_sequential", C.c_int64), ("steps_batched", C.c_int64),
+        ("kernel_launches", C.c_int64),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [("engine", C.c_int32), ("device_id", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+I32_FIELDS = [n for n, t in Problem._fields_ if t is _i32p]
+U8_FIELDS = [n for n, t in Problem._fields_ if t is _u8p]
+SCALAR_FIELDS = [n for n, t in Problem._fields_ if t is C.c_int32]
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class FlatProblem:
+    """A blance_problem held as numpy arrays (the SoA the ABI describes) plus the
+    name tables needed to un-intern a result."""
+
+    def __init__(self):
+        self.scalars = {n: 0 for n in SCALAR_FIELDS}
+        self.arrays = {}
+        # name tables (optional; synthetic problems may leave them None)
+        self.node_names = None
+        self.state_names = None
+        self.part_names = None
+        self._struct = None
+
+    def set(self, name, arr):
+        if name in I32_FIELDS:
+            a = np.ascontiguousarray(arr, dtype=np.int32)
+        elif name in U8_FIELDS:
+            a = np.ascontiguousarray(arr, dtype=np.uint8)
+        else:
+            raise KeyError(name)
+        if a.size == 0:          # keep a valid pointer for empty arrays
+            a = np.zeros(1, dtype=a.dtype)[:0].copy()
+        self.arrays[name] = a
+        self._struct = None
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        if "scalars" in d and name in d["scalars"]:
+            return d["scalars"][name]
+        if "arrays" in d and name in d["arrays"]:
+            return d["arrays"][name]
+        raise AttributeError(name)
+
+    def as_struct(self):
+        if self._struct is None:
+            s = Problem()
+            for k, v in self.scalars.items():
+                setattr(s, k, int(v))
+            self._keep = []
+            for n in I32_FIELDS + U8_FIELDS:
+                a = self.arrays.get(n)
+                if a is None:
+                    a = np.zeros(0, dtype=np.int32 if n in I32_FIELDS else np.uint8)
+                if a.size == 0:
+                    a = np.zeros(1, dtype=a.dtype)   # non-NULL pointer, zero logical length
+                self._keep.append(a)
+                setattr(s, n, _ptr(a, C.c_int32 if n in I32_FIELDS else C.c_uint8))
+            self._struct = s
+        return self._struct
+
+    def result_capacity(self):
+        P, M = self.scalars["n_parts"], self.scalars["n_states"]
+        if P * M == 0:
+            return 0
+        lens = np.diff(self.arrays["assign_off"].astype(np.int64)).reshape(P, M)
+        k = np.maximum(self.arrays["state_constraints"].astype(np.int64), 0)[None, :]
+        return int(np.maximum(lens, k).sum())
+
+
+class FlatResult:
+    """Caller-owned output buffers for one blance_plan call."""
+
+    def __init__(self, prob):
+        P, M = prob.scalars["n_parts"], prob.scalars["n_states"]
+        cap = prob.result_capacity()
+        self.out_off = np.zeros(P * M + 1, dtype=np.int32)
+        self.out_nodes = np.zeros(max(cap, 1), dtype=np.int32)
+        self.out_kind = np.zeros(max(P * M, 1), dtype=np.uint8)
+        self.warn_part = np.zeros(max(P * M, 1), dtype=np.int32)
+        self.warn_state = np.zeros(max(P * M, 1), dtype=np.int32)
+        s = Result()
+        s.out_off = _ptr(self.out_off, C.c_int32)
+        s.out_nodes = _ptr(self.out_nodes, C.c_int32)
+        s.out_kind = _ptr(self.out_kind, C.c_uint8)
+        s.out_capacity = cap
+        s.warn_part = _ptr(self.warn_part, C.c_int32)
+        s.warn_state = _ptr(self.warn_state, C.c_int32)
+        s.warn_capacity = P * M
+        self.struct = s
+        self.P, self.M = P, M
+
+    @property
+    def iterations(self):
+        return int(self.struct.iterations)
+
+    @property
+    def converged(self):
+        return bool(self.struct.converged)
+
+    @property
+    def n_warnings(self):
+        return int(self.struct.n_warnings)
+
+    def lists(self):
+        """[(p, m)] -> (kind, np.array of node ids)."""
+        off = self.out_off
+        return [[(int(self.out_kind[p * self.M + m]),
+                  self.out_nodes[off[p * self.M + m]:off[p * self.M + m + 1]].copy())
+                 for m in range(self.M)] for p in range(self.P)]
+
+    def warnings(self):
+        n = self.n_warnings
+        return list(zip(self.warn_part[:n].tolist(), self.warn_state[:n].tolist()))
+
+    def digest(self):
+        """SHA-256 over (out_kind, out_off, out_nodes[:total]) -- a compact
+        bit-exactness check between two implementations of the same problem."""
+        import hashlib
+        h = hashlib.sha256()
+        total = int(self.out_off[self.P * self.M]) if self.P * self.M else 0
+        h.update(self.out_kind[:self.P * self.M].tobytes())
+        h.update(self.out_off[:self.P * self.M + 1].tobytes())
+        h.update(self.out_nodes[:total].tobytes())
+        n = self.n_warnings
+        h.update(np.asarray([self.iterations, int(self.converged), n], dtype=np.int64).tobytes())
+        h.update(self.warn_part[:n].tobytes())
+        h.update(self.warn_state[:n].tobytes())
+        return h.hexdigest()

@@ -1,0 +1,212 @@
+/*
+ * blance_hip.h -- C ABI of the MI355X-native PlanNextMap planner.
+ *
+ * This is the drop-in boundary for couchbase/blance's planner path.  The
+ * reference has no FFI; the seam this ABI replaces is the call
+ *
+ *     PlanNextMapEx(...) -> planNextMapEx(...)        api.go:147-157, plan.go:23-58
+ *
+ * i.e. the whole convergence loop (plan.go:32-56) with every greedy sweep
+ * (planNextMapInnerEx, plan.go:60-331) runs behind ONE call of blance_plan().
+ * The host side (Go over cgo, or the C++/Python mirrors in this repo) interns
+ * strings to dense ids, flattens the maps to the int32 SoA arrays below, calls
+ * blance_plan(), un-interns the result and replays the caller-visible
+ * mutations of plan.go:49-55.  See INTEGRATION.md for the cgo stub.
+ *
+ * ABI rules: plain C, caller owns every buffer, nothing is retained after a
+ * call returns (cgo pointer rule), no callbacks, no exceptions cross the
+ * boundary, every entry point returns an int status (0 = ok, <0 = error).
+ *
+ * Id spaces
+ *   node id      0..n_nodes-1 = position in nodesAll (plan.go:72-75; names must
+ *                be unique).  n_nodes..n_nodes_ext-1 = names that occur only in
+ *                partition lists / nodesToRemove / nodesToAdd / NodeWeights:
+ *                they are counted and filtered but are never candidates
+ *                (candidates come from nodesAll, plan.go:77,:142).
+ *   state id     0..n_states-1 = the model's states in sortStateNames() order
+ *                (plan.go:437-474), which is the pass order of plan.go:307.
+ *                Pseudo state id n_states ("other") carries loads of state
+ *                names that are not in the model; they only feed
+ *                nodePartitionCounts (plan.go:118-124).
+ *   partition id 0..n_parts-1 = the partitions of partitionsToAssign, any order.
+ *   vertex id    hierarchy vertices: 0..n_nodes_ext-1 are the nodes, the rest
+ *                are interior names of NodeHierarchy plus the "" vertex that
+ *                findAncestor() yields past a root (plan.go:755-762).
+ */
+#ifndef BLANCE_HIP_H
+#define BLANCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLANCE_ABI_VERSION 1
+
+/* status codes */
+#define BLANCE_OK                0
+#define BLANCE_ERR_BAD_ARG      -1  /* NULL / inconsistent sizes / id out of range      */
+#define BLANCE_ERR_UNSUPPORTED  -2  /* input outside the supported envelope             */
+#define BLANCE_ERR_CAPACITY     -3  /* caller's output buffers too small                */
+#define BLANCE_ERR_DEVICE       -4  /* HIP runtime failure (see blance_last_error)      */
+#define BLANCE_ERR_NO_DEVICE    -5  /* no gfx950 device visible                         */
+#define BLANCE_ERR_COMM         -6  /* RCCL failure                                     */
+
+/* list kinds: Go distinguishes a missing map key, a nil slice and an empty
+ * non-nil slice under reflect.DeepEqual (plan.go:38). */
+#define BLANCE_LIST_ABSENT 0
+#define BLANCE_LIST_NIL    1
+#define BLANCE_LIST_SET    2
+
+/* NodeScoreBooster (plan.go:691-697) cannot be an arbitrary Go callback on the
+ * device; the one booster known in the wild (couchbase/cbgt, restated in
+ * control_test.go:19-26: max(float64(-w), stickiness)) is a built-in. */
+#define BLANCE_BOOSTER_NONE 0
+#define BLANCE_BOOSTER_CBGT 1
+
+/* engines (blance_options.engine) */
+#define BLANCE_ENGINE_AUTO        0 /* fastest exact schedule available                 */
+#define BLANCE_ENGINE_SEQUENTIAL  1 /* one in-order step at a time (always exact)       */
+
+typedef struct blance_problem {
+    /* ---- sizes -------------------------------------------------------- */
+    int32_t n_nodes;          /* N  = len(nodesAll)                                      */
+    int32_t n_nodes_ext;      /* NX >= N                                                 */
+    int32_t n_states;         /* M  = len(model)                                         */
+    int32_t n_parts;          /* P  = len(partitionsToAssign)                            */
+    int32_t n_prev;           /* len(prevMap): NumPartitions of sweep 1 (plan.go:161)    */
+    int32_t n_loads;          /* entries in load_*                                       */
+    int32_t n_rules;          /* entries in rule_inc/rule_exc                            */
+    int32_t n_vertices;       /* VX (0 when hierarchy_rules_nil)                         */
+    int32_t max_iterations;   /* MaxIterationsPerPlan (plan.go:21)                       */
+
+    /* ---- flags -------------------------------------------------------- */
+    int32_t partition_weights_nil;  /* opts.PartitionWeights == nil (plan.go:105,:270)   */
+    int32_t nodes_to_add_nil;       /* nodesToAdd == nil (plan.go:554)                   */
+    int32_t hierarchy_rules_nil;    /* opts.HierarchyRules == nil (plan.go:174)          */
+    int32_t booster_kind;           /* BLANCE_BOOSTER_*                                  */
+    int32_t top_state;              /* state id of minimum Priority (plan.go:126-132)    */
+
+    /* ---- model, by state id ------------------------------------------ */
+    const int32_t* state_priority;        /* [M] PartitionModelState.Priority            */
+    const int32_t* state_constraints;     /* [M] effective k: ModelStateConstraints
+                                                 override applied (plan.go:308-319)      */
+    const int32_t* state_stickiness;      /* [M] opts.StateStickiness[state]             */
+    const uint8_t* state_has_stickiness;  /* [M] key present (0 everywhere if map nil)   */
+
+    /* ---- nodes, by node id ------------------------------------------- */
+    const uint8_t* node_removed;      /* [NX] in nodesToRemove                           */
+    const uint8_t* node_added;        /* [NX] in nodesToAdd                              */
+    const int32_t* node_weight;       /* [NX] opts.NodeWeights[node]                     */
+    const uint8_t* node_has_weight;   /* [NX] key present (0 everywhere if map nil)      */
+
+    /* ---- partitions of partitionsToAssign, by partition id ------------ */
+    const int32_t* part_order;        /* [P] partition ids ordered by the static part of
+                                             partitionSorter's key (weight desc, numeric
+                                             name, name), plan.go:519-540; the per-pass
+                                             category "0/1/2" (plan.go:542-561) is
+                                             applied on the device as a stable 3-way
+                                             partition of this order                     */
+    const int32_t* part_weight;       /* [P] opts.PartitionWeights[name]                 */
+    const uint8_t* part_has_weight;   /* [P]                                             */
+    const uint8_t* part_in_prev;      /* [P] name is a key of prevMap                    */
+    const uint8_t* part_prev_never_equal; /* [P] prevMap[name] can never DeepEqual a
+                                             result (nil NodesByState map, non-model
+                                             state keys, Name != key)                    */
+    /* partitionsToAssign[p].NodesByState[state], CSR over (p * M + state) */
+    const int32_t* assign_off;        /* [P*M + 1]                                       */
+    const int32_t* assign_nodes;      /* [assign_off[P*M]] node ids, list order kept     */
+    const uint8_t* assign_kind;       /* [P*M] BLANCE_LIST_*                             */
+    /* prevMap[name].NodesByState[state] for the same partitions (empty when
+     * !part_in_prev) */
+    const int32_t* prev_off;          /* [P*M + 1]                                       */
+    const int32_t* prev_nodes;
+    const uint8_t* prev_kind;         /* [P*M]                                           */
+
+    /* ---- extra prevMap loads (countStateNodes, plan.go:374-399) -------- */
+    /* One entry per (partition, state, node) occurrence that the CSR above does
+     * not carry: partitions that are only in prevMap, and non-model states. */
+    const int32_t* load_state;        /* [n_loads] 0..M (M = "other")                    */
+    const int32_t* load_node;         /* [n_loads] node id                               */
+    const int32_t* load_weight;       /* [n_loads] the partition's weight                */
+    const uint8_t* load_first_sweep_only; /* [n_loads] entry belongs to a partition that
+                                             is also in partitionsToAssign, so sweep 1's
+                                             write-back (plan.go:49-52) replaces it      */
+
+    /* ---- hierarchy (plan.go:703-774) ---------------------------------- */
+    const int32_t* rule_off;          /* [M + 1] rules of state s: rule_off[s]..[s+1]    */
+    const int32_t* rule_inc;          /* [n_rules] HierarchyRule.IncludeLevel            */
+    const int32_t* rule_exc;          /* [n_rules] HierarchyRule.ExcludeLevel            */
+    int32_t        vertex_empty;      /* vertex id of ""                                 */
+    const int32_t* vertex_parent;     /* [VX] NodeHierarchy[v], vertex_empty if missing  */
+    const int32_t* vertex_leaf_lo;    /* [VX] leaves(v) = leaf positions [lo, hi) in a   */
+    const int32_t* vertex_leaf_hi;    /* [VX] DFS over children sorted by name           */
+    const int32_t* node_leaf_pos;     /* [NX] leaf position of the node, -1 if the node
+                                             has children (it is then never a leaf)      */
+} blance_problem;
+
+typedef struct blance_result {
+    /* nextMap[p].NodesByState[state], CSR over (p * M + state); caller allocates */
+    int32_t* out_off;         /* [P*M + 1]                                               */
+    int32_t* out_nodes;       /* [out_capacity]                                          */
+    uint8_t* out_kind;        /* [P*M]                                                   */
+    int64_t  out_capacity;    /* in: capacity of out_nodes (blance_result_capacity())    */
+    /* warnings of the last sweep (plan.go:70,:231-235): one (partition, state)
+     * pair per message, grouped by pass, in processing order */
+    int32_t* warn_part;       /* [warn_capacity]                                         */
+    int32_t* warn_state;      /* [warn_capacity]                                         */
+    int64_t  warn_capacity;   /* in: P*M always suffices                                 */
+    int64_t  n_warnings;      /* out                                                     */
+    int32_t  iterations;      /* out: sweeps run (1..max_iterations)                     */
+    int32_t  converged;       /* out: loop left through plan.go:43-45                    */
+    /* out: timings of this call */
+    double   device_ms;       /* first kernel -> last kernel, hipEvents                  */
+    double   total_ms;        /* incl. H2D / D2H of problem and result                   */
+    /* out: engine statistics (steps = findBestNodes calls) */
+    int64_t  steps_total;
+    int64_t  steps_sequential;    /* steps resolved one at a time                        */
+    int64_t  steps_batched;       /* steps resolved by an exact parallel schedule        */
+    int64_t  kernel_launches;
+} blance_result;
+
+typedef struct blance_options {
+    int32_t engine;           /* BLANCE_ENGINE_*                                         */
+    int32_t device_id;        /* HIP device ordinal                                      */
+    int32_t reserved[6];
+} blance_options;
+
+typedef struct blance_ctx blance_ctx;   /* opaque: device buffers, stream, events */
+
+/* Upper bound on out_nodes entries for a problem: sum over (p, state) of
+ * max(constraints, len(assign list)). */
+int64_t blance_result_capacity(const blance_problem* pb);
+
+/* Create / destroy a planner context bound to one gfx950 device. */
+int blance_ctx_create(const blance_options* opt, blance_ctx** out);
+void blance_ctx_destroy(blance_ctx* ctx);
+
+/* Run planNextMapEx (plan.go:23-58) for one problem.  Host buffers in, host
+ * buffers out.  Re-entrant per context (calls on one ctx are serialised). */
+int blance_plan(blance_ctx* ctx, const blance_problem* pb, blance_result* res);
+
+/* Device-resident variant used by the benchmark: upload once, plan many times,
+ * download once.  blance_plan() == upload + plan_resident + download. */
+int blance_upload(blance_ctx* ctx, const blance_problem* pb);
+int blance_plan_resident(blance_ctx* ctx, blance_result* res /* timings+stats only */);
+int blance_download(blance_ctx* ctx, blance_result* res);
+
+/* Validate a problem without touching a device (sizes, id ranges, supported
+ * envelope).  Same status codes as blance_plan. */
+int blance_validate(const blance_problem* pb);
+
+/* Text of the last error on this thread ("" if none). */
+const char* blance_last_error(void);
+
+int blance_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLANCE_HIP_H */

@@ -1,0 +1,142 @@
+"""Seeded random PlanNextMapEx() inputs (API level: dicts of strings) used to
+cross-check the oracles and the HIP path.  Covers the reference's feature set:
+add/remove nodes, partition weights, node weights (incl. negative + booster),
+stickiness, multi-primary, 0-constraint states, hierarchy rules on ragged
+trees, prevMap != partitionsToAssign, nodes outside nodesAll."""
+import random
+
+
+def random_case(seed, max_nodes=12, max_parts=24):
+    rng = random.Random(seed)
+    n_nodes = rng.randint(1, max_nodes)
+    nodes = ["n%02d" % i for i in range(n_nodes)]
+    rng.shuffle(nodes)
+    n_parts = rng.randint(0, max_parts)
+    numeric = rng.random() < 0.6
+    pnames = [str(i) if numeric else "p%03d" % i for i in range(n_parts)]
+    if numeric and rng.random() < 0.3 and n_parts > 2:
+        pnames[1] = "x" + pnames[1]           # mixed numeric / non numeric names
+
+    model_kind = rng.choice(["p", "pr", "pr", "pr2", "p2r", "prx"])
+    if model_kind == "p":
+        model = {"primary": {"priority": 0, "constraints": 1}}
+    elif model_kind == "pr":
+        model = {"primary": {"priority": 0, "constraints": 1},
+                 "replica": {"priority": 1, "constraints": rng.choice([0, 1, 1, 2])}}
+    elif model_kind == "pr2":
+        model = {"primary": {"priority": 0, "constraints": 1},
+                 "replica": {"priority": 1, "constraints": 2}}
+    elif model_kind == "p2r":
+        model = {"primary": {"priority": 0, "constraints": 2},
+                 "replica": {"priority": 1, "constraints": 1}}
+    else:
+        model = {"primary": {"priority": 0, "constraints": 1},
+                 "replica": {"priority": 1, "constraints": 1},
+                 "zreadonly": {"priority": 2, "constraints": rng.choice([0, 1])}}
+    states = list(model.keys())
+
+    # an existing layout for some partitions
+    extra_nodes = ["gone1", "gone2"] if rng.random() < 0.2 else []
+    pool = nodes + extra_nodes
+
+    def random_nbs(full):
+        nbs = {}
+        avail = pool[:]
+        rng.shuffle(avail)
+        for s in states:
+            if not full and rng.random() < 0.3:
+                continue
+            k = max(model[s]["constraints"], 0)
+            cnt = rng.choice([0, k, k, max(k - 1, 0), k + 1]) if full else rng.choice([0, k])
+            lst = [avail.pop() for _ in range(min(cnt, len(avail)))]
+            r = rng.random()
+            if not lst and r < 0.15:
+                nbs[s] = None
+            else:
+                nbs[s] = lst
+        return nbs
+
+    mode = rng.choice(["fresh", "aliased", "aliased", "separate"])
+    prev, assign = {}, {}
+    if mode == "fresh":
+        for p in pnames:
+            assign[p] = {"name": p, "nodesByState": {}}
+    elif mode == "aliased":
+        for p in pnames:
+            prev[p] = {"name": p, "nodesByState": random_nbs(True)}
+        assign = None
+    else:
+        for p in pnames:
+            if rng.random() < 0.8:
+                prev[p] = {"name": p, "nodesByState": random_nbs(True)}
+            assign[p] = {"name": p, "nodesByState": random_nbs(rng.random() < 0.7)}
+        for j in range(rng.randint(0, 3)):      # partitions only in prevMap
+            q = "only%d" % j
+            nbs = random_nbs(True)
+            if rng.random() < 0.3:
+                nbs["dead"] = [rng.choice(pool)]
+            prev[q] = {"name": q, "nodesByState": nbs}
+
+    n_rm = rng.choice([0, 0, 1, 2]) if n_nodes > 2 else 0
+    to_remove = rng.sample(nodes, min(n_rm, n_nodes))
+    rest = [n for n in nodes if n not in to_remove]
+    n_add = rng.choice([0, 0, 1, 2, len(rest)])
+    to_add = rng.sample(rest, min(n_add, len(rest)))
+    r = rng.random()
+    nodes_to_add = None if r < 0.15 else to_add
+    nodes_to_remove = None if (not to_remove and rng.random() < 0.2) else to_remove
+    if to_remove and mode == "separate":
+        # reference panics when a partition to assign is missing from prevMap
+        for p in pnames:
+            prev.setdefault(p, {"name": p, "nodesByState": random_nbs(True)})
+
+    opts = {"modelStateConstraints": None, "partitionWeights": None, "stateStickiness": None,
+            "nodeWeights": None, "nodeHierarchy": None, "hierarchyRules": None}
+    if rng.random() < 0.2:
+        s = rng.choice(states)
+        opts["modelStateConstraints"] = {s: rng.choice([0, 1, 2, 3])}
+    if rng.random() < 0.4:
+        opts["partitionWeights"] = {p: rng.choice([1, 2, 3, 10, 100])
+                                    for p in pnames if rng.random() < 0.5}
+    if rng.random() < 0.3:
+        opts["stateStickiness"] = {s: rng.choice([0, 1, 5, 1000]) for s in states if rng.random() < 0.7}
+    booster = None
+    if rng.random() < 0.4:
+        neg = rng.random() < 0.3
+        opts["nodeWeights"] = {n: (rng.choice([-3, -2, -1, 0, 1, 2, 3]) if neg else rng.choice([1, 2, 3, 4]))
+                               for n in nodes if rng.random() < 0.6}
+        if neg and rng.random() < 0.7:
+            booster = "cbgt"
+    if rng.random() < 0.5:
+        # ragged tree: racks of random size, some racks in zones, some nodes unparented
+        hier = {}
+        racks = ["r%d" % i for i in range(rng.randint(1, 4))]
+        zones = ["z%d" % i for i in range(rng.randint(1, 2))]
+        for n in nodes + (["ghost"] if rng.random() < 0.2 else []):
+            if rng.random() < 0.9:
+                hier[n] = rng.choice(racks)
+        for rk in racks:
+            if rng.random() < 0.8:
+                hier[rk] = rng.choice(zones)
+        if rng.random() < 0.2:
+            hier["emptyrack"] = zones[0]
+        opts["nodeHierarchy"] = hier
+        rules = {}
+        for s in states[1:]:
+            if rng.random() < 0.8:
+                rl = []
+                for _ in range(rng.choice([1, 1, 1, 2])):
+                    inc = rng.choice([1, 2, 2, 3])
+                    exc = rng.choice([0, 1, 1, 2])
+                    rl.append({"includeLevel": inc, "excludeLevel": exc})
+                rules[s] = rl
+        if rng.random() < 0.15:
+            rules[states[0]] = [{"includeLevel": 1, "excludeLevel": 0}]
+        opts["hierarchyRules"] = rules
+    elif rng.random() < 0.1:
+        opts["hierarchyRules"] = {}
+    case = {"prevMap": prev, "partitionsToAssign": assign, "aliased": assign is None,
+            "nodesAll": nodes, "nodesToRemove": nodes_to_remove, "nodesToAdd": nodes_to_add,
+            "model": model, "booster": booster, "seed": seed}
+    case.update(opts)
+    return case

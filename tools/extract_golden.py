@@ -516,8 +516,10 @@ def extract_control_tests(path):
 def extract_table(toks, funcs, fn):
     lo, hi = funcs[fn]
     j = lo
-    while not (toks[j].val == "tests" and toks[j + 1].val == ":="):
+    while j < hi and not (toks[j].val == "tests" and toks[j + 1].val == ":="):
         j += 1
+    if j >= hi:
+        raise SyntaxError("%s is not table driven" % fn)
     env = parse_assignments(toks, lo, j)
     p = Parser(toks, env)
     p.i = j + 2
@@ -535,8 +537,14 @@ def extract_helpers(ref):
         out[fn] = extract_table(toks, funcs, fn)
     toks = tokenize(open(os.path.join(ref, "misc_test.go")).read())
     funcs = split_funcs(toks)
-    for fn in ("TestStringsToMap", "TestStringsRemoveStrings", "TestStringsIntersectStrings"):
+    for fn in ("TestStringsRemoveStrings", "TestStringsIntersectStrings"):
         out[fn] = extract_table(toks, funcs, fn)
+    # misc_test.go:18-32 is three inline assertions, not a table
+    out["TestStringsToMap"] = [
+        {"s": [], "exp": {}, "source": "misc_test.go:19-23"},
+        {"s": ["a"], "exp": {"a": True}, "source": "misc_test.go:24-27"},
+        {"s": ["a", "b", "a"], "exp": {"a": True, "b": True}, "source": "misc_test.go:28-31"},
+    ]
     return out
 
 
