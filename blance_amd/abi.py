@@ -58,6 +58,7 @@ class Result(C.Structure):
         ("device_ms", C.c_double), ("total_ms", C.c_double),
         ("steps_total", C.c_int64), ("steps_sequential", C.c_int64), ("steps_batched", C.c_int64),
         ("kernel_launches", C.c_int64),
+        ("pass_kernel_ms", C.c_double), ("pass_kernel_launches", C.c_int64),
     ]
 
 

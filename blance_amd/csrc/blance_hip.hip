@@ -1,0 +1,1294 @@
+// MI355X (gfx950) implementation of blance's planNextMapEx (plan.go:23-58) behind
+// the C ABI of include/blance_hip.h.  One blance_plan() call runs the whole
+// convergence loop on the device; the host only sequences kernels and reads
+// one convergence word per sweep.  See DESIGN.md for the kernel inventory.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// (fp64 scores must keep the reference's operation order, plan.go:634-689).
+#ifndef BLANCE_SIMT_EMU
+#include <hip/hip_runtime.h>
+#define BLANCE_LAUNCH(kern, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+#define BLANCE_LAUNCH_NOSYNC BLANCE_LAUNCH   /* kernel has no barrier / cross-lane op */
+#define BLANCE_DYN_LDS(ptr)                                        \
+    extern __shared__ __align__(16) unsigned char blance_lds_[];   \
+    unsigned char* ptr = blance_lds_
+#endif
+
+#include <limits.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/blance_hip.h"
+#include "blance_kernels.h"
+
+namespace blance {
+
+// ============================================================================
+// Device helpers
+// ============================================================================
+
+// nodeSorter.Score, plan.go:634-689, in the reference's operation order.
+// Absent map keys are zeros here: x + 0.0 and x - 0.0 are exact.
+__device__ __forceinline__ double node_score(int cnt, int ntn, int tot, int hasw, int w, int NP,
+                                             double cf, int booster) {
+    double lp = 0.0, ff = 0.0;
+    if (NP > 0) {
+        lp = (double)ntn / (double)NP;              // plan.go:638-644
+        ff = (0.001 * (double)tot) / (double)NP;    // plan.go:647-652
+    }
+    double r = (double)cnt;                         // plan.go:664-670
+    r = r + lp;
+    r = r + ff;
+    if (hasw) {                                     // plan.go:675-684
+        if (w > 0) {
+            r = r / (double)w;
+        } else if (w < 0 && booster == BLANCE_BOOSTER_CBGT) {
+            double b = (double)(-w);                // control_test.go:19-26
+            if (b < cf) b = cf;
+            r = r + b;
+        }
+    }
+    r = r - cf;                                     // plan.go:686
+    return r;
+}
+
+// nodeSorter.Less, plan.go:617-628: (score, position) ascending, strict total order.
+__device__ __forceinline__ bool better(double s1, int n1, double s2, int n2) {
+    return s1 < s2 || (s1 == s2 && n1 < n2);
+}
+
+__device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+struct RedSlot { double s; int n; int pad; };
+
+// Lexicographic (score, position) argmin over a workgroup of T threads.
+// One barrier per call; slots are double-buffered by call parity.
+template <int T>
+__device__ __forceinline__ int block_argmin(double s, int n, RedSlot* red, int& round) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double s2 = __shfl_xor(s, off, 64);
+        int n2 = __shfl_xor(n, off, 64);
+        if (better(s2, n2, s, n)) { s = s2; n = n2; }
+    }
+    constexpr int W = T / 64;
+    if (W == 1) return n;
+    RedSlot* slot = red + (round & 1) * W;
+    round++;
+    if ((threadIdx.x & 63) == 0) {
+        slot[threadIdx.x >> 6].s = s;
+        slot[threadIdx.x >> 6].n = n;
+    }
+    __syncthreads();
+    double bs = slot[0].s;
+    int bn = slot[0].n;
+#pragma unroll
+    for (int j = 1; j < W; j++) {
+        double s2 = slot[j].s;
+        int n2 = slot[j].n;
+        if (better(s2, n2, bs, bn)) { bs = s2; bn = n2; }
+    }
+    return bn;
+}
+
+// Running value of includeExcludeNodesIntersect (plan.go:738-753) as leaf-interval
+// algebra: one include interval minus a few excluded sub-intervals.  Leaf
+// intervals of tree vertices are laminar (nested or disjoint), which keeps
+// every intermediate in this form (DESIGN.md "Hierarchy masks").
+struct Fold {
+    int empty;
+    int ilo, ihi;
+    int nx;
+    int xlo[kMaxAnchors], xhi[kMaxAnchors];
+};
+
+__device__ __forceinline__ void fold_push_x(Fold& f, int lo, int hi, int* err) {
+    // clip to the include interval (laminar: disjoint, inside, or covering)
+    if (hi <= f.ilo || lo >= f.ihi) return;
+    if (lo <= f.ilo && hi >= f.ihi) { f.empty = 1; return; }
+    bool dup = false;
+#pragma unroll
+    for (int j = 0; j < kMaxAnchors; j++)
+        if (j < f.nx && f.xlo[j] == lo && f.xhi[j] == hi) dup = true;
+    if (dup) return;
+    if (f.nx >= kMaxAnchors) { *err = 1; return; }
+#pragma unroll
+    for (int j = 0; j < kMaxAnchors; j++)
+        if (j == f.nx) { f.xlo[j] = lo; f.xhi[j] = hi; }
+    f.nx++;
+}
+
+__device__ __forceinline__ void fold_check_empty(Fold& f) {
+    if (f.empty) return;
+    int covered = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxAnchors; i++) {
+        if (i >= f.nx) continue;
+        bool nested = false;
+#pragma unroll
+        for (int j = 0; j < kMaxAnchors; j++)
+            if (j < f.nx && j != i && f.xlo[j] <= f.xlo[i] && f.xhi[i] <= f.xhi[j]) nested = true;
+        if (!nested) covered += f.xhi[i] - f.xlo[i];
+    }
+    if (covered >= f.ihi - f.ilo) f.empty = 1;
+}
+
+// One step of the fold: rv = (len(rv) == 0) ? set(a) : rv ∩ set(a)   (plan.go:744-750)
+__device__ __forceinline__ void fold_step(Fold& f, AnchorSet a, int* err) {
+    bool set_empty = (a.blo <= a.alo && a.bhi >= a.ahi);   // exclude covers include
+    if (f.empty) {
+        f.empty = set_empty ? 1 : 0;
+        f.ilo = a.alo; f.ihi = a.ahi; f.nx = 0;
+        if (!set_empty) fold_push_x(f, a.blo, a.bhi, err);
+        return;
+    }
+    if (set_empty) { f.empty = 1; return; }
+    // include ∩ include
+    int lo = f.ilo > a.alo ? f.ilo : a.alo;
+    int hi = f.ihi < a.ahi ? f.ihi : a.ahi;
+    if (lo >= hi) { f.empty = 1; return; }
+    int onx = f.nx;
+    int olo[kMaxAnchors], ohi[kMaxAnchors];
+#pragma unroll
+    for (int j = 0; j < kMaxAnchors; j++) { olo[j] = f.xlo[j]; ohi[j] = f.xhi[j]; }
+    f.ilo = lo; f.ihi = hi; f.nx = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxAnchors; j++)
+        if (j < onx && !f.empty) fold_push_x(f, olo[j], ohi[j], err);
+    if (!f.empty) fold_push_x(f, a.blo, a.bhi, err);
+    fold_check_empty(f);
+}
+
+__device__ __forceinline__ bool fold_contains(const Fold& f, int pos) {
+    if (f.empty || pos < f.ilo || pos >= f.ihi) return false;
+    bool in = true;
+#pragma unroll
+    for (int j = 0; j < kMaxAnchors; j++)
+        if (j < f.nx && pos >= f.xlo[j] && pos < f.xhi[j]) in = false;
+    return in;
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ============================================================================
+// The sequential state pass: assignStateToPartitions (plan.go:253-303) with
+// findBestNodes (plan.go:98-248) inlined.  ONE workgroup walks the partitions
+// in pass order; thread t owns nodes t, t+T, ... and keeps their load counts,
+// total counts, weights and partition-independent scores in registers, so a
+// step costs one barrier per argmin and no table traffic.
+// ============================================================================
+template <int T, int NPT>
+__global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
+    BLANCE_DYN_LDS(lds);
+    RedSlot* red = (RedSlot*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k;
+    const int SW = 1 + L;                        // words per state inside a record
+    int round = 0;
+
+    int cntv[NPT], totv[NPT], wv[NPT], lpos[NPT];
+    unsigned alive_m = 0, hasw_m = 0;
+    double g[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        int n = tid + i * T;
+        cntv[i] = 0; totv[i] = 0; wv[i] = 0; lpos[i] = -1; g[i] = 0.0;
+        if (n < NX) {
+            cntv[i] = q.cnt[s * NX + n];
+            int tsum = 0;
+            for (int t = 0; t <= M; t++) tsum += q.cnt[t * NX + n];   // plan.go:118-124
+            totv[i] = tsum;
+            wv[i] = q.node_weight[n];
+            if (q.node_has_weight[n]) hasw_m |= 1u << i;
+            if (n < N && q.alive[n]) alive_m |= 1u << i;
+            lpos[i] = q.node_leaf_pos[n];
+            g[i] = node_score(cntv[i], 0, totv[i], (hasw_m >> i) & 1, wv[i], NP, 0.0, q.booster_kind);
+        }
+    }
+
+    // step record of the current partition: lane j of every wave holds word j
+    int recw = 0, recw_next = 0;
+    if (q.P > 0 && lane < q.RW) recw_next = q.rec[lane];
+
+    for (int oi = 0; oi < q.P; oi++) {
+        recw = recw_next;
+        if (oi + 1 < q.P && lane < q.RW) recw_next = q.rec[(size_t)(oi + 1) * q.RW + lane];
+#define REC(i) __builtin_amdgcn_readlane(recw, (i))
+        const int p = REC(0);
+        const int w = REC(1);
+        const double stick = __hiloint2double(REC(3), REC(2));
+        // topPriorityNode, plan.go:134-138
+        int top = -1;
+        {
+            int hdr = REC(kRecHead + q.top_state * SW);
+            if ((hdr >> 16) != kListAbsent && (hdr & 0xffff) > 0) top = REC(kRecHead + q.top_state * SW + 1);
+        }
+        const int row = top < 0 ? NX : top;
+
+        // nodeToNodeCounts row of the top priority node (only read when NP > 0, plan.go:638)
+        int ntnv[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            int n = tid + i * T;
+            ntnv[i] = (NP > 0 && n < N) ? q.ntn[(size_t)row * N + n] : 0;
+        }
+
+        // membership of my nodes in the higher-priority lists (plan.go:146-154)
+        // and in this state's current list (plan.go:654-662)
+        unsigned inh_m = 0, own_m = 0;
+        int any_higher_key = 0;
+        for (int t = 0; t < M; t++) {
+            int hdr = REC(kRecHead + t * SW);
+            if ((hdr >> 16) == kListAbsent) continue;
+            int len = hdr & 0xffff;
+            bool higher = (q.higher_mask >> t) & 1;
+            if (higher) any_higher_key = 1;
+            if (!higher && t != s) continue;
+            for (int j = 0; j < len; j++) {
+                int x = REC(kRecHead + t * SW + 1 + j);
+#pragma unroll
+                for (int i = 0; i < NPT; i++) {
+                    if (x == tid + i * T) {
+                        if (higher) inh_m |= 1u << i;
+                        if (t == s) own_m |= 1u << i;
+                    }
+                }
+            }
+        }
+        const unsigned elig_m = alive_m & ~inh_m;
+
+        double sc[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            bool own = (own_m >> i) & 1;
+            if (own || ntnv[i] != 0)
+                sc[i] = node_score(cntv[i], ntnv[i], totv[i], (hasw_m >> i) & 1, wv[i], NP,
+                                   own ? stick : 0.0, q.booster_kind);
+            else
+                sc[i] = g[i];
+        }
+
+        int chosen[kMaxK];
+#pragma unroll
+        for (int j = 0; j < kMaxK; j++) chosen[j] = -1;
+        int n_out = 0;
+        unsigned emitted_m = 0;                    // my nodes already in the output list
+
+        if (q.hier) {                              // plan.go:174-226
+            int hn[kMaxAnchors];
+#pragma unroll
+            for (int j = 0; j < kMaxAnchors; j++) hn[j] = -1;
+            int n_hn = 0;
+            int cand0 = -2;                        // candidateNodes[0], computed lazily
+            int err = 0;
+            for (int r = q.rule_begin; r < q.rule_end; r++) {
+                const AnchorSet* tab = q.anchors + (size_t)r * (NX + 1);
+                int h = top < 0 ? q.vertex_empty_anchor : top;
+                if (top < 0 && n_hn > 0) h = hn[0];
+                Fold f;
+                f.empty = 1; f.ilo = 0; f.ihi = 0; f.nx = 0;
+#pragma unroll
+                for (int j = 0; j < kMaxAnchors; j++) { f.xlo[j] = 0; f.xhi[j] = 0; }
+                {
+                    AnchorSet a = tab[h];
+                    a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
+                    fold_step(f, a, &err);
+                }
+#pragma unroll
+                for (int j = 0; j < kMaxAnchors; j++) {
+                    if (j < n_hn) {
+                        AnchorSet a = tab[hn[j]];
+                        a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
+                        fold_step(f, a, &err);
+                    }
+                }
+                for (int i = 0; i < k; i++) {
+                    // best node of the rule's set ∩ nodesNext − higher priority nodes (plan.go:185-212)
+                    double bs = pos_inf();
+                    int bn = INT_MAX;
+#pragma unroll
+                    for (int u = 0; u < NPT; u++) {
+                        if (((elig_m >> u) & 1) && lpos[u] >= 0 && fold_contains(f, lpos[u]) &&
+                            better(sc[u], tid + u * T, bs, bn)) {
+                            bs = sc[u]; bn = tid + u * T;
+                        }
+                    }
+                    int best = uni(block_argmin<T>(bs, bn, red, round));
+                    int pick = -1;
+                    if (best != INT_MAX) {
+                        pick = best;
+                    } else {                        // plan.go:216-218
+                        if (cand0 == -2) {
+                            double cs = pos_inf();
+                            int cn = INT_MAX;
+#pragma unroll
+                            for (int u = 0; u < NPT; u++) {
+                                if (((elig_m >> u) & 1) && better(sc[u], tid + u * T, cs, cn)) {
+                                    cs = sc[u]; cn = tid + u * T;
+                                }
+                            }
+                            cand0 = uni(block_argmin<T>(cs, cn, red, round));
+                            if (cand0 == INT_MAX) cand0 = -1;
+                        }
+                        pick = cand0;
+                    }
+                    if (pick >= 0) {
+                        if (n_hn >= kMaxAnchors - 1) { err = 1; }
+                        else {
+#pragma unroll
+                            for (int j = 0; j < kMaxAnchors; j++) if (j == n_hn) hn[j] = pick;
+                            n_hn++;
+                            AnchorSet a = tab[pick];
+                            a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
+                            fold_step(f, a, &err);
+                        }
+                    }
+                }
+            }
+            if (err && tid == 0) *q.err = 1;
+            // candidateNodes = dedupe(hierarchyNodes ++ candidateNodes), plan.go:224-225
+#pragma unroll
+            for (int j = 0; j < kMaxAnchors; j++) {
+                if (j < n_hn && n_out < k) {
+                    int x = hn[j];
+                    bool dup = false;
+#pragma unroll
+                    for (int c = 0; c < kMaxK; c++) if (c < n_out && chosen[c] == x) dup = true;
+                    if (!dup) {
+#pragma unroll
+                        for (int c = 0; c < kMaxK; c++) if (c == n_out) chosen[c] = x;
+                        n_out++;
+#pragma unroll
+                        for (int u = 0; u < NPT; u++) if (x == tid + u * T) emitted_m |= 1u << u;
+                    }
+                }
+            }
+        }
+        // the sorted candidate list consumed lazily (plan.go:171-172, :228-235)
+        while (n_out < k) {
+            double bs = pos_inf();
+            int bn = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < NPT; u++) {
+                if (((elig_m & ~emitted_m) >> u) & 1) {
+                    if (better(sc[u], tid + u * T, bs, bn)) { bs = sc[u]; bn = tid + u * T; }
+                }
+            }
+            int best = uni(block_argmin<T>(bs, bn, red, round));
+            if (best == INT_MAX) break;
+#pragma unroll
+            for (int c = 0; c < kMaxK; c++) if (c == n_out) chosen[c] = best;
+            n_out++;
+#pragma unroll
+            for (int u = 0; u < NPT; u++) if (best == tid + u * T) emitted_m |= 1u << u;
+        }
+
+        // ---- commit (plan.go:238-245, :290-301); every thread updates the nodes it owns
+        unsigned changed_m = 0;
+        for (int t = 0; t < M; t++) {
+            int hdr = REC(kRecHead + t * SW);
+            if ((hdr >> 16) == kListAbsent) continue;
+            int len = hdr & 0xffff;
+            for (int j = 0; j < len; j++) {
+                int x = REC(kRecHead + t * SW + 1 + j);
+                bool hit = (t == s);
+                if (!hit) {
+                    // x also held this state (plan.go:290-293) or was chosen now (plan.go:294-297)
+                    int hs = REC(kRecHead + s * SW);
+                    if ((hs >> 16) != kListAbsent) {
+                        int ls = hs & 0xffff;
+                        for (int jj = 0; jj < ls; jj++)
+                            if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
+                    }
+#pragma unroll
+                    for (int c = 0; c < kMaxK; c++) if (c < n_out && chosen[c] == x) hit = true;
+                }
+                if (!hit) continue;
+#pragma unroll
+                for (int u = 0; u < NPT; u++) {
+                    if (x == tid + u * T) {
+                        totv[u] -= w;
+                        if (t == s) cntv[u] -= w;
+                        changed_m |= 1u << u;
+                    }
+                }
+                if (t != s && tid == 0) q.cnt[t * NX + x] -= w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxK; c++) {
+            if (c < n_out) {
+                int x = chosen[c];
+#pragma unroll
+                for (int u = 0; u < NPT; u++) {
+                    if (x == tid + u * T) {
+                        cntv[u] += w;
+                        totv[u] += w;
+                        changed_m |= 1u << u;
+                        if (NP > 0) q.ntn[(size_t)row * N + x] = ntnv[u] + 1;   // plan.go:238-245
+                    }
+                }
+            }
+        }
+        if (changed_m) {
+#pragma unroll
+            for (int u = 0; u < NPT; u++)
+                if ((changed_m >> u) & 1)
+                    g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
+        }
+        if (tid == 0) {
+            int is_nil = (n_out == 0 && q.n_alive == 0 && !any_higher_key && !q.hier);
+            int* o = q.out + (size_t)oi * q.OW;
+            o[0] = n_out | (is_nil << 16);
+#pragma unroll
+            for (int c = 0; c < kMaxK; c++) if (c < k) o[1 + c] = chosen[c];
+            if (n_out < k) {                       // plan.go:230-235
+                int wi = *q.warn_count;
+                q.warn_part[wi] = p;
+                q.warn_state[wi] = s;
+                *q.warn_count = wi + 1;
+            }
+        }
+#undef REC
+    }
+
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        int n = tid + i * T;
+        if (n < NX) q.cnt[s * NX + n] = cntv[i];
+    }
+}
+
+// ============================================================================
+// Data-parallel kernels around the pass
+// ============================================================================
+
+struct DevProblem {   // device pointers + sizes shared by the elementwise kernels
+    int32_t N, NX, M, L, P;
+    int32_t weights_nil;
+    const uint8_t* node_removed;   // view of this sweep (all zero after sweep 1)
+    const uint8_t* node_added;
+    const int32_t* part_weight;
+    const uint8_t* part_has_weight;
+    int32_t* live; int32_t* live_len; uint8_t* live_kind;
+    int32_t* prv;  int32_t* prv_len;  uint8_t* prv_kind;
+    uint8_t* in_prev; uint8_t* never_equal;
+};
+
+// leaf-interval table of every (rule, anchor): plan.go:723-734, :755-774
+__global__ void k_anchor_table(int n_rules, int NX, int vertex_empty, const int32_t* rule_inc,
+                               const int32_t* rule_exc, const int32_t* vparent, const int32_t* vlo,
+                               const int32_t* vhi, AnchorSet* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rules * (NX + 1)) return;
+    int r = i / (NX + 1), a = i % (NX + 1);
+    int v = a == NX ? vertex_empty : a;
+    int vi = v, ve = v;
+    for (int l = rule_inc[r]; l > 0; l--) vi = vparent[vi];   // findAncestor, plan.go:755-762
+    for (int l = rule_exc[r]; l > 0; l--) ve = vparent[ve];
+    AnchorSet s;
+    s.alo = vlo[vi]; s.ahi = vhi[vi]; s.blo = vlo[ve]; s.bhi = vhi[ve];
+    out[i] = s;
+}
+
+// nextPartitions = copy of partitionsToAssign minus nodesToRemove (plan.go:83-88)
+__global__ void k_live_init(DevProblem d, const int32_t* a_off, const int32_t* a_nodes,
+                            const uint8_t* a_kind, const int32_t* p_off, const int32_t* p_nodes,
+                            const uint8_t* p_kind) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    int len = 0;
+    for (int i = a_off[idx]; i < a_off[idx + 1]; i++) {
+        int n = a_nodes[i];
+        if (!d.node_removed[n]) d.live[(size_t)idx * d.L + len++] = n;
+    }
+    d.live_len[idx] = len;
+    d.live_kind[idx] = a_kind[idx] == kListAbsent ? kListAbsent : kListSet;
+    len = 0;
+    for (int i = p_off[idx]; i < p_off[idx + 1]; i++) d.prv[(size_t)idx * d.L + len++] = p_nodes[i];
+    d.prv_len[idx] = len;
+    d.prv_kind[idx] = p_kind[idx];
+}
+
+// sweeps >= 2: every present key is a non-nil slice again (plan.go:418)
+__global__ void k_live_refresh(DevProblem d) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    if (d.live_kind[idx] != kListAbsent) d.live_kind[idx] = kListSet;
+}
+
+// countStateNodes (plan.go:374-399): extra loads ...
+__global__ void k_count_loads(int n_loads, int NX, int later_sweep, const int32_t* st, const int32_t* nd,
+                              const int32_t* wt, const uint8_t* first_only, int32_t* cnt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_loads) return;
+    if (later_sweep && first_only[i]) return;
+    atomicAdd(&cnt[st[i] * NX + nd[i]], wt[i]);
+}
+
+// ... and the prevMap view of the partitions being assigned
+__global__ void k_count_prev(DevProblem d, int32_t* cnt) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    int p = idx / d.M, m = idx % d.M;
+    if (!d.in_prev[p]) return;
+    int w = (!d.weights_nil && d.part_has_weight[p]) ? d.part_weight[p] : 1;
+    for (int i = 0; i < d.prv_len[idx]; i++) atomicAdd(&cnt[m * d.NX + d.prv[(size_t)idx * d.L + i]], w);
+}
+
+// partitionSorter category (plan.go:542-561)
+__global__ void k_category(DevProblem d, int m, int any_removed, int add_nil, uint8_t* cat) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.P) return;
+    int cv = 2;
+    bool is0 = false;
+    if (any_removed && d.in_prev[p]) {
+        int idx = p * d.M + m;
+        if (d.prv_kind[idx] == kListSet)
+            for (int i = 0; i < d.prv_len[idx]; i++)
+                if (d.node_removed[d.prv[(size_t)idx * d.L + i]]) { is0 = true; break; }
+    }
+    if (is0) cv = 0;
+    else if (!add_nil) {
+        bool hit = false;
+        for (int t = 0; t < d.M && !hit; t++) {
+            int idx = p * d.M + t;
+            if (d.live_kind[idx] == kListAbsent) continue;
+            for (int i = 0; i < d.live_len[idx]; i++)
+                if (d.node_added[d.live[(size_t)idx * d.L + i]]) { hit = true; break; }
+        }
+        if (!hit) cv = 1;
+    }
+    cat[p] = (uint8_t)cv;
+}
+
+// Stable 3-way partition of the static order by category (the per-pass part of
+// partitionSorter, plan.go:519-562): chunk counts -> scan -> stable scatter.
+constexpr int kChunk = 1024;
+
+__global__ void k_order_count(int P, const int32_t* static_order, const uint8_t* cat, int n_chunks,
+                              int32_t* counts /* [3][n_chunks] */) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    int beg = c * kChunk, end = beg + kChunk < P ? beg + kChunk : P;
+    int k0 = 0, k1 = 0, k2 = 0;
+    for (int i = beg; i < end; i++) {
+        int cv = cat[static_order[i]];
+        k0 += cv == 0; k1 += cv == 1; k2 += cv == 2;
+    }
+    counts[c] = k0; counts[n_chunks + c] = k1; counts[2 * n_chunks + c] = k2;
+}
+
+__global__ void k_order_scan(int n, int32_t* counts) {   // exclusive scan, single thread: n = 3 * P / 1024
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int acc = 0;
+    for (int i = 0; i < n; i++) { int v = counts[i]; counts[i] = acc; acc += v; }
+}
+
+__global__ void k_order_scatter(int P, const int32_t* static_order, const uint8_t* cat, int n_chunks,
+                                const int32_t* offsets, int32_t* order) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    int beg = c * kChunk, end = beg + kChunk < P ? beg + kChunk : P;
+    int o0 = offsets[c], o1 = offsets[n_chunks + c], o2 = offsets[2 * n_chunks + c];
+    for (int i = beg; i < end; i++) {
+        int p = static_order[i];
+        int cv = cat[p];
+        if (cv == 0) order[o0++] = p; else if (cv == 1) order[o1++] = p; else order[o2++] = p;
+    }
+}
+
+// Step records in pass order: what findBestNodes needs to know about its partition.
+__global__ void k_gather(DevProblem d, int m, int RW, const int32_t* order, const int32_t* state_stickiness,
+                         const uint8_t* state_has_stickiness, int32_t* rec) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    int32_t* r = rec + (size_t)oi * RW;
+    int w = 1;                                         // plan.go:269-275
+    double stick = 1.5;                                // plan.go:104-115
+    if (!d.weights_nil) {
+        if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
+        else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
+    }
+    r[0] = p; r[1] = w;
+    r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    for (int t = 0; t < d.M; t++) {
+        int idx = p * d.M + t;
+        int32_t* rs = r + kRecHead + t * (1 + d.L);
+        int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
+        rs[0] = len | ((int)d.live_kind[idx] << 16);
+        for (int i = 0; i < d.L; i++) rs[1 + i] = i < len ? d.live[(size_t)idx * d.L + i] : -1;
+    }
+}
+
+// Apply the pass's choices to the live lists (plan.go:290-299); list edits only
+// touch the step's own partition, so this runs in parallel after the pass.
+__global__ void k_scatter(DevProblem d, int m, int RW, int OW, const int32_t* order, const int32_t* rec,
+                          const int32_t* out) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    const int32_t* r = rec + (size_t)oi * RW;
+    const int32_t* o = out + (size_t)oi * OW;
+    int n_out = o[0] & 0xffff, is_nil = o[0] >> 16;
+    const int32_t* old_s = r + kRecHead + m * (1 + d.L);
+    int n_old = (old_s[0] >> 16) == kListAbsent ? 0 : (old_s[0] & 0xffff);
+    for (int t = 0; t < d.M; t++) {
+        int idx = p * d.M + t;
+        if (t == m) continue;
+        if (d.live_kind[idx] == kListAbsent) continue;
+        int len = d.live_len[idx], w = 0;
+        int32_t* lst = d.live + (size_t)idx * d.L;
+        for (int i = 0; i < len; i++) {
+            int x = lst[i];
+            bool rm = false;
+            for (int j = 0; j < n_old; j++) rm |= old_s[1 + j] == x;
+            for (int j = 0; j < n_out; j++) rm |= o[1 + j] == x;
+            if (!rm) lst[w++] = x;
+        }
+        d.live_len[idx] = w;
+        d.live_kind[idx] = kListSet;
+    }
+    int idx = p * d.M + m;
+    for (int j = 0; j < n_out; j++) d.live[(size_t)idx * d.L + j] = o[1 + j];
+    d.live_len[idx] = n_out;
+    d.live_kind[idx] = is_nil ? kListNil : kListSet;
+}
+
+// Convergence test (plan.go:36-45) fused with the write-back prevMap[name] =
+// partitionsToAssign[name] = nextMap[name] (plan.go:49-52).
+__global__ void k_converge(DevProblem d, int32_t* not_match) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.P) return;
+    bool diff = !d.in_prev[p] || d.never_equal[p];
+    for (int m = 0; m < d.M; m++) {
+        int idx = p * d.M + m;
+        int len = d.live_len[idx];
+        if (d.live_kind[idx] != d.prv_kind[idx] || len != d.prv_len[idx]) diff = true;
+        for (int i = 0; i < len; i++) {
+            int x = d.live[(size_t)idx * d.L + i];
+            if (!diff && d.prv[(size_t)idx * d.L + i] != x) diff = true;
+            d.prv[(size_t)idx * d.L + i] = x;
+        }
+        d.prv_len[idx] = len;
+        d.prv_kind[idx] = d.live_kind[idx];
+    }
+    d.in_prev[p] = 1;
+    d.never_equal[p] = 0;
+    if (diff) atomicOr(not_match, 1);
+}
+
+}  // namespace blance
+
+// ============================================================================
+// Host side: context, upload, the sweep driver, download
+// ============================================================================
+using namespace blance;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, const char* a = "", long b = 0) {
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPTRY(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(BLANCE_ERR_DEVICE, "%s failed: line %ld", hipGetErrorString(e_), __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct blance_ctx {
+    int device = 0;
+    int engine = BLANCE_ENGINE_AUTO;
+    int force_threads = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+    bool uploaded = false;
+    bool planned = false;
+
+    // host copy of the small parts of the problem
+    blance_problem h{};
+    std::vector<int32_t> state_priority, state_constraints, rule_off;
+    int L = 1, np_later = 0, n_alive = 0, any_removed = 0;
+    int64_t out_capacity = 0;
+
+    // device: problem
+    DevBuf node_removed, node_added, node_weight, node_has_weight, alive, zeros_nx, node_leaf_pos;
+    DevBuf part_order, part_weight, part_has_weight, part_in_prev, part_never_equal;
+    DevBuf a_off, a_nodes, a_kind, p_off, p_nodes, p_kind;
+    DevBuf load_state, load_node, load_weight, load_first;
+    DevBuf rule_inc, rule_exc, vparent, vlo, vhi, anchors;
+    DevBuf state_stick, state_has_stick;
+    // device: working state
+    DevBuf live, live_len, live_kind, prv, prv_len, prv_kind, in_prev, never_equal;
+    DevBuf cnt, ntn, cat, order, chunk_counts, rec, out, warn_part, warn_state, scalars;
+    // scalars: [0] warn_count, [1] not_match, [2] err
+    int32_t iterations = 0, converged = 0;
+    int64_t n_warnings = 0, steps_total = 0, kernel_launches = 0, pass_launches = 0;
+    double device_ms = 0.0, pass_ms = 0.0;
+    std::vector<hipEvent_t> pass_events;     // begin/end pairs around every pass kernel
+
+    void free_all() {
+        DevBuf* all[] = {&node_removed, &node_added, &node_weight, &node_has_weight, &alive, &zeros_nx,
+                         &node_leaf_pos, &part_order, &part_weight, &part_has_weight, &part_in_prev,
+                         &part_never_equal, &a_off, &a_nodes, &a_kind, &p_off, &p_nodes, &p_kind,
+                         &load_state, &load_node, &load_weight, &load_first, &rule_inc, &rule_exc,
+                         &vparent, &vlo, &vhi, &anchors, &state_stick, &state_has_stick, &live,
+                         &live_len, &live_kind, &prv, &prv_len, &prv_kind, &in_prev, &never_equal,
+                         &cnt, &ntn, &cat, &order, &chunk_counts, &rec, &out, &warn_part,
+                         &warn_state, &scalars};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+extern "C" int blance_abi_version(void) { return BLANCE_ABI_VERSION; }
+extern "C" const char* blance_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int64_t blance_result_capacity(const blance_problem* pb) {
+    if (!pb || !pb->assign_off || !pb->state_constraints) return 0;
+    int64_t cap = 0;
+    const int64_t PM = (int64_t)pb->n_parts * pb->n_states;
+    for (int64_t idx = 0; idx < PM; idx++) {
+        int len = pb->assign_off[idx + 1] - pb->assign_off[idx];
+        int k = pb->state_constraints[idx % pb->n_states];
+        cap += len > k ? len : k;
+    }
+    return cap;
+}
+
+extern "C" int blance_validate(const blance_problem* pb) {
+    if (!pb) return fail(BLANCE_ERR_BAD_ARG, "null problem");
+    const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
+    if (N < 0 || NX < N || M < 0 || P < 0 || pb->n_prev < 0 || pb->n_loads < 0 || pb->n_rules < 0 ||
+        pb->max_iterations < 0)
+        return fail(BLANCE_ERR_BAD_ARG, "negative or inconsistent sizes");
+    if ((int64_t)P * (M > 0 ? M : 1) > (int64_t)INT32_MAX / 4) return fail(BLANCE_ERR_UNSUPPORTED, "P*M too large");
+    if (M > kMaxStates) return fail(BLANCE_ERR_UNSUPPORTED, "more than 16 model states");
+    if (M > 0 && (pb->top_state < 0 || pb->top_state >= M)) return fail(BLANCE_ERR_BAD_ARG, "top_state out of range");
+    const void* need[] = {pb->state_priority, pb->state_constraints, pb->state_stickiness, pb->state_has_stickiness,
+                          pb->node_removed, pb->node_added, pb->node_weight, pb->node_has_weight, pb->part_order,
+                          pb->part_weight, pb->part_has_weight, pb->part_in_prev, pb->part_prev_never_equal,
+                          pb->assign_off, pb->assign_nodes, pb->assign_kind, pb->prev_off, pb->prev_nodes,
+                          pb->prev_kind, pb->load_state, pb->load_node, pb->load_weight, pb->load_first_sweep_only,
+                          pb->rule_off, pb->rule_inc, pb->rule_exc, pb->node_leaf_pos};
+    for (const void* q : need) if (!q) return fail(BLANCE_ERR_BAD_ARG, "null array pointer");
+    const int64_t PM = (int64_t)P * M;
+    if (pb->assign_off[0] != 0 || pb->prev_off[0] != 0) return fail(BLANCE_ERR_BAD_ARG, "CSR offsets must start at 0");
+    for (int64_t i = 0; i < PM; i++) {
+        if (pb->assign_off[i + 1] < pb->assign_off[i] || pb->prev_off[i + 1] < pb->prev_off[i])
+            return fail(BLANCE_ERR_BAD_ARG, "CSR offsets not monotone");
+        if (pb->assign_kind[i] > BLANCE_LIST_SET || pb->prev_kind[i] > BLANCE_LIST_SET)
+            return fail(BLANCE_ERR_BAD_ARG, "bad list kind");
+        if (pb->assign_off[i + 1] - pb->assign_off[i] > 0xffff || pb->prev_off[i + 1] - pb->prev_off[i] > 0xffff)
+            return fail(BLANCE_ERR_UNSUPPORTED, "state list longer than 65535");
+    }
+    for (int64_t i = 0; i < pb->assign_off[PM]; i++)
+        if (pb->assign_nodes[i] < 0 || pb->assign_nodes[i] >= NX) return fail(BLANCE_ERR_BAD_ARG, "assign node id out of range");
+    for (int64_t i = 0; i < pb->prev_off[PM]; i++)
+        if (pb->prev_nodes[i] < 0 || pb->prev_nodes[i] >= NX) return fail(BLANCE_ERR_BAD_ARG, "prev node id out of range");
+    {
+        std::vector<uint8_t> seen((size_t)P, 0);
+        for (int i = 0; i < P; i++) {
+            int p = pb->part_order[i];
+            if (p < 0 || p >= P || seen[p]) return fail(BLANCE_ERR_BAD_ARG, "part_order is not a permutation");
+            seen[p] = 1;
+        }
+    }
+    for (int i = 0; i < pb->n_loads; i++)
+        if (pb->load_state[i] < 0 || pb->load_state[i] > M || pb->load_node[i] < 0 || pb->load_node[i] >= NX)
+            return fail(BLANCE_ERR_BAD_ARG, "load entry out of range");
+    for (int m = 0; m < M; m++) {
+        int k = pb->state_constraints[m];
+        if (k > kMaxK) return fail(BLANCE_ERR_UNSUPPORTED, "constraints > 8 for a state");
+        if (pb->rule_off[m + 1] < pb->rule_off[m]) return fail(BLANCE_ERR_BAD_ARG, "rule_off not monotone");
+        if (!pb->hierarchy_rules_nil && k > 0 && (pb->rule_off[m + 1] - pb->rule_off[m]) * k > kMaxAnchors - 1)
+            return fail(BLANCE_ERR_UNSUPPORTED, "more than 8 hierarchy picks per partition and state");
+    }
+    if (M > 0 && pb->rule_off[M] > pb->n_rules) return fail(BLANCE_ERR_BAD_ARG, "rule_off exceeds n_rules");
+    if (!pb->hierarchy_rules_nil) {
+        const int VX = pb->n_vertices;
+        if (VX <= NX || !pb->vertex_parent || !pb->vertex_leaf_lo || !pb->vertex_leaf_hi)
+            return fail(BLANCE_ERR_BAD_ARG, "hierarchy arrays missing");
+        if (pb->vertex_empty < 0 || pb->vertex_empty >= VX) return fail(BLANCE_ERR_BAD_ARG, "vertex_empty out of range");
+        for (int v = 0; v < VX; v++) {
+            if (pb->vertex_parent[v] < 0 || pb->vertex_parent[v] >= VX) return fail(BLANCE_ERR_BAD_ARG, "vertex_parent out of range");
+            if (pb->vertex_leaf_lo[v] < 0 || pb->vertex_leaf_hi[v] <= pb->vertex_leaf_lo[v])
+                return fail(BLANCE_ERR_BAD_ARG, "vertex leaf interval empty");
+        }
+        for (int r = 0; r < pb->n_rules; r++)
+            if (pb->rule_inc[r] < 0 || pb->rule_exc[r] < 0 || pb->rule_inc[r] > 64 || pb->rule_exc[r] > 64)
+                return fail(BLANCE_ERR_UNSUPPORTED, "hierarchy rule level outside 0..64");
+    }
+    if (pb->booster_kind != BLANCE_BOOSTER_NONE && pb->booster_kind != BLANCE_BOOSTER_CBGT)
+        return fail(BLANCE_ERR_UNSUPPORTED, "unknown booster kind");
+    if (NX > 1024 * 8) return fail(BLANCE_ERR_UNSUPPORTED, "more than 8192 node names (register-resident tables)");
+    int L = 1;
+    for (int m = 0; m < M; m++) if (pb->state_constraints[m] > L) L = pb->state_constraints[m];
+    for (int64_t i = 0; i < PM; i++) {
+        int a = pb->assign_off[i + 1] - pb->assign_off[i], b = pb->prev_off[i + 1] - pb->prev_off[i];
+        if (a > L) L = a;
+        if (b > L) L = b;
+    }
+    if (kRecHead + M * (1 + L) > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
+    if ((int64_t)(NX + 1) * (N > 0 ? N : 1) * 4 > (int64_t)64 << 30) return fail(BLANCE_ERR_UNSUPPORTED, "nodeToNodeCounts matrix > 64 GiB");
+    return BLANCE_OK;
+}
+
+extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
+    if (!out) return fail(BLANCE_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(BLANCE_ERR_NO_DEVICE, "no HIP device visible");
+    int dev = opt ? opt->device_id : 0;
+    if (dev < 0 || dev >= n_dev) return fail(BLANCE_ERR_BAD_ARG, "device_id out of range");
+    HIPTRY(hipSetDevice(dev));
+    blance_ctx* c = new blance_ctx();
+    c->device = dev;
+    c->engine = opt ? opt->engine : BLANCE_ENGINE_AUTO;
+    c->force_threads = opt ? opt->reserved[0] : 0;
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(BLANCE_ERR_DEVICE, "stream/event creation failed");
+    }
+    *out = c;
+    return BLANCE_OK;
+}
+
+extern "C" void blance_ctx_destroy(blance_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->free_all();
+    for (hipEvent_t e : c->pass_events) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <class T>
+static int put(blance_ctx* c, DevBuf& b, const T* src, size_t n) {
+    if (b.reserve(n * sizeof(T))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    if (n) HIPTRY(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+#define PUT(buf, src, n) do { int e__ = put(c, c->buf, src, (size_t)(n)); if (e__) return e__; } while (0)
+#define RESERVE(buf, bytes) do { if (c->buf.reserve((size_t)(bytes))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed"); } while (0)
+
+static inline int cdiv(int64_t a, int b) { return (int)((a + b - 1) / b); }
+
+static int upload_locked(blance_ctx* c, const blance_problem* pb) {
+    int st = blance_validate(pb);
+    if (st) return st;
+    HIPTRY(hipSetDevice(c->device));
+    c->uploaded = false;
+    c->planned = false;
+    c->h = *pb;
+    const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
+    const int64_t PM = (int64_t)P * M;
+    c->state_priority.assign(pb->state_priority, pb->state_priority + M);
+    c->state_constraints.assign(pb->state_constraints, pb->state_constraints + M);
+    c->rule_off.assign(pb->rule_off, pb->rule_off + M + 1);
+    int L = 1;
+    for (int m = 0; m < M; m++) if (pb->state_constraints[m] > L) L = pb->state_constraints[m];
+    for (int64_t i = 0; i < PM; i++) {
+        int a = pb->assign_off[i + 1] - pb->assign_off[i], b = pb->prev_off[i + 1] - pb->prev_off[i];
+        if (a > L) L = a;
+        if (b > L) L = b;
+    }
+    c->L = L;
+    int fresh = 0;
+    for (int p = 0; p < P; p++) if (!pb->part_in_prev[p]) fresh++;
+    c->np_later = pb->n_prev + fresh;                      // plan.go:50
+    std::vector<uint8_t> alive((size_t)NX + 1, 0);
+    c->n_alive = 0;
+    c->any_removed = 0;
+    for (int n = 0; n < NX; n++) {
+        if (pb->node_removed[n]) c->any_removed = 1;
+        if (n < N && !pb->node_removed[n]) { alive[n] = 1; c->n_alive++; }
+    }
+    c->out_capacity = blance_result_capacity(pb);
+
+    PUT(node_removed, pb->node_removed, NX);
+    PUT(node_added, pb->node_added, NX);
+    PUT(node_weight, pb->node_weight, NX);
+    PUT(node_has_weight, pb->node_has_weight, NX);
+    PUT(alive, alive.data(), NX);
+    PUT(node_leaf_pos, pb->node_leaf_pos, NX);
+    RESERVE(zeros_nx, NX + 1);
+    HIPTRY(hipMemsetAsync(c->zeros_nx.p, 0, (size_t)NX + 1, c->stream));
+    PUT(part_order, pb->part_order, P);
+    PUT(part_weight, pb->part_weight, P);
+    PUT(part_has_weight, pb->part_has_weight, P);
+    PUT(part_in_prev, pb->part_in_prev, P);
+    PUT(part_never_equal, pb->part_prev_never_equal, P);
+    PUT(a_off, pb->assign_off, PM + 1);
+    PUT(a_nodes, pb->assign_nodes, pb->assign_off[PM]);
+    PUT(a_kind, pb->assign_kind, PM);
+    PUT(p_off, pb->prev_off, PM + 1);
+    PUT(p_nodes, pb->prev_nodes, pb->prev_off[PM]);
+    PUT(p_kind, pb->prev_kind, PM);
+    PUT(load_state, pb->load_state, pb->n_loads);
+    PUT(load_node, pb->load_node, pb->n_loads);
+    PUT(load_weight, pb->load_weight, pb->n_loads);
+    PUT(load_first, pb->load_first_sweep_only, pb->n_loads);
+    PUT(state_stick, pb->state_stickiness, M);
+    PUT(state_has_stick, pb->state_has_stickiness, M);
+    PUT(rule_inc, pb->rule_inc, pb->n_rules);
+    PUT(rule_exc, pb->rule_exc, pb->n_rules);
+    if (!pb->hierarchy_rules_nil) {
+        PUT(vparent, pb->vertex_parent, pb->n_vertices);
+        PUT(vlo, pb->vertex_leaf_lo, pb->n_vertices);
+        PUT(vhi, pb->vertex_leaf_hi, pb->n_vertices);
+        RESERVE(anchors, sizeof(AnchorSet) * (size_t)(pb->n_rules > 0 ? pb->n_rules : 1) * (NX + 1));
+        if (pb->n_rules > 0) {
+            int n = pb->n_rules * (NX + 1);
+            BLANCE_LAUNCH_NOSYNC(k_anchor_table, cdiv(n, 256), 256, 0, c->stream, pb->n_rules, NX,
+                                 pb->vertex_empty, c->rule_inc.as<int32_t>(), c->rule_exc.as<int32_t>(),
+                                 c->vparent.as<int32_t>(), c->vlo.as<int32_t>(), c->vhi.as<int32_t>(),
+                                 c->anchors.as<AnchorSet>());
+        }
+    }
+    const int RW = kRecHead + M * (1 + L);
+    int kmax = 1;
+    for (int m = 0; m < M; m++) if (pb->state_constraints[m] > kmax) kmax = pb->state_constraints[m];
+    RESERVE(live, sizeof(int32_t) * (size_t)(PM * L + 1));
+    RESERVE(live_len, sizeof(int32_t) * (size_t)(PM + 1));
+    RESERVE(live_kind, (size_t)PM + 1);
+    RESERVE(prv, sizeof(int32_t) * (size_t)(PM * L + 1));
+    RESERVE(prv_len, sizeof(int32_t) * (size_t)(PM + 1));
+    RESERVE(prv_kind, (size_t)PM + 1);
+    RESERVE(in_prev, (size_t)P + 1);
+    RESERVE(never_equal, (size_t)P + 1);
+    RESERVE(cnt, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1));
+    RESERVE(ntn, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1));
+    RESERVE(cat, (size_t)P + 1);
+    RESERVE(order, sizeof(int32_t) * ((size_t)P + 1));
+    RESERVE(chunk_counts, sizeof(int32_t) * 3 * (size_t)(cdiv(P, kChunk) + 1));
+    RESERVE(rec, sizeof(int32_t) * ((size_t)P * RW + 64));
+    RESERVE(out, sizeof(int32_t) * ((size_t)P * (1 + kmax) + 1));
+    RESERVE(warn_part, sizeof(int32_t) * (size_t)(PM + 1));
+    RESERVE(warn_state, sizeof(int32_t) * (size_t)(PM + 1));
+    RESERVE(scalars, 64);
+    HIPTRY(hipStreamSynchronize(c->stream));
+    // the caller's arrays are not retained: drop the host pointers
+    blance_problem& h = c->h;
+    h.state_priority = h.state_constraints = h.state_stickiness = nullptr;
+    h.state_has_stickiness = h.node_removed = h.node_added = nullptr;
+    c->uploaded = true;
+    return BLANCE_OK;
+}
+
+template <int T, int NPT>
+static void launch_pass(blance_ctx* c, const PassParams& q) {
+    size_t lds = sizeof(RedSlot) * 2 * (T / 64) + 64;
+    auto kern = k_pass_seq<T, NPT>;
+    BLANCE_LAUNCH(kern, 1, T, lds, c->stream, q);
+}
+
+static int dispatch_pass(blance_ctx* c, const PassParams& q) {
+    // T threads own NPT nodes each (register resident); one workgroup runs the pass.
+    const int NX = q.NX > 0 ? q.NX : 1;
+    int T = c->force_threads;
+    if (T != 64 && T != 256 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 256 : 1024);
+    if (T == 64 && NX > 256) T = 256;
+    if (T == 256 && NX > 1024) T = 1024;
+    const int npt = cdiv(NX, T);
+    if (T == 64) {
+        if (npt <= 1) launch_pass<64, 1>(c, q);
+        else launch_pass<64, 4>(c, q);
+    } else if (T == 256) {
+        if (npt <= 1) launch_pass<256, 1>(c, q);
+        else launch_pass<256, 4>(c, q);
+    } else {
+        if (npt <= 2) launch_pass<1024, 2>(c, q);
+        else if (npt <= 4) launch_pass<1024, 4>(c, q);
+        else if (npt <= 8) launch_pass<1024, 8>(c, q);
+        else return fail(BLANCE_ERR_UNSUPPORTED, "too many nodes for the register-resident pass");
+    }
+    return 0;
+}
+
+static int plan_locked(blance_ctx* c, blance_result* res) {
+    if (!c->uploaded) return fail(BLANCE_ERR_BAD_ARG, "no problem uploaded");
+    HIPTRY(hipSetDevice(c->device));
+    const blance_problem& h = c->h;
+    const int N = h.n_nodes, NX = h.n_nodes_ext, M = h.n_states, P = h.n_parts, L = c->L;
+    const int64_t PM = (int64_t)P * M;
+    const int RW = kRecHead + M * (1 + L);
+    hipStream_t sm = c->stream;
+    int32_t* scal = c->scalars.as<int32_t>();
+    int64_t launches = 0, steps = 0;
+    int n_pass = 0;
+
+    DevProblem d;
+    d.N = N; d.NX = NX; d.M = M; d.L = L; d.P = P;
+    d.weights_nil = h.partition_weights_nil;
+    d.part_weight = c->part_weight.as<int32_t>();
+    d.part_has_weight = c->part_has_weight.as<uint8_t>();
+    d.live = c->live.as<int32_t>(); d.live_len = c->live_len.as<int32_t>(); d.live_kind = c->live_kind.as<uint8_t>();
+    d.prv = c->prv.as<int32_t>(); d.prv_len = c->prv_len.as<int32_t>(); d.prv_kind = c->prv_kind.as<uint8_t>();
+    d.in_prev = c->in_prev.as<uint8_t>(); d.never_equal = c->never_equal.as<uint8_t>();
+
+    HIPTRY(hipEventRecord(c->ev0, sm));
+    HIPTRY(hipMemsetAsync(scal, 0, 64, sm));
+    if (P > 0) {
+        HIPTRY(hipMemcpyAsync(d.in_prev, c->part_in_prev.p, (size_t)P, hipMemcpyDeviceToDevice, sm));
+        HIPTRY(hipMemcpyAsync(d.never_equal, c->part_never_equal.p, (size_t)P, hipMemcpyDeviceToDevice, sm));
+    }
+    int iterations = 0, converged = 0;
+    for (int it = 0; it < h.max_iterations; it++) {                 // plan.go:32
+        const bool first = it == 0;
+        d.node_removed = first ? c->node_removed.as<uint8_t>() : c->zeros_nx.as<uint8_t>();   // plan.go:53-55
+        d.node_added = first ? c->node_added.as<uint8_t>() : c->zeros_nx.as<uint8_t>();
+        const int add_nil = first ? h.nodes_to_add_nil : 0;
+        const int any_removed = first ? c->any_removed : 0;
+        const int NP = first ? h.n_prev : c->np_later;
+        HIPTRY(hipMemsetAsync(scal, 0, 8, sm));                     // warn_count, not_match
+        if (PM > 0) {
+            if (first)
+                BLANCE_LAUNCH_NOSYNC(k_live_init, cdiv(PM, 256), 256, 0, sm, d, c->a_off.as<int32_t>(),
+                                     c->a_nodes.as<int32_t>(), c->a_kind.as<uint8_t>(), c->p_off.as<int32_t>(),
+                                     c->p_nodes.as<int32_t>(), c->p_kind.as<uint8_t>());
+            else
+                BLANCE_LAUNCH_NOSYNC(k_live_refresh, cdiv(PM, 256), 256, 0, sm, d);
+            launches++;
+        }
+        // stateNodeCounts = countStateNodes(prevMap), plan.go:94
+        HIPTRY(hipMemsetAsync(c->cnt.p, 0, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1), sm));
+        if (h.n_loads > 0) {
+            BLANCE_LAUNCH_NOSYNC(k_count_loads, cdiv(h.n_loads, 256), 256, 0, sm, h.n_loads, NX, first ? 0 : 1,
+                                 c->load_state.as<int32_t>(), c->load_node.as<int32_t>(),
+                                 c->load_weight.as<int32_t>(), c->load_first.as<uint8_t>(), c->cnt.as<int32_t>());
+            launches++;
+        }
+        if (PM > 0) {
+            BLANCE_LAUNCH_NOSYNC(k_count_prev, cdiv(PM, 256), 256, 0, sm, d, c->cnt.as<int32_t>());
+            launches++;
+        }
+        for (int m = 0; m < M; m++) {                               // plan.go:307-324
+            const int k = c->state_constraints[m];
+            if (k <= 0 || P == 0) continue;
+            const int n_chunks = cdiv(P, kChunk);
+            BLANCE_LAUNCH_NOSYNC(k_category, cdiv(P, 256), 256, 0, sm, d, m, any_removed, add_nil, c->cat.as<uint8_t>());
+            BLANCE_LAUNCH_NOSYNC(k_order_count, cdiv(n_chunks, 64), 64, 0, sm, P, c->part_order.as<int32_t>(),
+                                 c->cat.as<uint8_t>(), n_chunks, c->chunk_counts.as<int32_t>());
+            BLANCE_LAUNCH_NOSYNC(k_order_scan, 1, 64, 0, sm, 3 * n_chunks, c->chunk_counts.as<int32_t>());
+            BLANCE_LAUNCH_NOSYNC(k_order_scatter, cdiv(n_chunks, 64), 64, 0, sm, P, c->part_order.as<int32_t>(),
+                                 c->cat.as<uint8_t>(), n_chunks, c->chunk_counts.as<int32_t>(), c->order.as<int32_t>());
+            BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, RW, c->order.as<int32_t>(),
+                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
+            if (NP > 0)                                             // nodeToNodeCounts := fresh, plan.go:266
+                HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
+            PassParams q;
+            memset(&q, 0, sizeof q);
+            q.N = N; q.NX = NX; q.M = M; q.L = L; q.P = P; q.s = m; q.k = k; q.top_state = h.top_state;
+            q.NP = NP; q.RW = RW; q.OW = 1 + k;
+            q.higher_mask = 0;
+            for (int t = 0; t < M; t++)
+                if (c->state_priority[t] < c->state_priority[m]) q.higher_mask |= 1 << t;
+            q.hier = !h.hierarchy_rules_nil;
+            q.rule_begin = c->rule_off[m]; q.rule_end = c->rule_off[m + 1];
+            q.booster_kind = h.booster_kind;
+            q.n_alive = c->n_alive;
+            q.vertex_empty_anchor = NX;
+            q.alive = c->alive.as<uint8_t>();
+            q.node_weight = c->node_weight.as<int32_t>();
+            q.node_has_weight = c->node_has_weight.as<uint8_t>();
+            q.node_leaf_pos = c->node_leaf_pos.as<int32_t>();
+            q.anchors = c->anchors.as<AnchorSet>();
+            q.cnt = c->cnt.as<int32_t>();
+            q.ntn = c->ntn.as<int32_t>();
+            q.rec = c->rec.as<int32_t>();
+            q.out = c->out.as<int32_t>();
+            q.warn_part = c->warn_part.as<int32_t>();
+            q.warn_state = c->warn_state.as<int32_t>();
+            q.warn_count = scal + 0;
+            q.err = scal + 2;
+            while (c->pass_events.size() < 2 * (size_t)(n_pass + 1)) {
+                hipEvent_t ev;
+                HIPTRY(hipEventCreate(&ev));
+                c->pass_events.push_back(ev);
+            }
+            HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
+            int e = dispatch_pass(c, q);
+            if (e) return e;
+            HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
+            n_pass++;
+            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, q.OW, c->order.as<int32_t>(),
+                                 c->rec.as<int32_t>(), c->out.as<int32_t>());
+            launches += 7;
+            steps += P;
+        }
+        iterations++;
+        // convergence (plan.go:36-45) + write-back (plan.go:49-52)
+        if (P > 0) {
+            BLANCE_LAUNCH_NOSYNC(k_converge, cdiv(P, 256), 256, 0, sm, d, scal + 1);
+            launches++;
+        }
+        int32_t hs[4] = {0, 0, 0, 0};
+        HIPTRY(hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(hipGetLastError());
+        if (hs[2]) return fail(BLANCE_ERR_UNSUPPORTED, "hierarchy fold overflowed the device's interval budget");
+        c->n_warnings = hs[0];
+        if (!hs[1]) { converged = 1; break; }
+    }
+    HIPTRY(hipEventRecord(c->ev1, sm));
+    HIPTRY(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    double pass_ms = 0.0;
+    for (int i = 0; i < n_pass; i++) {
+        float pm = 0.f;
+        HIPTRY(hipEventElapsedTime(&pm, c->pass_events[2 * i], c->pass_events[2 * i + 1]));
+        pass_ms += pm;
+    }
+    c->pass_ms = pass_ms;
+    c->pass_launches = n_pass;
+    c->iterations = iterations;
+    c->converged = converged;
+    c->device_ms = ms;
+    c->steps_total = steps;
+    c->kernel_launches = launches;
+    c->planned = true;
+    if (iterations == 0) c->n_warnings = 0;
+    if (res) {
+        res->iterations = iterations;
+        res->converged = converged;
+        res->device_ms = ms;
+        res->total_ms = ms;
+        res->steps_total = steps;
+        res->steps_sequential = steps;
+        res->steps_batched = 0;
+        res->kernel_launches = launches;
+        res->n_warnings = c->n_warnings;
+        res->pass_kernel_ms = pass_ms;
+        res->pass_kernel_launches = n_pass;
+    }
+    return BLANCE_OK;
+}
+
+static int download_locked(blance_ctx* c, blance_result* res) {
+    if (!c->planned) return fail(BLANCE_ERR_BAD_ARG, "nothing planned yet");
+    if (!res || !res->out_off || !res->out_nodes || !res->out_kind || !res->warn_part || !res->warn_state)
+        return fail(BLANCE_ERR_BAD_ARG, "null result buffers");
+    HIPTRY(hipSetDevice(c->device));
+    const blance_problem& h = c->h;
+    const int M = h.n_states, P = h.n_parts, L = c->L;
+    const size_t PM = (size_t)P * M;
+    if (c->n_warnings > res->warn_capacity) return fail(BLANCE_ERR_CAPACITY, "warn_capacity too small");
+    std::vector<int32_t> live(PM * L + 1), len(PM + 1);
+    std::vector<uint8_t> kind(PM + 1);
+    if (c->iterations == 0) {
+        // MaxIterationsPerPlan <= 0: planNextMapEx returns (nil, nil) -- nothing to report (plan.go:32-58)
+        for (size_t i = 0; i <= PM; i++) res->out_off[i] = 0;
+        for (size_t i = 0; i < PM; i++) res->out_kind[i] = BLANCE_LIST_ABSENT;
+        res->n_warnings = 0;
+        res->iterations = 0;
+        res->converged = 0;
+        return BLANCE_OK;
+    }
+    if (PM) {
+        HIPTRY(hipMemcpyAsync(live.data(), c->live.p, sizeof(int32_t) * PM * L, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipMemcpyAsync(len.data(), c->live_len.p, sizeof(int32_t) * PM, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipMemcpyAsync(kind.data(), c->live_kind.p, PM, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (c->n_warnings) {
+        HIPTRY(hipMemcpyAsync(res->warn_part, c->warn_part.p, sizeof(int32_t) * (size_t)c->n_warnings, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipMemcpyAsync(res->warn_state, c->warn_state.p, sizeof(int32_t) * (size_t)c->n_warnings, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPTRY(hipStreamSynchronize(c->stream));
+    int64_t off = 0;
+    for (size_t idx = 0; idx < PM; idx++) {
+        res->out_off[idx] = (int32_t)off;
+        res->out_kind[idx] = kind[idx];
+        int n = kind[idx] == BLANCE_LIST_ABSENT ? 0 : len[idx];
+        if (off + n > res->out_capacity) return fail(BLANCE_ERR_CAPACITY, "out_capacity too small");
+        for (int i = 0; i < n; i++) res->out_nodes[off + i] = live[idx * L + i];
+        off += n;
+    }
+    res->out_off[PM] = (int32_t)off;
+    res->n_warnings = c->n_warnings;
+    res->iterations = c->iterations;
+    res->converged = c->converged;
+    res->device_ms = c->device_ms;
+    res->steps_total = c->steps_total;
+    res->steps_sequential = c->steps_total;
+    res->steps_batched = 0;
+    res->kernel_launches = c->kernel_launches;
+    res->pass_kernel_ms = c->pass_ms;
+    res->pass_kernel_launches = c->pass_launches;
+    return BLANCE_OK;
+}
+
+extern "C" int blance_upload(blance_ctx* c, const blance_problem* pb) {
+    if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    return upload_locked(c, pb);
+}
+
+extern "C" int blance_plan_resident(blance_ctx* c, blance_result* res) {
+    if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    return plan_locked(c, res);
+}
+
+extern "C" int blance_download(blance_ctx* c, blance_result* res) {
+    if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    return download_locked(c, res);
+}
+
+extern "C" int blance_plan(blance_ctx* c, const blance_problem* pb, blance_result* res) {
+    if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
+    if (!res) return fail(BLANCE_ERR_BAD_ARG, "null result");
+    std::lock_guard<std::mutex> g(c->mu);
+    hipEvent_t t0, t1;
+    HIPTRY(hipSetDevice(c->device));
+    HIPTRY(hipEventCreate(&t0));
+    HIPTRY(hipEventCreate(&t1));
+    HIPTRY(hipEventRecord(t0, c->stream));
+    int st = upload_locked(c, pb);
+    if (!st) st = plan_locked(c, res);
+    if (!st) st = download_locked(c, res);
+    if (!st) {
+        (void)hipEventRecord(t1, c->stream);
+        (void)hipEventSynchronize(t1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        res->total_ms = ms;
+    }
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return st;
+}

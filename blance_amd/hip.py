@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI (include/blance_hip.h) exported by
+blance_amd/lib/libblance_hip.so -- the hand-written HIP planner for gfx950.
+
+There is no CPU fallback: if the library is missing or no device is visible
+the calls raise.  (tests/simt builds the same kernel source against a SIMT
+emulator for GPU-less logic tests; that library is loaded only by tests, through
+the `lib_path` argument.)
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libblance_hip.so")
+
+EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", "blance_validate",
+           "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
+           "blance_plan_resident", "blance_download"]
+
+_libs = {}
+
+
+class BlanceError(RuntimeError):
+    def __init__(self, status, text):
+        RuntimeError.__init__(self, "blance status %d: %s" % (status, text))
+        self.status = status
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    lib = _libs.get(path)
+    if lib is not None:
+        return lib
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.blance_abi_version.restype = C.c_int
+    lib.blance_last_error.restype = C.c_char_p
+    lib.blance_result_capacity.restype = C.c_int64
+    lib.blance_result_capacity.argtypes = [C.POINTER(abi.Problem)]
+    lib.blance_validate.restype = C.c_int
+    lib.blance_validate.argtypes = [C.POINTER(abi.Problem)]
+    lib.blance_ctx_create.restype = C.c_int
+    lib.blance_ctx_create.argtypes = [C.POINTER(abi.Options), C.POINTER(C.c_void_p)]
+    lib.blance_ctx_destroy.restype = None
+    lib.blance_ctx_destroy.argtypes = [C.c_void_p]
+    for name in ("blance_plan",):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(abi.Problem), C.POINTER(abi.Result)]
+    lib.blance_upload.restype = C.c_int
+    lib.blance_upload.argtypes = [C.c_void_p, C.POINTER(abi.Problem)]
+    lib.blance_plan_resident.restype = C.c_int
+    lib.blance_plan_resident.argtypes = [C.c_void_p, C.POINTER(abi.Result)]
+    lib.blance_download.restype = C.c_int
+    lib.blance_download.argtypes = [C.c_void_p, C.POINTER(abi.Result)]
+    if lib.blance_abi_version() != abi.ABI_VERSION:
+        raise ImportError("ABI version mismatch")
+    _libs[path] = lib
+    return lib
+
+
+class Planner:
+    """One blance_ctx: a planner bound to one gfx950 device."""
+
+    def __init__(self, device_id=0, engine=abi.ENGINE_AUTO, lib_path=None, force_threads=0):
+        self.lib = load_library(lib_path)
+        opt = abi.Options()
+        opt.engine = engine
+        opt.device_id = device_id
+        opt.reserved[0] = force_threads
+        h = C.c_void_p()
+        self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))
+        self._h = h
+
+    def _check(self, st):
+        if st != abi.OK:
+            raise BlanceError(st, (self.lib.blance_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.blance_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def validate(self, fp):
+        return self.lib.blance_validate(C.byref(fp.as_struct()))
+
+    def plan(self, fp):
+        """blance_plan(): host buffers in, host buffers out."""
+        res = abi.FlatResult(fp)
+        self._check(self.lib.blance_plan(self._h, C.byref(fp.as_struct()), C.byref(res.struct)))
+        return res
+
+    def upload(self, fp):
+        self._fp = fp
+        self._check(self.lib.blance_upload(self._h, C.byref(fp.as_struct())))
+
+    def plan_resident(self):
+        """Run the whole planNextMapEx loop on the uploaded problem; returns the
+        timing/statistics part of blance_result."""
+        r = abi.Result()
+        self._check(self.lib.blance_plan_resident(self._h, C.byref(r)))
+        return r
+
+    def download(self):
+        res = abi.FlatResult(self._fp)
+        self._check(self.lib.blance_download(self._h, C.byref(res.struct)))
+        return res

@@ -1,0 +1,194 @@
+"""Synthetic PlanNextMapEx() inputs of the shapes BASELINE.json names
+(SURVEY.md section 8(d)), at two levels:
+
+  *_case(...)  -> the API-level arguments (dicts of strings), for any size the
+                  host interning layer can chew (used by the parity tests);
+  *_flat(...)  -> the same problem built directly as the int32 SoA of
+                  include/blance_hip.h with numpy (used by bench.py at 1M
+                  partitions, where interning a million Go-style map entries
+                  in Python would dominate).
+
+tests/test_synth.py checks that both routes give byte-identical problems.
+"""
+import numpy as np
+
+from . import abi, problem
+
+MODEL_P1 = {"primary": {"priority": 0, "constraints": 1}}
+MODEL_P1R1 = {"primary": {"priority": 0, "constraints": 1},
+              "replica": {"priority": 1, "constraints": 1}}
+MODEL_P1R2 = {"primary": {"priority": 0, "constraints": 1},
+              "replica": {"priority": 1, "constraints": 2}}
+
+
+def _node_names(n, width):
+    return [("n%0" + str(width) + "d") % i for i in range(n)]
+
+
+def _fresh_partitions(P):
+    return {str(i): {"name": str(i), "nodesByState": {}} for i in range(P)}
+
+
+def hierarchy_names(N, rack=16, racks_per_zone=8, zones_per_dc=8, width=4):
+    """3-level rack/zone/DC tree of config 3: NodeHierarchy child -> parent."""
+    nodes = _node_names(N, width)
+    hier = {}
+    n_racks = (N + rack - 1) // rack
+    n_zones = (n_racks + racks_per_zone - 1) // racks_per_zone
+    for i, n in enumerate(nodes):
+        hier[n] = "r%03d" % (i // rack)
+    for r in range(n_racks):
+        hier["r%03d" % r] = "z%02d" % (r // racks_per_zone)
+    for z in range(n_zones):
+        hier["z%02d" % z] = "d%d" % (z // zones_per_dc)
+    return hier
+
+
+def config_case(cfg, P=None, N=None):
+    """API-level arguments of BASELINE.json config `cfg` (1, 2 or 3); P and N
+    override the named size (for reduced-scale parity tests)."""
+    if cfg == 1:
+        P, N = P or 64, N or 4
+        nodes = ["n%d" % i for i in range(N)]
+        model, hier, rules = MODEL_P1, None, None
+    elif cfg == 2:
+        P, N = P or 65536, N or 256
+        nodes = _node_names(N, 3)
+        model, hier, rules = MODEL_P1R1, None, None
+    elif cfg == 3:
+        P, N = P or 1048576, N or 4096
+        nodes = _node_names(N, 4)
+        model = MODEL_P1R2
+        hier = hierarchy_names(N)
+        rules = {"replica": [{"includeLevel": 2, "excludeLevel": 1}]}
+    else:
+        raise ValueError("config %r" % (cfg,))
+    return {"prevMap": {}, "partitionsToAssign": _fresh_partitions(P), "aliased": False,
+            "nodesAll": nodes, "nodesToRemove": [], "nodesToAdd": list(nodes), "model": model,
+            "nodeHierarchy": hier, "hierarchyRules": rules}
+
+
+def case_to_flat(c, max_iterations=10):
+    prev = c["prevMap"]
+    assign = prev if c.get("aliased") else c["partitionsToAssign"]
+    return problem.build_problem(
+        prev, assign, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"],
+        c.get("modelStateConstraints"), c.get("partitionWeights"), c.get("stateStickiness"),
+        c.get("nodeWeights"), c.get("nodeHierarchy"), c.get("hierarchyRules"), c.get("booster"),
+        max_iterations=max_iterations)
+
+
+def config_flat(cfg, P=None, N=None, max_iterations=10):
+    """The flat problem of config `cfg` without going through strings."""
+    if cfg == 1:
+        P, N = P or 64, N or 4
+        prios, cons = [0], [1]
+        hier = False
+    elif cfg == 2:
+        P, N = P or 65536, N or 256
+        prios, cons = [0, 1], [1, 1]
+        hier = False
+    elif cfg == 3:
+        P, N = P or 1048576, N or 4096
+        prios, cons = [0, 1], [1, 2]
+        hier = True
+    else:
+        raise ValueError("config %r" % (cfg,))
+    M = len(prios)
+    fp = abi.FlatProblem()
+    z8 = lambda n: np.zeros(n, dtype=np.uint8)
+    z32 = lambda n: np.zeros(n, dtype=np.int32)
+    fp.set("state_priority", prios)
+    fp.set("state_constraints", cons)
+    fp.set("state_stickiness", z32(M))
+    fp.set("state_has_stickiness", z8(M))
+    fp.set("node_removed", z8(N))
+    fp.set("node_added", np.ones(N, dtype=np.uint8))
+    fp.set("node_weight", z32(N))
+    fp.set("node_has_weight", z8(N))
+    fp.set("part_order", np.arange(P, dtype=np.int32))        # names "0".."P-1": numeric order
+    fp.set("part_weight", np.ones(P, dtype=np.int32))
+    fp.set("part_has_weight", z8(P))
+    fp.set("part_in_prev", z8(P))
+    fp.set("part_prev_never_equal", z8(P))
+    fp.set("assign_off", z32(P * M + 1))
+    fp.set("assign_nodes", z32(0))
+    fp.set("assign_kind", z8(P * M))
+    fp.set("prev_off", z32(P * M + 1))
+    fp.set("prev_nodes", z32(0))
+    fp.set("prev_kind", z8(P * M))
+    for k in ("load_state", "load_node", "load_weight"):
+        fp.set(k, z32(0))
+    fp.set("load_first_sweep_only", z8(0))
+    VX, v_empty = 0, 0
+    if hier:
+        rack, rpz, zpd = 16, 8, 8
+        n_racks = (N + rack - 1) // rack
+        n_zones = (n_racks + rpz - 1) // rpz
+        n_dcs = (n_zones + zpd - 1) // zpd
+        r0, z0, d0 = N, N + n_racks, N + n_racks + n_zones
+        v_empty = d0 + n_dcs
+        VX = v_empty + 1
+        parent = np.full(VX, v_empty, dtype=np.int32)
+        nid = np.arange(N)
+        parent[:N] = r0 + nid // rack
+        parent[r0:z0] = z0 + np.arange(n_racks) // rpz
+        parent[z0:d0] = d0 + np.arange(n_zones) // zpd
+        lo = np.zeros(VX, dtype=np.int32)
+        hi = np.zeros(VX, dtype=np.int32)
+        lo[:N] = nid
+        hi[:N] = nid + 1
+        rk = np.arange(n_racks)
+        lo[r0:z0] = rk * rack
+        hi[r0:z0] = np.minimum((rk + 1) * rack, N)
+        zn = np.arange(n_zones)
+        lo[z0:d0] = zn * rack * rpz
+        hi[z0:d0] = np.minimum((zn + 1) * rack * rpz, N)
+        dc = np.arange(n_dcs)
+        lo[d0:v_empty] = dc * rack * rpz * zpd
+        hi[d0:v_empty] = np.minimum((dc + 1) * rack * rpz * zpd, N)
+        lo[v_empty] = N
+        hi[v_empty] = N + 1
+        fp.set("rule_off", [0, 0, 1])
+        fp.set("rule_inc", [2])
+        fp.set("rule_exc", [1])
+        fp.set("vertex_parent", parent)
+        fp.set("vertex_leaf_lo", lo)
+        fp.set("vertex_leaf_hi", hi)
+        fp.set("node_leaf_pos", nid.astype(np.int32))
+    else:
+        fp.set("rule_off", z32(M + 1))
+        fp.set("rule_inc", z32(0))
+        fp.set("rule_exc", z32(0))
+        fp.set("vertex_parent", z32(0))
+        fp.set("vertex_leaf_lo", z32(0))
+        fp.set("vertex_leaf_hi", z32(0))
+        fp.set("node_leaf_pos", np.full(N, -1, dtype=np.int32))
+    fp.scalars.update(n_nodes=N, n_nodes_ext=N, n_states=M, n_parts=P, n_prev=0, n_loads=0,
+                      n_rules=1 if hier else 0, n_vertices=VX, max_iterations=int(max_iterations),
+                      partition_weights_nil=1, nodes_to_add_nil=0,
+                      hierarchy_rules_nil=0 if hier else 1, booster_kind=abi.BOOSTER_NONE,
+                      top_state=0, vertex_empty=v_empty)
+    return fp
+
+
+def assignments(fp):
+    """Metric numerator: node slots in the returned map."""
+    k = np.maximum(fp.arrays["state_constraints"].astype(np.int64), 0)
+    return int(fp.scalars["n_parts"]) * int(k.sum())
+
+
+def algorithmic_bytes_per_sweep(fp):
+    """per findBestNodes call N*(16 + 4*k*[rules]) + 40."""
+    N = int(fp.scalars["n_nodes"])
+    P = int(fp.scalars["n_parts"])
+    cons = fp.arrays["state_constraints"]
+    roff = fp.arrays["rule_off"]
+    total = 0
+    for m in range(int(fp.scalars["n_states"])):
+        k = int(cons[m])
+        if k <= 0:
+            continue
+        has_rules = (not fp.scalars["hierarchy_rules_nil"]) and int(roff[m + 1]) > int(roff[m])
+        total += N * (16 + (4 * k if has_rules else 0)) + 40
+    return P * total

@@ -169,6 +169,10 @@ typedef struct blance_result {
     int64_t  steps_sequential;    /* steps resolved one at a time                        */
     int64_t  steps_batched;       /* steps resolved by an exact parallel schedule        */
     int64_t  kernel_launches;
+    /* out: the dominant kernel (one launch per state pass), timed with hipEvents
+     * on the planner's stream: sum of its launch durations and launch count */
+    double   pass_kernel_ms;
+    int64_t  pass_kernel_launches;
 } blance_result;
 
 typedef struct blance_options {

@@ -1,0 +1,122 @@
+"""GPU parity tests proper: the hand-written HIP planner, called through the C
+ABI (blance_plan), against the CPU oracle on the same inputs -- bit exact
+(node ids, list kinds, warnings, sweep count)."""
+import numpy as np
+import pytest
+
+from blance_amd import hip, problem, synth
+from helpers import build_from_case
+from randgen import random_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def planner():
+    pl = hip.Planner(device_id=0)
+    yield pl
+    pl.close()
+
+
+def _oracle(fp):
+    from oracle import loader
+    return loader.plan(fp)
+
+
+def _same(got, want, tag):
+    assert got.iterations == want.iterations, tag
+    assert got.converged == want.converged, tag
+    assert got.warnings() == want.warnings(), tag
+    assert got.digest() == want.digest(), tag
+
+
+def test_golden_cases(planner, golden_cases):
+    """The reference's own 69 end-to-end tables (plan_test.go, control_test.go)."""
+    from oracle import blance_ref as R
+    for c in golden_cases:
+        fp = build_from_case(c)
+        got = planner.plan(fp)
+        out, w = problem.decode_result(fp, got)
+        assert out == c["exp"], (c["suite"], c["index"], c["source"])
+        assert R.count_warnings(w, c["warningCountMode"]) == c["expNumWarnings"], c["source"]
+        _same(got, _oracle(fp), c["source"])
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_instances(planner, block):
+    n = 0
+    for seed in range(block * 250, (block + 1) * 250):
+        try:
+            fp = build_from_case(random_case(seed))
+        except problem.Unsupported:
+            continue
+        _same(planner.plan(fp), _oracle(fp), seed)
+        n += 1
+    assert n > 150
+
+
+def test_random_larger_instances(planner):
+    for seed in range(5000, 5040):
+        try:
+            fp = build_from_case(random_case(seed, max_nodes=300, max_parts=400))
+        except problem.Unsupported:
+            continue
+        _same(planner.plan(fp), _oracle(fp), seed)
+
+
+@pytest.mark.parametrize("threads", [64, 256, 1024])
+def test_workgroup_shapes(threads, golden_cases):
+    """Every workgroup shape of the pass kernel gives the same answer."""
+    pl = hip.Planner(device_id=0, force_threads=threads)
+    for c in golden_cases[::3]:
+        fp = build_from_case(c)
+        _same(pl.plan(fp), _oracle(fp), c["source"])
+    for seed in range(40):
+        try:
+            fp = build_from_case(random_case(seed, max_nodes=100, max_parts=60))
+        except problem.Unsupported:
+            continue
+        _same(pl.plan(fp), _oracle(fp), seed)
+    pl.close()
+
+
+def test_config1(planner):
+    fp = synth.config_flat(1)
+    got = planner.plan(fp)
+    _same(got, _oracle(fp), "cfg1")
+    # partition i -> node i mod 4, two sweeps
+    assert got.iterations == 2
+    assert got.out_nodes[:64].tolist() == [i % 4 for i in range(64)]
+
+
+def test_config2_full(planner):
+    fp = synth.config_flat(2)
+    got = planner.plan(fp)
+    _same(got, _oracle(fp), "cfg2")
+    prim = got.out_nodes[0::2][:65536]
+    rep = got.out_nodes[1::2][:65536]
+    i = np.arange(65536)
+    assert np.array_equal(prim, i % 256) and np.array_equal(rep, (i % 256) ^ 1)
+
+
+@pytest.mark.parametrize("P,N", [(4096, 4096), (16384, 1024), (20000, 777)])
+def test_config3_reduced(planner, P, N):
+    fp = synth.config_flat(3, P=P, N=N)
+    _same(planner.plan(fp), _oracle(fp), ("cfg3", P, N))
+
+
+def test_resident_replan_is_deterministic(planner):
+    fp = synth.config_flat(3, P=8192, N=512)
+    planner.upload(fp)
+    planner.plan_resident()
+    a = planner.download().digest()
+    planner.plan_resident()
+    b = planner.download().digest()
+    assert a == b == _oracle(fp).digest()
+
+
+def test_unsupported_is_refused(planner):
+    fp = synth.config_flat(2, P=16, N=9000)          # beyond the register-resident pass
+    with pytest.raises(hip.BlanceError) as e:
+        planner.plan(fp)
+    assert e.value.status == -2
