@@ -18,8 +18,10 @@
 #include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -101,38 +103,48 @@ __device__ __forceinline__ int block_argmin(double s, int n, RedSlot* red, int& 
 // algebra: one include interval minus a few excluded sub-intervals.  Leaf
 // intervals of tree vertices are laminar (nested or disjoint), which keeps
 // every intermediate in this form (DESIGN.md "Hierarchy masks").
-struct Fold {
+template <int XN>
+struct FoldT {
     int empty;
     int ilo, ihi;
     int nx;
-    int xlo[kMaxAnchors], xhi[kMaxAnchors];
+    int xlo[XN], xhi[XN];
 };
 
-__device__ __forceinline__ void fold_push_x(Fold& f, int lo, int hi, int* err) {
+template <int XN>
+__device__ __forceinline__ void fold_reset(FoldT<XN>& f) {
+    f.empty = 1; f.ilo = 0; f.ihi = 0; f.nx = 0;
+#pragma unroll
+    for (int j = 0; j < XN; j++) { f.xlo[j] = 0; f.xhi[j] = 0; }
+}
+
+template <int XN>
+__device__ __forceinline__ void fold_push_x(FoldT<XN>& f, int lo, int hi, int* err) {
     // clip to the include interval (laminar: disjoint, inside, or covering)
     if (hi <= f.ilo || lo >= f.ihi) return;
     if (lo <= f.ilo && hi >= f.ihi) { f.empty = 1; return; }
     bool dup = false;
 #pragma unroll
-    for (int j = 0; j < kMaxAnchors; j++)
+    for (int j = 0; j < XN; j++)
         if (j < f.nx && f.xlo[j] == lo && f.xhi[j] == hi) dup = true;
     if (dup) return;
-    if (f.nx >= kMaxAnchors) { *err = 1; return; }
+    if (f.nx >= XN) { *err = 1; return; }
 #pragma unroll
-    for (int j = 0; j < kMaxAnchors; j++)
+    for (int j = 0; j < XN; j++)
         if (j == f.nx) { f.xlo[j] = lo; f.xhi[j] = hi; }
     f.nx++;
 }
 
-__device__ __forceinline__ void fold_check_empty(Fold& f) {
+template <int XN>
+__device__ __forceinline__ void fold_check_empty(FoldT<XN>& f) {
     if (f.empty) return;
     int covered = 0;
 #pragma unroll
-    for (int i = 0; i < kMaxAnchors; i++) {
+    for (int i = 0; i < XN; i++) {
         if (i >= f.nx) continue;
         bool nested = false;
 #pragma unroll
-        for (int j = 0; j < kMaxAnchors; j++)
+        for (int j = 0; j < XN; j++)
             if (j < f.nx && j != i && f.xlo[j] <= f.xlo[i] && f.xhi[i] <= f.xhi[j]) nested = true;
         if (!nested) covered += f.xhi[i] - f.xlo[i];
     }
@@ -140,7 +152,8 @@ __device__ __forceinline__ void fold_check_empty(Fold& f) {
 }
 
 // One step of the fold: rv = (len(rv) == 0) ? set(a) : rv ∩ set(a)   (plan.go:744-750)
-__device__ __forceinline__ void fold_step(Fold& f, AnchorSet a, int* err) {
+template <int XN>
+__device__ __forceinline__ void fold_step(FoldT<XN>& f, AnchorSet a, int* err) {
     bool set_empty = (a.blo <= a.alo && a.bhi >= a.ahi);   // exclude covers include
     if (f.empty) {
         f.empty = set_empty ? 1 : 0;
@@ -153,26 +166,31 @@ __device__ __forceinline__ void fold_step(Fold& f, AnchorSet a, int* err) {
     int lo = f.ilo > a.alo ? f.ilo : a.alo;
     int hi = f.ihi < a.ahi ? f.ihi : a.ahi;
     if (lo >= hi) { f.empty = 1; return; }
-    int onx = f.nx;
-    int olo[kMaxAnchors], ohi[kMaxAnchors];
+    if (lo != f.ilo || hi != f.ihi) {      // the include interval shrank: re-clip the exclusions
+        int onx = f.nx;
+        int olo[XN], ohi[XN];
 #pragma unroll
-    for (int j = 0; j < kMaxAnchors; j++) { olo[j] = f.xlo[j]; ohi[j] = f.xhi[j]; }
-    f.ilo = lo; f.ihi = hi; f.nx = 0;
+        for (int j = 0; j < XN; j++) { olo[j] = f.xlo[j]; ohi[j] = f.xhi[j]; }
+        f.ilo = lo; f.ihi = hi; f.nx = 0;
 #pragma unroll
-    for (int j = 0; j < kMaxAnchors; j++)
-        if (j < onx && !f.empty) fold_push_x(f, olo[j], ohi[j], err);
+        for (int j = 0; j < XN; j++)
+            if (j < onx && !f.empty) fold_push_x(f, olo[j], ohi[j], err);
+    }
     if (!f.empty) fold_push_x(f, a.blo, a.bhi, err);
     fold_check_empty(f);
 }
 
-__device__ __forceinline__ bool fold_contains(const Fold& f, int pos) {
+template <int XN>
+__device__ __forceinline__ bool fold_contains(const FoldT<XN>& f, int pos) {
     if (f.empty || pos < f.ilo || pos >= f.ihi) return false;
     bool in = true;
 #pragma unroll
-    for (int j = 0; j < kMaxAnchors; j++)
+    for (int j = 0; j < XN; j++)
         if (j < f.nx && pos >= f.xlo[j] && pos < f.xhi[j]) in = false;
     return in;
 }
+
+using Fold = FoldT<kMaxAnchors>;
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -292,9 +310,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                 int h = top < 0 ? q.vertex_empty_anchor : top;
                 if (top < 0 && n_hn > 0) h = hn[0];
                 Fold f;
-                f.empty = 1; f.ilo = 0; f.ihi = 0; f.nx = 0;
-#pragma unroll
-                for (int j = 0; j < kMaxAnchors; j++) { f.xlo[j] = 0; f.xhi[j] = 0; }
+                fold_reset(f);
                 {
                     AnchorSet a = tab[h];
                     a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
@@ -466,6 +482,267 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
 }
 
 // ============================================================================
+// Region chains.  When the state's hierarchy rule cuts the cluster into regions
+// (every node's include set is the same leaf interval as its neighbours'), a
+// step whose top priority node and current nodes all live in one region reads
+// and writes only that region's counters.  Steps of different regions commute,
+// so each region's steps run as an independent in-order chain on one wave64:
+// lanes own the region's leaves, the region's slice of nodeToNodeCounts sits
+// in LDS, and the argmin is a DPP reduction -- no barrier, no global traffic
+// on the critical path.  A chain that would have to look outside its region
+// (fallback to candidateNodes[0], unmet constraints) raises flags[1] and the
+// host redoes the whole pass with k_pass_seq.
+// ============================================================================
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void argmin_stage(double& s, int& n) {
+    int lo2 = dpp_mov<CTRL>(__double2loint(s));
+    int hi2 = dpp_mov<CTRL>(__double2hiint(s));
+    int n2 = dpp_mov<CTRL>(n);
+    double s2 = __hiloint2double(hi2, lo2);
+    if (better(s2, n2, s, n)) { s = s2; n = n2; }
+}
+
+// (score, position) argmin over one wave64; result is wave-uniform.
+__device__ __forceinline__ int wave_argmin(double s, int n) {
+    argmin_stage<0xB1>(s, n);     // quad_perm [1,0,3,2]
+    argmin_stage<0x4E>(s, n);     // quad_perm [2,3,0,1]
+    argmin_stage<0x141>(s, n);    // row_half_mirror
+    argmin_stage<0x140>(s, n);    // row_mirror: every row of 16 now agrees
+    double bs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 0),
+                                 __builtin_amdgcn_readlane(__double2loint(s), 0));
+    int bn = __builtin_amdgcn_readlane(n, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        double s2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), r),
+                                     __builtin_amdgcn_readlane(__double2loint(s), r));
+        int n2 = __builtin_amdgcn_readlane(n, r);
+        if (better(s2, n2, bs, bn)) { bs = s2; bn = n2; }
+    }
+    return bn;
+}
+
+template <int NPTC, int KM>
+__global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
+    BLANCE_DYN_LDS(lds);
+    if (q.flags[0]) return;
+    const int lane = threadIdx.x;
+    const int rg = blockIdx.x;
+    const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
+    const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
+    if (cbeg >= cend) return;
+    const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k;
+    const int SW = 1 + L;
+    int* xs_lo = (int*)lds;              // exclude interval of each region leaf used as an anchor
+    int* xs_hi = xs_lo + size;
+    int* ntn_l = xs_hi + size;           // [size][size] nodeToNodeCounts of this region's rows
+
+    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC];
+    unsigned alive_m = 0, hasw_m = 0;
+    double g[NPTC];
+#pragma unroll
+    for (int i = 0; i < NPTC; i++) {
+        int pos = lo + lane + 64 * i;
+        nid[i] = -1; cntv[i] = 0; totv[i] = 0; wv[i] = 0; g[i] = 0.0;
+        if (pos < hi) {
+            int n = q.leaf_node[pos];
+            nid[i] = n;
+            int blo = 0, bhi = 0;
+            if (n >= 0) {
+                cntv[i] = q.cnt[s * NX + n];
+                int tsum = 0;
+                for (int t = 0; t <= M; t++) tsum += q.cnt[t * NX + n];
+                totv[i] = tsum;
+                wv[i] = q.node_weight[n];
+                if (q.node_has_weight[n]) hasw_m |= 1u << i;
+                if (n < N && q.alive[n]) alive_m |= 1u << i;
+                g[i] = node_score(cntv[i], 0, totv[i], (hasw_m >> i) & 1, wv[i], NP, 0.0, q.booster_kind);
+                blo = q.anchors[n].blo; bhi = q.anchors[n].bhi;
+            }
+            xs_lo[pos - lo] = blo;
+            xs_hi[pos - lo] = bhi;
+        }
+    }
+    if (NP > 0 && q.ntn_in_lds)
+        for (int i = lane; i < size * size; i += 64) ntn_l[i] = 0;
+    __syncthreads();
+
+    int recw = 0, recw_next = 0;
+    if (lane < q.RW) recw_next = q.rec[(size_t)cbeg * q.RW + lane];
+    bool escaped = false;
+
+    for (int ci = cbeg; ci < cend && !escaped; ci++) {
+        recw = recw_next;
+        if (ci + 1 < cend && lane < q.RW) recw_next = q.rec[(size_t)(ci + 1) * q.RW + lane];
+#define REC(i) __builtin_amdgcn_readlane(recw, (i))
+        const int w = REC(1);
+        const double stick = __hiloint2double(REC(3), REC(2));
+        const int tl = REC(4) - lo;                      // local leaf index of the top priority node
+        const int top = REC(kRecHead + q.top_state * SW + 1);
+
+        int ntnv[NPTC];
+#pragma unroll
+        for (int i = 0; i < NPTC; i++) {
+            ntnv[i] = 0;
+            if (NP > 0) {
+                if (q.ntn_in_lds) { if (lane + 64 * i < size) ntnv[i] = ntn_l[tl * size + lane + 64 * i]; }
+                else if (nid[i] >= 0 && nid[i] < N) ntnv[i] = q.ntn[(size_t)top * N + nid[i]];
+            }
+        }
+        unsigned inh_m = 0, own_m = 0;
+        for (int t = 0; t < M; t++) {
+            int hdr = REC(kRecHead + t * SW);
+            if ((hdr >> 16) == kListAbsent) continue;
+            int len = hdr & 0xffff;
+            bool higher = (q.higher_mask >> t) & 1;
+            if (!higher && t != s) continue;
+            for (int j = 0; j < len; j++) {
+                int x = REC(kRecHead + t * SW + 1 + j);
+#pragma unroll
+                for (int i = 0; i < NPTC; i++) {
+                    if (x == nid[i]) {
+                        if (higher) inh_m |= 1u << i;
+                        if (t == s) own_m |= 1u << i;
+                    }
+                }
+            }
+        }
+        const unsigned elig_m = alive_m & ~inh_m;
+        double sc[NPTC];
+#pragma unroll
+        for (int i = 0; i < NPTC; i++) {
+            bool own = (own_m >> i) & 1;
+            if (own || ntnv[i] != 0)
+                sc[i] = node_score(cntv[i], ntnv[i], totv[i], (hasw_m >> i) & 1, wv[i], NP,
+                                   own ? stick : 0.0, q.booster_kind);
+            else
+                sc[i] = g[i];
+        }
+
+        // the rule's k picks (plan.go:177-223); every anchor's include set is this region
+        FoldT<KM + 1> f;
+        fold_reset(f);
+        int err = 0;
+        {
+            AnchorSet a;
+            a.alo = lo; a.ahi = hi; a.blo = uni(xs_lo[tl]); a.bhi = uni(xs_hi[tl]);
+            fold_step(f, a, &err);
+        }
+        int chosen[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) chosen[j] = -1;
+        int n_out = 0;
+        for (int slot = 0; slot < k; slot++) {
+            double bs = pos_inf();
+            int bn = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                if (((elig_m >> u) & 1) && fold_contains(f, lo + lane + 64 * u) &&
+                    better(sc[u], nid[u], bs, bn)) {
+                    bs = sc[u]; bn = nid[u];
+                }
+            }
+            int best = wave_argmin(bs, bn);
+            if (best == INT_MAX) { escaped = true; break; }      // would fall back to candidateNodes[0]
+            int wl = 0;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                unsigned long long bm = __ballot(nid[u] == best);
+                if (bm) wl = __ffsll((long long)bm) - 1 + 64 * u;
+            }
+            wl = uni(wl);
+            bool dup = false;
+#pragma unroll
+            for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == best) dup = true;
+            if (!dup) {
+#pragma unroll
+                for (int c = 0; c < KM; c++) if (c == n_out) chosen[c] = best;
+                n_out++;
+            }
+            AnchorSet a;
+            a.alo = lo; a.ahi = hi; a.blo = uni(xs_lo[wl]); a.bhi = uni(xs_hi[wl]);
+            fold_step(f, a, &err);
+        }
+        if (n_out < k || err) escaped = true;                    // would need the global candidate list
+        if (escaped) break;
+
+        // ---- commit: as in k_pass_seq, the owner lane of a node updates it
+        unsigned changed_m = 0;
+        for (int t = 0; t < M; t++) {
+            int hdr = REC(kRecHead + t * SW);
+            if ((hdr >> 16) == kListAbsent) continue;
+            int len = hdr & 0xffff;
+            for (int j = 0; j < len; j++) {
+                int x = REC(kRecHead + t * SW + 1 + j);
+                bool hit = (t == s);
+                if (!hit) {
+                    int hs = REC(kRecHead + s * SW);
+                    if ((hs >> 16) != kListAbsent) {
+                        int ls = hs & 0xffff;
+                        for (int jj = 0; jj < ls; jj++)
+                            if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
+                    }
+#pragma unroll
+                    for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == x) hit = true;
+                }
+                if (!hit) continue;
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    if (x == nid[u]) {
+                        totv[u] -= w;
+                        if (t == s) cntv[u] -= w;
+                        changed_m |= 1u << u;
+                    }
+                }
+                if (t != s && lane == 0) q.cnt[t * NX + x] -= w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KM; c++) {
+            if (c < n_out) {
+                int x = chosen[c];
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    if (x == nid[u]) {
+                        cntv[u] += w;
+                        totv[u] += w;
+                        changed_m |= 1u << u;
+                        if (NP > 0) {
+                            if (q.ntn_in_lds) ntn_l[tl * size + lane + 64 * u] = ntnv[u] + 1;
+                            else q.ntn[(size_t)top * N + x] = ntnv[u] + 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (changed_m) {
+#pragma unroll
+            for (int u = 0; u < NPTC; u++)
+                if ((changed_m >> u) & 1)
+                    g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
+        }
+        if (lane == 0) {
+            int* o = q.out + (size_t)ci * q.OW;
+            o[0] = n_out;
+#pragma unroll
+            for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
+        }
+#undef REC
+    }
+    if (escaped) {
+        if (lane == 0) q.flags[1] = 1;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NPTC; i++)
+        if (nid[i] >= 0) q.cnt[s * NX + nid[i]] = cntv[i];
+}
+
+// ============================================================================
 // Data-parallel kernels around the pass
 // ============================================================================
 
@@ -480,22 +757,6 @@ struct DevProblem {   // device pointers + sizes shared by the elementwise kerne
     int32_t* prv;  int32_t* prv_len;  uint8_t* prv_kind;
     uint8_t* in_prev; uint8_t* never_equal;
 };
-
-// leaf-interval table of every (rule, anchor): plan.go:723-734, :755-774
-__global__ void k_anchor_table(int n_rules, int NX, int vertex_empty, const int32_t* rule_inc,
-                               const int32_t* rule_exc, const int32_t* vparent, const int32_t* vlo,
-                               const int32_t* vhi, AnchorSet* out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rules * (NX + 1)) return;
-    int r = i / (NX + 1), a = i % (NX + 1);
-    int v = a == NX ? vertex_empty : a;
-    int vi = v, ve = v;
-    for (int l = rule_inc[r]; l > 0; l--) vi = vparent[vi];   // findAncestor, plan.go:755-762
-    for (int l = rule_exc[r]; l > 0; l--) ve = vparent[ve];
-    AnchorSet s;
-    s.alo = vlo[vi]; s.ahi = vhi[vi]; s.blo = vlo[ve]; s.bhi = vhi[ve];
-    out[i] = s;
-}
 
 // nextPartitions = copy of partitionsToAssign minus nodesToRemove (plan.go:83-88)
 __global__ void k_live_init(DevProblem d, const int32_t* a_off, const int32_t* a_nodes,
@@ -604,9 +865,79 @@ __global__ void k_order_scatter(int P, const int32_t* static_order, const uint8_
     }
 }
 
+// Region of every step of the pass, or flags[0] if some step is not region-local:
+// its top priority node and the nodes it currently holds in this state must sit
+// in one region (their counters are then owned by that region's chain).
+__global__ void k_chain_classify(DevProblem d, int m, int top_state, const int32_t* order,
+                                 const int32_t* node_region, int32_t* regid, int32_t* flags) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    int idxT = p * d.M + top_state;
+    int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
+    int rg = top >= 0 ? node_region[top] : -1;
+    if (rg >= 0) {
+        int idx = p * d.M + m;
+        if (d.live_kind[idx] != kListAbsent)
+            for (int i = 0; i < d.live_len[idx]; i++)
+                if (node_region[d.live[(size_t)idx * d.L + i]] != rg) rg = -1;
+    }
+    if (rg < 0) { flags[0] = 1; rg = 0; }
+    regid[oi] = rg;
+}
+
+// Stable partition of the pass order by region: chunk counts -> scan -> scatter.
+constexpr int kBChunk = 256;
+
+__global__ void k_bucket_count(int P, const int32_t* regid, int n_chunks, int32_t* counts /* [B][n_chunks], zeroed */) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    int beg = c * kBChunk, end = beg + kBChunk < P ? beg + kBChunk : P;
+    for (int i = beg; i < end; i++) counts[(size_t)regid[i] * n_chunks + c]++;
+}
+
+// exclusive scan of n ints by one workgroup of 1024 threads (n up to a few million)
+__global__ __launch_bounds__(1024) void k_scan_excl(int n, int32_t* data) {
+    BLANCE_DYN_LDS(lds);
+    int* part = (int*)lds;                       // [1024]
+    const int tid = threadIdx.x, T = 1024;
+    int per = (n + T - 1) / T;
+    int beg = tid * per, end = beg + per < n ? beg + per : n;
+    int sum = 0;
+    for (int i = beg; i < end; i++) sum += data[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1) {
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int acc = part[tid] - sum;
+    for (int i = beg; i < end; i++) { int v = data[i]; data[i] = acc; acc += v; }
+}
+
+__global__ void k_region_offsets(int B, int n_chunks, int P, const int32_t* offsets, int32_t* reg_off) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    reg_off[b] = b == B ? P : offsets[(size_t)b * n_chunks];
+}
+
+__global__ void k_bucket_scatter(int P, const int32_t* regid, const int32_t* order, int n_chunks,
+                                 int32_t* offsets, int32_t* chain_order) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    int beg = c * kBChunk, end = beg + kBChunk < P ? beg + kBChunk : P;
+    for (int i = beg; i < end; i++) {
+        int pos = offsets[(size_t)regid[i] * n_chunks + c]++;
+        chain_order[pos] = order[i];
+    }
+}
+
 // Step records in pass order: what findBestNodes needs to know about its partition.
-__global__ void k_gather(DevProblem d, int m, int RW, const int32_t* order, const int32_t* state_stickiness,
-                         const uint8_t* state_has_stickiness, int32_t* rec) {
+__global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
+                         const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
+                         const int32_t* node_leaf_pos, int32_t* rec) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
     if (oi >= d.P) return;
     int p = order[oi];
@@ -619,6 +950,11 @@ __global__ void k_gather(DevProblem d, int m, int RW, const int32_t* order, cons
     }
     r[0] = p; r[1] = w;
     r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    {
+        int idxT = p * d.M + top_state;
+        int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
+        r[4] = top >= 0 ? node_leaf_pos[top] : -1;
+    }
     for (int t = 0; t < d.M; t++) {
         int idx = p * d.M + t;
         int32_t* rs = r + kRecHead + t * (1 + d.L);
@@ -737,6 +1073,15 @@ struct blance_ctx {
     blance_problem h{};
     std::vector<int32_t> state_priority, state_constraints, rule_off;
     int L = 1, np_later = 0, n_alive = 0, any_removed = 0;
+    int chain_min_parts = 2048;
+    struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
+        bool ok = false;
+        int n_regions = 0, max_size = 0;
+        DevBuf node_region, reg_lo, reg_hi;
+    };
+    std::vector<RuleRegions> rule_regions;
+    DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save;
+    int64_t steps_batched = 0;
     int64_t out_capacity = 0;
 
     // device: problem
@@ -765,6 +1110,10 @@ struct blance_ctx {
                          &cnt, &ntn, &cat, &order, &chunk_counts, &rec, &out, &warn_part,
                          &warn_state, &scalars};
         for (DevBuf* b : all) b->release();
+        for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); }
+        rule_regions.clear();
+        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save};
+        for (DevBuf* b : more) b->release();
     }
 };
 
@@ -874,6 +1223,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->device = dev;
     c->engine = opt ? opt->engine : BLANCE_ENGINE_AUTO;
     c->force_threads = opt ? opt->reserved[0] : 0;
+    if (opt && opt->reserved[1] > 0) c->chain_min_parts = opt->reserved[1];
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -965,17 +1315,70 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     PUT(state_has_stick, pb->state_has_stickiness, M);
     PUT(rule_inc, pb->rule_inc, pb->n_rules);
     PUT(rule_exc, pb->rule_exc, pb->n_rules);
+    for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); }
+    c->rule_regions.clear();
     if (!pb->hierarchy_rules_nil) {
-        PUT(vparent, pb->vertex_parent, pb->n_vertices);
-        PUT(vlo, pb->vertex_leaf_lo, pb->n_vertices);
-        PUT(vhi, pb->vertex_leaf_hi, pb->n_vertices);
-        RESERVE(anchors, sizeof(AnchorSet) * (size_t)(pb->n_rules > 0 ? pb->n_rules : 1) * (NX + 1));
-        if (pb->n_rules > 0) {
-            int n = pb->n_rules * (NX + 1);
-            BLANCE_LAUNCH_NOSYNC(k_anchor_table, cdiv(n, 256), 256, 0, c->stream, pb->n_rules, NX,
-                                 pb->vertex_empty, c->rule_inc.as<int32_t>(), c->rule_exc.as<int32_t>(),
-                                 c->vparent.as<int32_t>(), c->vlo.as<int32_t>(), c->vhi.as<int32_t>(),
-                                 c->anchors.as<AnchorSet>());
+        // leaf-interval table of every (rule, anchor): plan.go:723-734, :755-774
+        const int R = pb->n_rules;
+        std::vector<AnchorSet> tab((size_t)(R > 0 ? R : 1) * (NX + 1));
+        for (int r = 0; r < R; r++)
+            for (int a = 0; a <= NX; a++) {
+                int v = a == NX ? pb->vertex_empty : a;
+                int vi = v, ve = v;
+                for (int l = pb->rule_inc[r]; l > 0; l--) vi = pb->vertex_parent[vi];   // findAncestor
+                for (int l = pb->rule_exc[r]; l > 0; l--) ve = pb->vertex_parent[ve];
+                AnchorSet st;
+                st.alo = pb->vertex_leaf_lo[vi]; st.ahi = pb->vertex_leaf_hi[vi];
+                st.blo = pb->vertex_leaf_lo[ve]; st.bhi = pb->vertex_leaf_hi[ve];
+                tab[(size_t)r * (NX + 1) + a] = st;
+            }
+        PUT(anchors, tab.data(), tab.size());
+        int n_leaves = 1;
+        for (int v = 0; v < pb->n_vertices; v++) if (pb->vertex_leaf_hi[v] > n_leaves) n_leaves = pb->vertex_leaf_hi[v];
+        std::vector<int32_t> leaf_node((size_t)n_leaves, -1);
+        for (int a = 0; a < NX; a++)
+            if (pb->node_leaf_pos[a] >= 0 && pb->node_leaf_pos[a] < n_leaves) leaf_node[pb->node_leaf_pos[a]] = a;
+        PUT(leaf_node, leaf_node.data(), leaf_node.size());
+        // Does the rule cut the leaves into regions?  Every node whose leaf lies in
+        // a region must have exactly that region as its include set.
+        c->rule_regions.resize(R);
+        for (int r = 0; r < R; r++) {
+            blance_ctx::RuleRegions& rr = c->rule_regions[r];
+            const AnchorSet* t = &tab[(size_t)r * (NX + 1)];
+            std::vector<std::pair<int, int>> iv;
+            for (int a = 0; a < NX; a++) {
+                int lp = pb->node_leaf_pos[a];
+                if (lp >= 0 && t[a].alo <= lp && lp < t[a].ahi) iv.emplace_back(t[a].alo, t[a].ahi);
+            }
+            std::sort(iv.begin(), iv.end());
+            iv.erase(std::unique(iv.begin(), iv.end()), iv.end());
+            bool ok = iv.size() >= 2;
+            for (size_t i = 1; i < iv.size() && ok; i++) if (iv[i].first < iv[i - 1].second) ok = false;
+            std::vector<int32_t> node_region((size_t)NX, -1), rlo, rhi;
+            int max_size = 0;
+            if (ok) {
+                for (auto& x : iv) {
+                    rlo.push_back(x.first); rhi.push_back(x.second);
+                    if (x.second - x.first > max_size) max_size = x.second - x.first;
+                }
+                for (int a = 0; a < NX && ok; a++) {
+                    int lp = pb->node_leaf_pos[a];
+                    if (lp < 0) continue;
+                    size_t j = std::upper_bound(rlo.begin(), rlo.end(), lp) - rlo.begin();
+                    if (j == 0 || lp >= rhi[j - 1]) continue;
+                    if (t[a].alo != rlo[j - 1] || t[a].ahi != rhi[j - 1]) ok = false;
+                    node_region[a] = (int)j - 1;
+                }
+            }
+            if (max_size > 256) ok = false;
+            rr.ok = ok;
+            rr.n_regions = ok ? (int)rlo.size() : 0;
+            rr.max_size = max_size;
+            if (ok) {
+                if (put(c, rr.node_region, node_region.data(), node_region.size())) return BLANCE_ERR_DEVICE;
+                if (put(c, rr.reg_lo, rlo.data(), rlo.size())) return BLANCE_ERR_DEVICE;
+                if (put(c, rr.reg_hi, rhi.data(), rhi.size())) return BLANCE_ERR_DEVICE;
+            }
         }
     }
     const int RW = kRecHead + M * (1 + L);
@@ -999,6 +1402,15 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     RESERVE(warn_part, sizeof(int32_t) * (size_t)(PM + 1));
     RESERVE(warn_state, sizeof(int32_t) * (size_t)(PM + 1));
     RESERVE(scalars, 64);
+    {
+        int maxB = 1;
+        for (auto& rr : c->rule_regions) if (rr.ok && rr.n_regions > maxB) maxB = rr.n_regions;
+        RESERVE(regid, sizeof(int32_t) * ((size_t)P + 1));
+        RESERVE(chain_order, sizeof(int32_t) * ((size_t)P + 1));
+        RESERVE(bucket_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv(P, kBChunk) + 1) + 1));
+        RESERVE(reg_off, sizeof(int32_t) * ((size_t)maxB + 2));
+        RESERVE(cnt_save, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1));
+    }
     HIPTRY(hipStreamSynchronize(c->stream));
     // the caller's arrays are not retained: drop the host pointers
     blance_problem& h = c->h;
@@ -1038,6 +1450,34 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     return 0;
 }
 
+template <int NPTC, int KM>
+static void launch_chain(blance_ctx* c, const ChainParams& q, size_t lds) {
+    auto kern = k_pass_chain<NPTC, KM>;
+    BLANCE_LAUNCH(kern, q.n_regions, 64, lds, c->stream, q);
+}
+
+// one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
+static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
+    int nptc = cdiv(max_size, 64);
+    size_t ntn_bytes = sizeof(int32_t) * (size_t)max_size * max_size;
+    q.ntn_in_lds = ntn_bytes <= 140 * 1024;
+    size_t lds = sizeof(int32_t) * 2 * (size_t)max_size + (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
+    if (q.k <= 2) {
+        if (nptc <= 1) launch_chain<1, 2>(c, q, lds);
+        else if (nptc <= 2) launch_chain<2, 2>(c, q, lds);
+        else if (nptc <= 4) launch_chain<4, 2>(c, q, lds);
+        else return false;
+    } else if (q.k <= 4) {
+        if (nptc <= 1) launch_chain<1, 4>(c, q, lds);
+        else if (nptc <= 2) launch_chain<2, 4>(c, q, lds);
+        else if (nptc <= 4) launch_chain<4, 4>(c, q, lds);
+        else return false;
+    } else {
+        return false;
+    }
+    return true;
+}
+
 static int plan_locked(blance_ctx* c, blance_result* res) {
     if (!c->uploaded) return fail(BLANCE_ERR_BAD_ARG, "no problem uploaded");
     HIPTRY(hipSetDevice(c->device));
@@ -1047,7 +1487,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     const int RW = kRecHead + M * (1 + L);
     hipStream_t sm = c->stream;
     int32_t* scal = c->scalars.as<int32_t>();
-    int64_t launches = 0, steps = 0;
+    int64_t launches = 0, steps = 0, batched = 0;
     int n_pass = 0;
 
     DevProblem d;
@@ -1105,19 +1545,89 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             BLANCE_LAUNCH_NOSYNC(k_order_scan, 1, 64, 0, sm, 3 * n_chunks, c->chunk_counts.as<int32_t>());
             BLANCE_LAUNCH_NOSYNC(k_order_scatter, cdiv(n_chunks, 64), 64, 0, sm, P, c->part_order.as<int32_t>(),
                                  c->cat.as<uint8_t>(), n_chunks, c->chunk_counts.as<int32_t>(), c->order.as<int32_t>());
-            BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, RW, c->order.as<int32_t>(),
-                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
             if (NP > 0)                                             // nodeToNodeCounts := fresh, plan.go:266
                 HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
+            const int OW = 1 + k;
+            int higher_mask = 0;
+            for (int t = 0; t < M; t++)
+                if (c->state_priority[t] < c->state_priority[m]) higher_mask |= 1 << t;
+            const int r0 = c->rule_off[m], r1 = c->rule_off[m + 1];
+            while (c->pass_events.size() < 2 * (size_t)(n_pass + 2)) {
+                hipEvent_t ev;
+                HIPTRY(hipEventCreate(&ev));
+                c->pass_events.push_back(ev);
+            }
+
+            // ---- region chains, when the state's single hierarchy rule allows them
+            bool done = false;
+            if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
+                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
+                blance_ctx::RuleRegions& rr = c->rule_regions[r0];
+                const int B = rr.n_regions, nbc = cdiv(P, kBChunk);
+                HIPTRY(hipMemsetAsync(scal + 4, 0, 8, sm));
+                HIPTRY(hipMemsetAsync(c->bucket_counts.p, 0, sizeof(int32_t) * (size_t)B * nbc, sm));
+                BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+                                     rr.node_region.as<int32_t>(), c->regid.as<int32_t>(), scal + 4);
+                BLANCE_LAUNCH_NOSYNC(k_bucket_count, cdiv(nbc, 64), 64, 0, sm, P, c->regid.as<int32_t>(), nbc,
+                                     c->bucket_counts.as<int32_t>());
+                BLANCE_LAUNCH(k_scan_excl, 1, 1024, 4096 + 64, sm, B * nbc, c->bucket_counts.as<int32_t>());
+                BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nbc, P,
+                                     c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
+                BLANCE_LAUNCH_NOSYNC(k_bucket_scatter, cdiv(nbc, 64), 64, 0, sm, P, c->regid.as<int32_t>(),
+                                     c->order.as<int32_t>(), nbc, c->bucket_counts.as<int32_t>(),
+                                     c->chain_order.as<int32_t>());
+                BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->chain_order.as<int32_t>(),
+                                     c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
+                                     c->node_leaf_pos.as<int32_t>(), c->rec.as<int32_t>());
+                HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
+                                      hipMemcpyDeviceToDevice, sm));
+                ChainParams cq;
+                memset(&cq, 0, sizeof cq);
+                cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k; cq.top_state = h.top_state;
+                cq.NP = NP; cq.RW = RW; cq.OW = OW; cq.higher_mask = higher_mask; cq.booster_kind = h.booster_kind;
+                cq.n_regions = B;
+                cq.reg_lo = rr.reg_lo.as<int32_t>(); cq.reg_hi = rr.reg_hi.as<int32_t>();
+                cq.reg_off = c->reg_off.as<int32_t>();
+                cq.leaf_node = c->leaf_node.as<int32_t>();
+                cq.anchors = c->anchors.as<AnchorSet>() + (size_t)r0 * (NX + 1);
+                cq.alive = c->alive.as<uint8_t>();
+                cq.node_weight = c->node_weight.as<int32_t>();
+                cq.node_has_weight = c->node_has_weight.as<uint8_t>();
+                cq.cnt = c->cnt.as<int32_t>(); cq.ntn = c->ntn.as<int32_t>();
+                cq.rec = c->rec.as<int32_t>(); cq.out = c->out.as<int32_t>();
+                cq.flags = scal + 4;
+                HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
+                bool launched = dispatch_chain(c, cq, rr.max_size);
+                HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
+                launches += 7;
+                if (launched) {
+                    n_pass++;
+                    int32_t fl[2] = {0, 0};
+                    HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
+                    HIPTRY(hipStreamSynchronize(sm));
+                    if (!fl[0] && !fl[1]) {
+                        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, OW, c->chain_order.as<int32_t>(),
+                                             c->rec.as<int32_t>(), c->out.as<int32_t>());
+                        launches++;
+                        batched += P;
+                        done = true;
+                    } else {                                        // not region-local after all: redo in order
+                        HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
+                                              hipMemcpyDeviceToDevice, sm));
+                    }
+                }
+            }
+            if (!done) {
+            BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->order.as<int32_t>(),
+                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
+                                 c->node_leaf_pos.as<int32_t>(), c->rec.as<int32_t>());
             PassParams q;
             memset(&q, 0, sizeof q);
             q.N = N; q.NX = NX; q.M = M; q.L = L; q.P = P; q.s = m; q.k = k; q.top_state = h.top_state;
-            q.NP = NP; q.RW = RW; q.OW = 1 + k;
-            q.higher_mask = 0;
-            for (int t = 0; t < M; t++)
-                if (c->state_priority[t] < c->state_priority[m]) q.higher_mask |= 1 << t;
+            q.NP = NP; q.RW = RW; q.OW = OW;
+            q.higher_mask = higher_mask;
             q.hier = !h.hierarchy_rules_nil;
-            q.rule_begin = c->rule_off[m]; q.rule_end = c->rule_off[m + 1];
+            q.rule_begin = r0; q.rule_end = r1;
             q.booster_kind = h.booster_kind;
             q.n_alive = c->n_alive;
             q.vertex_empty_anchor = NX;
@@ -1134,11 +1644,6 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             q.warn_state = c->warn_state.as<int32_t>();
             q.warn_count = scal + 0;
             q.err = scal + 2;
-            while (c->pass_events.size() < 2 * (size_t)(n_pass + 1)) {
-                hipEvent_t ev;
-                HIPTRY(hipEventCreate(&ev));
-                c->pass_events.push_back(ev);
-            }
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
             int e = dispatch_pass(c, q);
             if (e) return e;
@@ -1146,6 +1651,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             n_pass++;
             BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, q.OW, c->order.as<int32_t>(),
                                  c->rec.as<int32_t>(), c->out.as<int32_t>());
+            }
             launches += 7;
             steps += P;
         }
@@ -1172,6 +1678,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         float pm = 0.f;
         HIPTRY(hipEventElapsedTime(&pm, c->pass_events[2 * i], c->pass_events[2 * i + 1]));
         pass_ms += pm;
+        if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] pass kernel %d: %.3f ms\n", i, pm);
     }
     c->pass_ms = pass_ms;
     c->pass_launches = n_pass;
@@ -1179,6 +1686,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     c->converged = converged;
     c->device_ms = ms;
     c->steps_total = steps;
+    c->steps_batched = batched;
     c->kernel_launches = launches;
     c->planned = true;
     if (iterations == 0) c->n_warnings = 0;
@@ -1188,8 +1696,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         res->device_ms = ms;
         res->total_ms = ms;
         res->steps_total = steps;
-        res->steps_sequential = steps;
-        res->steps_batched = 0;
+        res->steps_sequential = steps - batched;
+        res->steps_batched = batched;
         res->kernel_launches = launches;
         res->n_warnings = c->n_warnings;
         res->pass_kernel_ms = pass_ms;
@@ -1243,8 +1751,8 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     res->converged = c->converged;
     res->device_ms = c->device_ms;
     res->steps_total = c->steps_total;
-    res->steps_sequential = c->steps_total;
-    res->steps_batched = 0;
+    res->steps_sequential = c->steps_total - c->steps_batched;
+    res->steps_batched = c->steps_batched;
     res->kernel_launches = c->kernel_launches;
     res->pass_kernel_ms = c->pass_ms;
     res->pass_kernel_launches = c->pass_launches;

@@ -10,7 +10,8 @@ constexpr int kListAbsent = 0, kListNil = 1, kListSet = 2;   // include/blance_h
 constexpr int kMaxK = 8;         // largest supported Constraints per state
 constexpr int kMaxAnchors = 9;   // hierarchy anchors per fold: 1 + (#rules of a state) * k <= 9
 constexpr int kMaxStates = 16;
-constexpr int kRecHead = 4;      // step-record header words: partition, weight, stickiness (fp64)
+constexpr int kRecHead = 5;      // step-record header words: partition, weight, stickiness (fp64),
+                                 // leaf position of the top priority node (-1 if none)
 
 // One rule's include/exclude leaf intervals for one anchor (plan.go:723-734):
 // leaves(findAncestor(a, IncludeLevel)) = [alo, ahi), leaves(findAncestor(a, ExcludeLevel)) = [blo, bhi).
@@ -44,6 +45,28 @@ struct PassParams {
     int32_t* warn_state;
     int32_t* warn_count;
     int32_t* err;                  // device error word (interval overflow ...)
+};
+
+// Parameters of a state pass run as independent per-region chains (DESIGN.md
+// "Region chains"): one wave64 per hierarchy region walks that region's steps.
+struct ChainParams {
+    int32_t N, NX, M, L;
+    int32_t s, k, top_state, NP, RW, OW;
+    int32_t higher_mask, booster_kind;
+    int32_t n_regions, ntn_in_lds;
+    const int32_t* reg_lo;         // [n_regions] leaf interval of the region
+    const int32_t* reg_hi;
+    const int32_t* reg_off;        // [n_regions + 1] step range of the region in chain order
+    const int32_t* leaf_node;      // [n_leaves] node id at a leaf position, -1 if none
+    const AnchorSet* anchors;      // the state's single rule: [NX + 1]
+    const uint8_t* alive;
+    const int32_t* node_weight;
+    const uint8_t* node_has_weight;
+    int32_t* cnt;
+    int32_t* ntn;
+    const int32_t* rec;            // [P * RW] step records in chain order
+    int32_t* out;                  // [P * OW]
+    int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape
 };
 
 }  // namespace blance

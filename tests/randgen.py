@@ -140,3 +140,68 @@ def random_case(seed, max_nodes=12, max_parts=24):
             "model": model, "booster": booster, "seed": seed}
     case.update(opts)
     return case
+
+
+def random_regular_case(seed, max_parts=60):
+    """Inputs whose hierarchy rule cuts the cluster into regions (uniform
+    rack/zone trees), the shape the region-chain kernel accepts -- with enough
+    variety (existing layouts, weights, removals, tiny regions) to also hit
+    its escape path."""
+    rng = random.Random(seed)
+    rack = rng.choice([1, 2, 3, 4])
+    racks_per_zone = rng.choice([2, 2, 3, 4])
+    n_zones = rng.choice([2, 2, 3, 5])
+    n_nodes = rack * racks_per_zone * n_zones - rng.choice([0, 0, 0, 1, 2])
+    nodes = ["n%03d" % i for i in range(n_nodes)]
+    hier = {}
+    for i, n in enumerate(nodes):
+        hier[n] = "r%02d" % (i // rack)
+    for r in range((n_nodes + rack - 1) // rack):
+        hier["r%02d" % r] = "z%d" % (r // racks_per_zone)
+    if rng.random() < 0.5:
+        for z in range(n_zones):
+            hier["z%d" % z] = "dc"
+    k_rep = rng.choice([1, 2, 2, 3])
+    model = {"primary": {"priority": 0, "constraints": 1},
+             "replica": {"priority": 1, "constraints": k_rep}}
+    rule = rng.choice([(2, 1), (2, 1), (2, 0), (1, 0), (3, 1), (2, 2)])
+    rules = {"replica": [{"includeLevel": rule[0], "excludeLevel": rule[1]}]}
+    if rng.random() < 0.15:
+        rules["primary"] = [{"includeLevel": 1, "excludeLevel": 0}]
+    n_parts = rng.randint(1, max_parts)
+    pnames = [str(i) for i in range(n_parts)]
+    mode = rng.choice(["fresh", "aliased", "aliased", "stale"])
+    prev, assign = {}, {}
+    if mode == "fresh":
+        for p in pnames:
+            assign[p] = {"name": p, "nodesByState": {}}
+    else:
+        for p in pnames:
+            pick = rng.sample(nodes, min(len(nodes), 1 + k_rep))
+            if mode == "aliased" and rng.random() < 0.8:
+                # a layout the rule itself could have produced: replicas in the primary's zone
+                z = [n for n in nodes if hier[hier[n]] == hier[hier[pick[0]]] and n != pick[0]]
+                rng.shuffle(z)
+                pick = [pick[0]] + z[:k_rep]
+            prev[p] = {"name": p, "nodesByState": {"primary": pick[:1], "replica": pick[1:]}}
+        if mode == "stale":
+            for p in pnames:
+                assign[p] = {"name": p, "nodesByState": {"primary": list(prev[p]["nodesByState"]["primary"])}}
+        else:
+            assign = None
+    to_remove = rng.sample(nodes, rng.choice([0, 0, 1, 2])) if mode != "fresh" or True else []
+    if mode == "fresh":
+        to_remove = []
+    rest = [n for n in nodes if n not in to_remove]
+    to_add = rng.sample(rest, rng.choice([0, 0, 2, len(rest)]) if len(rest) > 2 else 0)
+    opts = {"modelStateConstraints": None, "partitionWeights": None, "stateStickiness": None,
+            "nodeWeights": None, "nodeHierarchy": hier, "hierarchyRules": rules}
+    if rng.random() < 0.3:
+        opts["partitionWeights"] = {p: rng.choice([1, 2, 3, 10]) for p in pnames if rng.random() < 0.5}
+    if rng.random() < 0.3:
+        opts["nodeWeights"] = {n: rng.choice([1, 2, 3]) for n in nodes if rng.random() < 0.5}
+    case = {"prevMap": prev, "partitionsToAssign": assign, "aliased": assign is None,
+            "nodesAll": nodes, "nodesToRemove": to_remove, "nodesToAdd": to_add,
+            "model": model, "booster": None, "seed": seed}
+    case.update(opts)
+    return case

@@ -183,6 +183,28 @@ inline double __shfl_xor(double v, int mask, int = 64) {
 inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)emu::wave_exchange((uint32_t)v, src); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)emu::wave_exchange((uint32_t)v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
+// DPP lane selects used by wave_argmin: quad_perm (ctrl < 0x100), row_half_mirror, row_mirror
+inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+    int l = threadIdx.x & 63, from;
+    if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else { fprintf(stderr, "emu: dpp ctrl %x not modelled\n", ctrl); abort(); }
+    return (int)(uint32_t)emu::wave_exchange((uint32_t)src, from);
+}
+inline unsigned long long __ballot(int pred) {
+    if (!emu::t_block) return pred ? 1ull : 0ull;
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    uint64_t* x = &emu::t_block->xch[(size_t)w * 64];
+    x[l] = pred ? 1 : 0;
+    emu::wave_barrier();
+    unsigned long long m = 0;
+    int lanes = emu::t_block->wave_bar[w].expected;
+    for (int i = 0; i < lanes; i++) if (x[i]) m |= 1ull << i;
+    emu::wave_barrier();
+    return m;
+}
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 inline double __longlong_as_double(long long x) { double d; memcpy(&d, &x, 8); return d; }
 inline double __hiloint2double(int hi, int lo) {
