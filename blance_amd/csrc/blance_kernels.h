@@ -20,6 +20,7 @@ struct AnchorSet { int32_t alo, ahi, blo, bhi; };
 // Parameters of one state pass (assignStateToPartitions, plan.go:253-303).
 struct PassParams {
     int32_t N, NX, M, L, P;
+    int32_t beg, end;       // steps [beg, end) of the pass order run by this launch
     int32_t s;              // state id of this pass
     int32_t k;              // constraints
     int32_t top_state;
@@ -67,6 +68,28 @@ struct ChainParams {
     const int32_t* rec;            // [P * RW] step records in chain order
     int32_t* out;                  // [P * OW]
     int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape
+};
+
+// Flat (no hierarchy rule) passes resolved in bulk: DESIGN.md "Flat bulk engine".
+constexpr int kTopList = 8;      // smallest partition-independent scores kept for the stay test
+
+struct FlatParams {
+    int32_t N, NX, M, L, P;
+    int32_t s, k, top_state, NP, RW, OW;
+    int32_t higher_mask, booster_kind;
+    const uint8_t* alive;
+    const int32_t* node_weight;
+    const uint8_t* node_has_weight;
+    const int32_t* cnt;            // [(M + 1) * NX]
+    const int32_t* tot;            // [NX] sum over states, refreshed by k_flat_prepare
+    const double* g;               // [NX] partition-independent score of every node
+    const double* top_g;           // [kTopList] smallest (g, node) among nodesNext
+    const int32_t* top_n;
+    const int32_t* row_count;      // [NX + 1] steps of this pass per top priority node
+    int32_t* ntn;
+    const int32_t* rec;
+    int32_t* out;
+    int32_t* scan;                 // [0] first step that is not a certain stay, [1] first not fresh-identical
 };
 
 }  // namespace blance

@@ -205,6 +205,8 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline long long __double_as_longlong(double d) { long long x; memcpy(&x, &d, 8); return x; }
 
 inline double __longlong_as_double(long long x) { double d; memcpy(&d, &x, 8); return d; }
 inline double __hiloint2double(int hi, int lo) {

@@ -6,7 +6,7 @@ import pytest
 
 from blance_amd import hip, problem, synth
 from helpers import build_from_case
-from randgen import random_case
+from randgen import random_case, random_regular_case
 
 pytestmark = pytest.mark.gpu
 
@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def planner():
     pl = hip.Planner(device_id=0)
+    yield pl
+    pl.close()
+
+
+@pytest.fixture(scope="module")
+def eager_planner():
+    """Bulk engines (region chains, flat stay / fresh runs) switched on for passes
+    of any size, so small random inputs exercise them and their fallbacks."""
+    pl = hip.Planner(device_id=0, chain_min_parts=1)
     yield pl
     pl.close()
 
@@ -53,6 +62,56 @@ def test_random_instances(planner, block):
         _same(planner.plan(fp), _oracle(fp), seed)
         n += 1
     assert n > 150
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_instances_bulk_engines(eager_planner, block):
+    n = bulk = 0
+    for seed in range(block * 250, (block + 1) * 250):
+        try:
+            fp = build_from_case(random_case(seed))
+        except problem.Unsupported:
+            continue
+        got = eager_planner.plan(fp)
+        _same(got, _oracle(fp), seed)
+        n += 1
+        bulk += got.struct.steps_batched > 0
+    assert n > 150 and bulk > 20
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_regular_hierarchies_region_chains(eager_planner, block):
+    n = bulk = 0
+    for seed in range(block * 200, (block + 1) * 200):
+        try:
+            fp = build_from_case(random_regular_case(seed))
+        except problem.Unsupported:
+            continue
+        got = eager_planner.plan(fp)
+        _same(got, _oracle(fp), seed)
+        n += 1
+        bulk += got.struct.steps_batched > 0
+    assert n > 150 and bulk > 40
+
+
+def test_golden_cases_bulk_engines(eager_planner, golden_cases):
+    for c in golden_cases:
+        fp = build_from_case(c)
+        _same(eager_planner.plan(fp), _oracle(fp), c["source"])
+
+
+def test_sequential_engine_option(golden_cases):
+    """BLANCE_ENGINE_SEQUENTIAL: every step one at a time, same answer."""
+    from blance_amd import abi
+    pl = hip.Planner(device_id=0, engine=abi.ENGINE_SEQUENTIAL, chain_min_parts=1)
+    for c in golden_cases[::2]:
+        fp = build_from_case(c)
+        got = pl.plan(fp)
+        _same(got, _oracle(fp), c["source"])
+        assert got.struct.steps_batched == 0
+    fp = synth.config_flat(3, P=3000, N=512)
+    _same(pl.plan(fp), _oracle(fp), "cfg3 sequential")
+    pl.close()
 
 
 def test_random_larger_instances(planner):
