@@ -13,6 +13,9 @@
 #define BLANCE_DYN_LDS(ptr)                                        \
     extern __shared__ __align__(16) unsigned char blance_lds_[];   \
     unsigned char* ptr = blance_lds_
+// a wave64 runs in lockstep: LDS writes of one lane are seen by the other lanes'
+// later reads without a barrier; this only pins the compiler's schedule
+#define BLANCE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 #include <limits.h>
@@ -526,6 +529,45 @@ __device__ __forceinline__ int wave_argmin(double s, int n) {
     return bn;
 }
 
+#ifdef BLANCE_PHASE_PROF     // developer build only: per-phase shader-clock totals of chain 0
+#define PH_DECL unsigned long long ph_acc[12] = {0}, ph_t0 = clock64(), ph_t1
+#define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
+#define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
+    printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_DUMP(steps)
+#endif
+
+// nodeSorter.Score with the two quotients that do not depend on the node taken
+// from LDS tables filled by the same expressions (bit-identical by construction).
+__device__ __forceinline__ double chain_score(int cnt, int ntn, int tot, int hasw, int w, int NP, double cf,
+                                              int booster, const double* lp_tab, const double* ff_tab) {
+    double lp = 0.0, ff = 0.0;
+    if (NP > 0) {
+        bool lin = (unsigned)ntn < (unsigned)kLpTab, fin = (unsigned)tot < (unsigned)kFfTab;
+        lp = lp_tab[lin ? ntn : 0];
+        ff = ff_tab[fin ? tot : 0];
+        if (!lin) lp = (double)ntn / (double)NP;
+        if (!fin) ff = (0.001 * (double)tot) / (double)NP;
+    }
+    double r = (double)cnt;
+    r = r + lp;
+    r = r + ff;
+    if (hasw) {
+        if (w > 0) {
+            r = r / (double)w;
+        } else if (w < 0 && booster == BLANCE_BOOSTER_CBGT) {
+            double b = (double)(-w);
+            if (b < cf) b = cf;
+            r = r + b;
+        }
+    }
+    r = r - cf;
+    return r;
+}
+
 template <int NPTC, int KM>
 __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     BLANCE_DYN_LDS(lds);
@@ -537,209 +579,443 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     if (cbeg >= cend) return;
     const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k;
     const int SW = 1 + L;
-    int* xs_lo = (int*)lds;              // exclude interval of each region leaf used as an anchor
-    int* xs_hi = xs_lo + size;
-    int* ntn_l = xs_hi + size;           // [size][size] nodeToNodeCounts of this region's rows
+    // LDS: quotient tables, a 64-step staging area for step records and outputs (no
+    // global memory operation inside the step loop), the region's nodeToNodeCounts rows
+    double* lp_tab = (double*)lds;                   // [kLpTab]
+    double* ff_tab = lp_tab + kLpTab;                // [kFfTab]
+    double* gL = ff_tab + kFfTab;                    // [size] mirrors of the per-leaf registers,
+    double* ffL = gL + size;                         // [size] (0.001 * tot) / NP of the leaf
+    int* cntL = (int*)(ffL + size);                  // [size] read by the stay validators
+    int* totL = cntL + size;
+    int* nidL = totL + size;
+    int* wgtL = nidL + size;
+    int* flgL = wgtL + size;                         // bit 0 alive (in nodesNext), bit 1 has weight
+    int* xloL = flgL + size;                         // exclude interval of the leaf's node as an anchor
+    int* xhiL = xloL + size;
+    int* recbuf = xhiL + size;                       // [64][RW]
+    int* outbuf = recbuf + 64 * q.RW;                // [64][OW]
+    int* ntn_l = outbuf + 64 * q.OW;                 // [size][ST] nodeToNodeCounts rows, padded stride
+    const int ST = size + 1;
+    if (NP > 0) {
+        for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = (double)i / (double)NP;
+        for (int i = lane; i < kFfTab; i += 64) ff_tab[i] = (0.001 * (double)i) / (double)NP;
+        if (q.ntn_in_lds)
+            for (int i = lane; i < size * ST; i += 64) ntn_l[i] = 0;
+    }
+    __syncthreads();
 
-    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC];
+    // lane l owns leaves lo + l + 64 u: node id, counters, exclude interval as an anchor
+    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], xsl[NPTC], xsh[NPTC], pos[NPTC];
     unsigned alive_m = 0, hasw_m = 0;
     double g[NPTC];
 #pragma unroll
-    for (int i = 0; i < NPTC; i++) {
-        int pos = lo + lane + 64 * i;
-        nid[i] = -1; cntv[i] = 0; totv[i] = 0; wv[i] = 0; g[i] = 0.0;
-        if (pos < hi) {
-            int n = q.leaf_node[pos];
-            nid[i] = n;
-            int blo = 0, bhi = 0;
+    for (int u = 0; u < NPTC; u++) {
+        pos[u] = lo + lane + 64 * u;
+        nid[u] = -2; cntv[u] = 0; totv[u] = 0; wv[u] = 0; xsl[u] = 0; xsh[u] = 0; g[u] = 0.0;
+        if (pos[u] < hi) {
+            int n = q.leaf_node[pos[u]];
             if (n >= 0) {
-                cntv[i] = q.cnt[s * NX + n];
+                nid[u] = n;
+                cntv[u] = q.cnt[s * NX + n];
                 int tsum = 0;
                 for (int t = 0; t <= M; t++) tsum += q.cnt[t * NX + n];
-                totv[i] = tsum;
-                wv[i] = q.node_weight[n];
-                if (q.node_has_weight[n]) hasw_m |= 1u << i;
-                if (n < N && q.alive[n]) alive_m |= 1u << i;
-                g[i] = node_score(cntv[i], 0, totv[i], (hasw_m >> i) & 1, wv[i], NP, 0.0, q.booster_kind);
-                blo = q.anchors[n].blo; bhi = q.anchors[n].bhi;
+                totv[u] = tsum;
+                wv[u] = q.node_weight[n];
+                if (q.node_has_weight[n]) hasw_m |= 1u << u;
+                if (n < N && q.alive[n]) alive_m |= 1u << u;
+                g[u] = chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind, lp_tab, ff_tab);
+                xsl[u] = q.anchors[n].blo; xsh[u] = q.anchors[n].bhi;
             }
-            xs_lo[pos - lo] = blo;
-            xs_hi[pos - lo] = bhi;
+            const int i = lane + 64 * u;
+            gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u]; nidL[i] = nid[u]; wgtL[i] = wv[u];
+            ffL[i] = NP > 0 ? (0.001 * (double)totv[u]) / (double)NP : 0.0;
+            flgL[i] = ((alive_m >> u) & 1) | (((hasw_m >> u) & 1) << 1);
+            xloL[i] = xsl[u]; xhiL[i] = xsh[u];
         }
     }
-    if (NP > 0 && q.ntn_in_lds)
-        for (int i = lane; i < size * size; i += 64) ntn_l[i] = 0;
-    __syncthreads();
-
-    int recw = 0, recw_next = 0;
-    if (lane < q.RW) recw_next = q.rec[(size_t)cbeg * q.RW + lane];
     bool escaped = false;
+    // stay speculation: tried again whenever the last general step turned out to be a stay
+    const bool spec_ok = q.ntn_in_lds || NP == 0;
+    bool try_spec = true, gmin_dirty = true;
+    double gmin_s = 0.0;
+    int gmin_n = INT_MAX;
+    int spec_steps = 0, spec_batches = 0;          // statistics (lane 0)
+    PH_DECL;
 
-    for (int ci = cbeg; ci < cend && !escaped; ci++) {
-        recw = recw_next;
-        if (ci + 1 < cend && lane < q.RW) recw_next = q.rec[(size_t)(ci + 1) * q.RW + lane];
+    for (int base = cbeg; base < cend && !escaped; base += 64) {
+      const int nb = cend - base < 64 ? cend - base : 64;
+      PH(0);
+      for (int i = lane; i < nb * q.RW; i += 64) recbuf[i] = q.rec[(size_t)base * q.RW + i];
+      __syncthreads();
+      int b = 0;
+      while (b < nb) {
+        // ---- Speculate that the next (up to 64) steps keep their nodes.  A stay
+        // changes no counter, so under that hypothesis every step sees the state as
+        // it is now and lane a can check step b + a on its own: the partition's
+        // nodes, scored exactly (stickiness, nodeToNodeCounts row), must beat a lower
+        // bound of every other candidate -- the smallest partition-independent score
+        // of the region (the terms it leaves out are >= 0 and IEEE add / divide /
+        // subtract are monotone).  The verified prefix is committed; the first step
+        // that is not a certain stay takes the general step below.
+        if (spec_ok && try_spec) {
+            if (gmin_dirty) {                      // smallest (g, node) over the region's live leaves
+                double ms = pos_inf();
+                int mn = INT_MAX;
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    const bool ok = (alive_m >> u) & 1;
+                    const bool take = ok && better(g[u], nid[u], ms, mn);
+                    ms = take ? g[u] : ms;
+                    mn = take ? nid[u] : mn;
+                }
+                gmin_n = wave_argmin(ms, mn);
+                gmin_s = pos_inf();
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    unsigned long long bm = __ballot(nid[u] == gmin_n);
+                    if (bm) {
+                        int wl = __ffsll((long long)bm) - 1;
+                        gmin_s = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(g[u]), wl),
+                                                  __builtin_amdgcn_readlane(__double2loint(g[u]), wl));
+                    }
+                }
+                gmin_dirty = false;
+            }
+            const int a = lane;
+            const int sb = b + a;
+            const bool active = sb < nb;
+            const int* rp = recbuf + (active ? sb : b) * q.RW;
+            bool fail = false;
+            const double vstick = __hiloint2double(rp[3], rp[2]);
+            const int vtl = rp[4] - lo;
+            const int hs = rp[kRecHead + s * SW];
+            if ((hs >> 16) == kListAbsent || (hs & 0xffff) != k) fail = true;
+            int o[KM], oi[KM], blo[KM], bhi[KM];
+            double so[KM];
+#pragma unroll
+            for (int j = 0; j < KM; j++) { o[j] = -3; oi[j] = 0; so[j] = 0.0; blo[j] = 0; bhi[j] = 0; }
+            blo[0] = rp[5]; bhi[0] = rp[6];
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                if (j < k) {
+                    o[j] = rp[kRecHead + s * SW + 1 + j];
+                    int li = rp[kRecHead + M * SW + j] - lo;
+                    if (li < 0 || li >= size || o[j] < 0) { fail = true; li = 0; }
+                    oi[j] = li;
+                    if (j + 1 < KM) { blo[j + 1] = xloL[li]; bhi[j + 1] = xhiL[li]; }
+                }
+            }
+            // nodes of the other states: a node held twice would move (plan.go:290-297);
+            // a higher priority node is no candidate (plan.go:146-154)
+            for (int t = 0; t < M; t++) {
+                if (t == s) continue;
+                const int hdr = rp[kRecHead + t * SW];
+                if ((hdr >> 16) == kListAbsent) continue;
+                for (int j = 0; j < L; j++) {
+                    const int x = rp[kRecHead + t * SW + 1 + j];
+#pragma unroll
+                    for (int jj = 0; jj < KM; jj++) if (x >= 0 && x == o[jj]) fail = true;
+                }
+            }
+            // the anchors' exclude intervals must be representable exactly (as in the general step)
+            {
+                int cov = 0;
+#pragma unroll
+                for (int j = 0; j < KM; j++) {               // anchors 0..k-1 decide the k picks
+                    if (j < k) {
+                        bool dup = false;
+#pragma unroll
+                        for (int e = 0; e < KM; e++) {
+                            if (e < j) {
+                                if (blo[e] == blo[j] && bhi[e] == bhi[j]) dup = true;
+                                else if (!(bhi[j] <= blo[e] || blo[j] >= bhi[e])) fail = true;
+                            }
+                        }
+                        if (blo[j] < lo || bhi[j] > hi || bhi[j] - blo[j] >= size) fail = true;
+                        if (!dup) cov += bhi[j] - blo[j];
+                        if (cov >= size) fail = true;
+                    }
+                }
+            }
+            // the partition's own nodes: candidates of their slot, in list order, below the bound
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                if (j < k) {
+                    const int li = oi[j], p = lo + li;
+                    if (!(flgL[li] & 1) || nidL[li] != o[j]) fail = true;
+#pragma unroll
+                    for (int e = 0; e < KM; e++) if (e <= j && p >= blo[e] && p < bhi[e]) fail = true;
+                    const int nt = NP > 0 ? ntn_l[vtl * ST + li] : 0;
+                    so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
+                                        q.booster_kind, lp_tab, ff_tab);
+                    if (j > 0 && !better(so[j - 1], o[j - 1], so[j], o[j])) fail = true;
+                    if (!better(so[j], o[j], gmin_s, gmin_n)) fail = true;
+                }
+            }
+            // an earlier step of the batch with the same top priority node would have bumped my row
+            if (NP > 0) {
+                for (int e = 0; e < 64; e++) {
+                    const int t2 = __builtin_amdgcn_readlane(vtl, e);
+                    if (e < a && t2 == vtl) fail = true;
+                }
+            }
+            if (!active) fail = false;
+            const unsigned long long fm = __ballot(fail);
+            int nok = fm ? __ffsll((long long)fm) - 1 : 64;
+            if (nok > nb - b) nok = nb - b;
+            if (a < nok) {
+                int* op = outbuf + sb * q.OW;
+                op[0] = k;
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < k) {
+                        op[1 + j] = o[j];
+                        if (NP > 0) ntn_l[vtl * ST + oi[j]] += 1;      // plan.go:238-245
+                    }
+                }
+            }
+            BLANCE_WAVE_SYNC();
+            if (lane == 0) { spec_steps += nok; spec_batches++; }
+            b += nok;
+            if (b >= nb) break;
+            if (nok == 64) continue;
+        }
+        PH(1);
+        const int recw = lane < q.RW ? recbuf[b * q.RW + lane] : 0;
 #define REC(i) __builtin_amdgcn_readlane(recw, (i))
         const int w = REC(1);
         const double stick = __hiloint2double(REC(3), REC(2));
         const int tl = REC(4) - lo;                      // local leaf index of the top priority node
         const int top = REC(kRecHead + q.top_state * SW + 1);
-
         int ntnv[NPTC];
 #pragma unroll
-        for (int i = 0; i < NPTC; i++) {
-            ntnv[i] = 0;
+        for (int u = 0; u < NPTC; u++) {
+            ntnv[u] = 0;
             if (NP > 0) {
-                if (q.ntn_in_lds) { if (lane + 64 * i < size) ntnv[i] = ntn_l[tl * size + lane + 64 * i]; }
-                else if (nid[i] >= 0 && nid[i] < N) ntnv[i] = q.ntn[(size_t)top * N + nid[i]];
+                if (q.ntn_in_lds) { if (lane + 64 * u < size) ntnv[u] = ntn_l[tl * ST + lane + 64 * u]; }
+                else if (nid[u] >= 0 && nid[u] < N) ntnv[u] = q.ntn[(size_t)top * N + nid[u]];
             }
         }
+        PH(2);
+        // my leaves in the higher priority lists (plan.go:146-154) / in this state's list (plan.go:654-662)
         unsigned inh_m = 0, own_m = 0;
         for (int t = 0; t < M; t++) {
-            int hdr = REC(kRecHead + t * SW);
-            if ((hdr >> 16) == kListAbsent) continue;
-            int len = hdr & 0xffff;
-            bool higher = (q.higher_mask >> t) & 1;
-            if (!higher && t != s) continue;
-            for (int j = 0; j < len; j++) {
-                int x = REC(kRecHead + t * SW + 1 + j);
+            const int hdr = REC(kRecHead + t * SW);
+            const bool present = (hdr >> 16) != kListAbsent;
+            const unsigned hi_t = (present && ((q.higher_mask >> t) & 1)) ? 1u : 0u;
+            const unsigned own_t = (present && t == s) ? 1u : 0u;
+            if (!(hi_t | own_t)) continue;
+            for (int j = 0; j < L; j++) {
+                const int x = REC(kRecHead + t * SW + 1 + j);          // -1 past the end of the list
 #pragma unroll
-                for (int i = 0; i < NPTC; i++) {
-                    if (x == nid[i]) {
-                        if (higher) inh_m |= 1u << i;
-                        if (t == s) own_m |= 1u << i;
-                    }
+                for (int u = 0; u < NPTC; u++) {
+                    const unsigned eq = x == nid[u] ? 1u : 0u;
+                    inh_m |= (eq & hi_t) << u;
+                    own_m |= (eq & own_t) << u;
                 }
             }
         }
+        PH(3);
         const unsigned elig_m = alive_m & ~inh_m;
         double sc[NPTC];
-#pragma unroll
-        for (int i = 0; i < NPTC; i++) {
-            bool own = (own_m >> i) & 1;
-            if (own || ntnv[i] != 0)
-                sc[i] = node_score(cntv[i], ntnv[i], totv[i], (hasw_m >> i) & 1, wv[i], NP,
-                                   own ? stick : 0.0, q.booster_kind);
-            else
-                sc[i] = g[i];
-        }
-
-        // the rule's k picks (plan.go:177-223); every anchor's include set is this region
-        FoldT<KM + 1> f;
-        fold_reset(f);
-        int err = 0;
         {
-            AnchorSet a;
-            a.alo = lo; a.ahi = hi; a.blo = uni(xs_lo[tl]); a.bhi = uni(xs_hi[tl]);
-            fold_step(f, a, &err);
+            unsigned need_m = own_m;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) if (ntnv[u] != 0) need_m |= 1u << u;
+            if (__ballot(need_m != 0)) {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    double full = chain_score(cntv[u], ntnv[u], totv[u], (hasw_m >> u) & 1, wv[u], NP,
+                                              ((own_m >> u) & 1) ? stick : 0.0, q.booster_kind, lp_tab, ff_tab);
+                    sc[u] = ((need_m >> u) & 1) ? full : g[u];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) sc[u] = g[u];
+            }
         }
+        PH(4);
+        // The rule's k picks (plan.go:177-223).  Every anchor's include set is this
+        // region, so the running set is the region minus the anchors' exclude
+        // intervals; anything the simple bookkeeping below cannot represent exactly
+        // (empty set -> reset, nested intervals, fallback picks) escapes.
+        int xb_lo[KM], xb_hi[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) { xb_lo[j] = 0; xb_hi[j] = 0; }
+        int n_x = 0, covered = 0;
+        unsigned excl_m = 0;
+        bool esc = false;
         int chosen[KM];
 #pragma unroll
         for (int j = 0; j < KM; j++) chosen[j] = -1;
         int n_out = 0;
+        int alo = REC(5), ahi = REC(6);                  // exclude interval of the top priority node
+        PH(5);
         for (int slot = 0; slot < k; slot++) {
+            {   // add the anchor's exclude interval
+                bool dup = false, clash = false;
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < n_x) {
+                        if (xb_lo[j] == alo && xb_hi[j] == ahi) dup = true;
+                        else if (!(ahi <= xb_lo[j] || alo >= xb_hi[j])) clash = true;
+                    }
+                }
+                if (alo < lo || ahi > hi || ahi - alo >= size || clash) esc = true;
+                if (!dup) {
+#pragma unroll
+                    for (int j = 0; j < KM; j++) if (j == n_x) { xb_lo[j] = alo; xb_hi[j] = ahi; }
+                    n_x++;
+                    covered += ahi - alo;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) excl_m |= (pos[u] >= alo && pos[u] < ahi) ? (1u << u) : 0u;
+                }
+                if (covered >= size) esc = true;
+            }
             double bs = pos_inf();
             int bn = INT_MAX;
 #pragma unroll
             for (int u = 0; u < NPTC; u++) {
-                if (((elig_m >> u) & 1) && fold_contains(f, lo + lane + 64 * u) &&
-                    better(sc[u], nid[u], bs, bn)) {
-                    bs = sc[u]; bn = nid[u];
-                }
+                const bool ok = ((elig_m & ~excl_m) >> u) & 1;
+                const bool take = ok && better(sc[u], nid[u], bs, bn);
+                bs = take ? sc[u] : bs;
+                bn = take ? nid[u] : bn;
             }
-            int best = wave_argmin(bs, bn);
-            if (best == INT_MAX) { escaped = true; break; }      // would fall back to candidateNodes[0]
-            int wl = 0;
+            PH(6);
+            const int best = wave_argmin(bs, bn);
+            PH(7);
+            if (best == INT_MAX) esc = true;
+            // the winner's exclude interval becomes the next anchor
+            int wlo = 0, whi = 0;
 #pragma unroll
             for (int u = 0; u < NPTC; u++) {
                 unsigned long long bm = __ballot(nid[u] == best);
-                if (bm) wl = __ffsll((long long)bm) - 1 + 64 * u;
+                if (bm) {
+                    int wl = __ffsll((long long)bm) - 1;
+                    wlo = __builtin_amdgcn_readlane(xsl[u], wl);
+                    whi = __builtin_amdgcn_readlane(xsh[u], wl);
+                }
             }
-            wl = uni(wl);
-            bool dup = false;
 #pragma unroll
-            for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == best) dup = true;
-            if (!dup) {
+            for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == best) esc = true;   // duplicate pick
 #pragma unroll
-                for (int c = 0; c < KM; c++) if (c == n_out) chosen[c] = best;
-                n_out++;
-            }
-            AnchorSet a;
-            a.alo = lo; a.ahi = hi; a.blo = uni(xs_lo[wl]); a.bhi = uni(xs_hi[wl]);
-            fold_step(f, a, &err);
+            for (int c = 0; c < KM; c++) if (c == n_out) chosen[c] = best;
+            n_out++;
+            alo = wlo; ahi = whi;
+            PH(8);
         }
-        if (n_out < k || err) escaped = true;                    // would need the global candidate list
-        if (escaped) break;
+        if (esc) { escaped = true; break; }
 
-        // ---- commit: as in k_pass_seq, the owner lane of a node updates it
-        unsigned changed_m = 0;
-        for (int t = 0; t < M; t++) {
-            int hdr = REC(kRecHead + t * SW);
-            if ((hdr >> 16) == kListAbsent) continue;
-            int len = hdr & 0xffff;
-            for (int j = 0; j < len; j++) {
-                int x = REC(kRecHead + t * SW + 1 + j);
-                bool hit = (t == s);
-                if (!hit) {
-                    int hs = REC(kRecHead + s * SW);
-                    if ((hs >> 16) != kListAbsent) {
-                        int ls = hs & 0xffff;
-                        for (int jj = 0; jj < ls; jj++)
-                            if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
-                    }
+        // ---- commit (plan.go:238-245, :290-301): the owner lane of a leaf updates it
+        int dc[NPTC], dt[NPTC];
+#pragma unroll
+        for (int u = 0; u < NPTC; u++) { dc[u] = 0; dt[u] = 0; }
+        {
+            const int hs = REC(kRecHead + s * SW);
+            const bool s_present = (hs >> 16) != kListAbsent;
+            for (int j = 0; j < L; j++) {                 // old nodes of this state leave it
+                const int x = s_present ? REC(kRecHead + s * SW + 1 + j) : -1;
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) { int d = x == nid[u] ? w : 0; dc[u] -= d; dt[u] -= d; }
+            }
+            for (int t = 0; t < M; t++) {                 // a node of another state that also held this
+                if (t == s) continue;                     // state or is chosen now leaves that state
+                const int hdr = REC(kRecHead + t * SW);
+                if ((hdr >> 16) == kListAbsent) continue;
+                for (int j = 0; j < L; j++) {
+                    const int x = REC(kRecHead + t * SW + 1 + j);
+                    if (x < 0) continue;
+                    bool hit = false;
+                    if (s_present)
+                        for (int jj = 0; jj < L; jj++) if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
 #pragma unroll
                     for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == x) hit = true;
-                }
-                if (!hit) continue;
+                    if (!hit) continue;
 #pragma unroll
-                for (int u = 0; u < NPTC; u++) {
-                    if (x == nid[u]) {
-                        totv[u] -= w;
-                        if (t == s) cntv[u] -= w;
-                        changed_m |= 1u << u;
-                    }
+                    for (int u = 0; u < NPTC; u++) dt[u] -= x == nid[u] ? w : 0;
+                    if (lane == 0) q.cnt[t * NX + x] -= w;
                 }
-                if (t != s && lane == 0) q.cnt[t * NX + x] -= w;
             }
         }
 #pragma unroll
         for (int c = 0; c < KM; c++) {
             if (c < n_out) {
-                int x = chosen[c];
+                const int x = chosen[c];
 #pragma unroll
                 for (int u = 0; u < NPTC; u++) {
-                    if (x == nid[u]) {
-                        cntv[u] += w;
-                        totv[u] += w;
-                        changed_m |= 1u << u;
-                        if (NP > 0) {
-                            if (q.ntn_in_lds) ntn_l[tl * size + lane + 64 * u] = ntnv[u] + 1;
-                            else q.ntn[(size_t)top * N + x] = ntnv[u] + 1;
-                        }
+                    const bool mine = x == nid[u];
+                    dc[u] += mine ? w : 0;
+                    dt[u] += mine ? w : 0;
+                    if (NP > 0 && mine) {
+                        if (q.ntn_in_lds) ntn_l[tl * ST + lane + 64 * u] = ntnv[u] + 1;
+                        else q.ntn[(size_t)top * N + x] = ntnv[u] + 1;
                     }
                 }
             }
         }
-        if (changed_m) {
+        PH(9);
+        {
+            unsigned changed_m = 0;
 #pragma unroll
-            for (int u = 0; u < NPTC; u++)
-                if ((changed_m >> u) & 1)
-                    g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
+            for (int u = 0; u < NPTC; u++) {
+                cntv[u] += dc[u];
+                totv[u] += dt[u];
+                if (dc[u] | dt[u]) changed_m |= 1u << u;
+            }
+            if (__ballot(changed_m != 0)) {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    double gn = chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind,
+                                            lp_tab, ff_tab);
+                    g[u] = ((changed_m >> u) & 1) ? gn : g[u];
+                    if ((changed_m >> u) & 1) {
+                        const int i = lane + 64 * u;
+                        gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u];
+                        double f = 0.0;
+                        if (NP > 0) {
+                            f = ff_tab[(unsigned)totv[u] < (unsigned)kFfTab ? totv[u] : 0];
+                            if ((unsigned)totv[u] >= (unsigned)kFfTab) f = (0.001 * (double)totv[u]) / (double)NP;
+                        }
+                        ffL[i] = f;
+                    }
+                }
+            }
+        }
+        PH(10);
+        {
+            // did this step keep its nodes?  then the next ones probably do, too
+            const int hs2 = REC(kRecHead + s * SW);
+            bool same = (hs2 >> 16) != kListAbsent && (hs2 & 0xffff) == n_out;
+#pragma unroll
+            for (int c = 0; c < KM; c++)
+                if (c < n_out && c < L && REC(kRecHead + s * SW + 1 + c) != chosen[c]) same = false;
+            try_spec = same;
+            gmin_dirty = true;
         }
         if (lane == 0) {
-            int* o = q.out + (size_t)ci * q.OW;
+            int* o = outbuf + b * q.OW;
             o[0] = n_out;
 #pragma unroll
             for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
         }
+        PH(11);
 #undef REC
+        BLANCE_WAVE_SYNC();
+        b++;
+      }
+      __syncthreads();
+      if (!escaped)
+          for (int i = lane; i < nb * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
     }
+    PH_DUMP(cend - cbeg);
+    if (lane == 0 && spec_batches) { atomicAdd(&q.flags[2], spec_steps); atomicAdd(&q.flags[3], spec_batches); }
     if (escaped) {
         if (lane == 0) q.flags[1] = 1;
         return;
     }
 #pragma unroll
-    for (int i = 0; i < NPTC; i++)
-        if (nid[i] >= 0) q.cnt[s * NX + nid[i]] = cntv[i];
+    for (int u = 0; u < NPTC; u++)
+        if (nid[u] >= 0) q.cnt[s * NX + nid[u]] = cntv[u];
 }
 
 // ============================================================================
@@ -1281,7 +1557,7 @@ __global__ void k_bucket_scatter(int P, const int32_t* regid, const int32_t* ord
 // Step records in pass order: what findBestNodes needs to know about its partition.
 __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
                          const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
-                         const int32_t* node_leaf_pos, int32_t* rec) {
+                         const int32_t* node_leaf_pos, const AnchorSet* rule_anchors, int32_t* rec) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
     if (oi >= d.P) return;
     int p = order[oi];
@@ -1298,6 +1574,8 @@ __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32
         int idxT = p * d.M + top_state;
         int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
         r[4] = top >= 0 ? node_leaf_pos[top] : -1;
+        r[5] = (top >= 0 && rule_anchors) ? rule_anchors[top].blo : 0;
+        r[6] = (top >= 0 && rule_anchors) ? rule_anchors[top].bhi : 0;
     }
     for (int t = 0; t < d.M; t++) {
         int idx = p * d.M + t;
@@ -1305,6 +1583,9 @@ __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32
         int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
         rs[0] = len | ((int)d.live_kind[idx] << 16);
         for (int i = 0; i < d.L; i++) rs[1 + i] = i < len ? d.live[(size_t)idx * d.L + i] : -1;
+        if (t == m)                                    // leaf positions of this state's nodes (chain stay test)
+            for (int i = 0; i < d.L; i++)
+                r[kRecHead + d.M * (1 + d.L) + i] = i < len ? node_leaf_pos[d.live[(size_t)idx * d.L + i]] : -1;
     }
 }
 
@@ -1552,7 +1833,7 @@ extern "C" int blance_validate(const blance_problem* pb) {
         if (a > L) L = a;
         if (b > L) L = b;
     }
-    if (kRecHead + M * (1 + L) > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
+    if (kRecHead + M * (1 + L) + L > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
     if ((int64_t)(NX + 1) * (N > 0 ? N : 1) * 4 > (int64_t)64 << 30) return fail(BLANCE_ERR_UNSUPPORTED, "nodeToNodeCounts matrix > 64 GiB");
     return BLANCE_OK;
 }
@@ -1728,7 +2009,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
             }
         }
     }
-    const int RW = kRecHead + M * (1 + L);
+    const int RW = kRecHead + M * (1 + L) + L;   // header, per-state lists, leaf positions of this state's nodes
     int kmax = 1;
     for (int m = 0; m < M; m++) if (pb->state_constraints[m] > kmax) kmax = pb->state_constraints[m];
     RESERVE(live, sizeof(int32_t) * (size_t)(PM * L + 1));
@@ -1913,9 +2194,10 @@ static void launch_chain(blance_ctx* c, const ChainParams& q, size_t lds) {
 // one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
 static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
     int nptc = cdiv(max_size, 64);
-    size_t ntn_bytes = sizeof(int32_t) * (size_t)max_size * max_size;
-    q.ntn_in_lds = ntn_bytes <= 140 * 1024;
-    size_t lds = sizeof(int32_t) * 2 * (size_t)max_size + (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
+    size_t ntn_bytes = sizeof(int32_t) * (size_t)max_size * (max_size + 1);
+    q.ntn_in_lds = ntn_bytes <= 100 * 1024;
+    size_t lds = sizeof(double) * (kLpTab + kFfTab + 2 * (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
+                 sizeof(int32_t) * 64 * (size_t)(q.RW + q.OW) + (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
     if (q.k <= 2) {
         if (nptc <= 1) launch_chain<1, 2>(c, q, lds);
         else if (nptc <= 2) launch_chain<2, 2>(c, q, lds);
@@ -1938,7 +2220,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     const blance_problem& h = c->h;
     const int N = h.n_nodes, NX = h.n_nodes_ext, M = h.n_states, P = h.n_parts, L = c->L;
     const int64_t PM = (int64_t)P * M;
-    const int RW = kRecHead + M * (1 + L);
+    const int RW = kRecHead + M * (1 + L) + L;   // header, per-state lists, leaf positions of this state's nodes
     hipStream_t sm = c->stream;
     int32_t* scal = c->scalars.as<int32_t>();
     int64_t launches = 0, steps = 0, batched = 0;
@@ -2018,7 +2300,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
                 blance_ctx::RuleRegions& rr = c->rule_regions[r0];
                 const int B = rr.n_regions, nbc = cdiv(P, kBChunk);
-                HIPTRY(hipMemsetAsync(scal + 4, 0, 8, sm));
+                HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
                 HIPTRY(hipMemsetAsync(c->bucket_counts.p, 0, sizeof(int32_t) * (size_t)B * nbc, sm));
                 BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
                                      rr.node_region.as<int32_t>(), c->regid.as<int32_t>(), scal + 4);
@@ -2032,7 +2314,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                                      c->chain_order.as<int32_t>());
                 BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->chain_order.as<int32_t>(),
                                      c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
-                                     c->node_leaf_pos.as<int32_t>(), c->rec.as<int32_t>());
+                                     c->node_leaf_pos.as<int32_t>(),
+                                     c->anchors.as<AnchorSet>() + (size_t)r0 * (NX + 1), c->rec.as<int32_t>());
                 HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                       hipMemcpyDeviceToDevice, sm));
                 ChainParams cq;
@@ -2056,9 +2339,12 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 launches += 7;
                 if (launched) {
                     n_pass++;
-                    int32_t fl[2] = {0, 0};
+                    int32_t fl[4] = {0, 0, 0, 0};
                     HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
                     HIPTRY(hipStreamSynchronize(sm));
+                    if (getenv("BLANCE_TRACE"))
+                        fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
+                                m, fl[2], P, fl[3]);
                     if (!fl[0] && !fl[1]) {
                         BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, OW, c->chain_order.as<int32_t>(),
                                              c->rec.as<int32_t>(), c->out.as<int32_t>());
@@ -2074,7 +2360,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             if (!done) {
             BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->order.as<int32_t>(),
                                  c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
-                                 c->node_leaf_pos.as<int32_t>(), c->rec.as<int32_t>());
+                                 c->node_leaf_pos.as<int32_t>(), (const AnchorSet*)nullptr, c->rec.as<int32_t>());
             PassParams q;
             memset(&q, 0, sizeof q);
             q.N = N; q.NX = NX; q.M = M; q.L = L; q.P = P; q.s = m; q.k = k; q.top_state = h.top_state;

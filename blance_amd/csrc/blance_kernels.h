@@ -10,8 +10,11 @@ constexpr int kListAbsent = 0, kListNil = 1, kListSet = 2;   // include/blance_h
 constexpr int kMaxK = 8;         // largest supported Constraints per state
 constexpr int kMaxAnchors = 9;   // hierarchy anchors per fold: 1 + (#rules of a state) * k <= 9
 constexpr int kMaxStates = 16;
-constexpr int kRecHead = 5;      // step-record header words: partition, weight, stickiness (fp64),
-                                 // leaf position of the top priority node (-1 if none)
+constexpr int kRecHead = 7;      // step-record header words: partition, weight, stickiness (fp64),
+                                 // leaf position of the top priority node (-1 if none) and, for a
+                                 // region-chain pass, the exclude interval of that node under the rule
+constexpr int kLpTab = 512;      // chain kernel LDS tables: c / NP for c < kLpTab ...
+constexpr int kFfTab = 2048;     // ... and (0.001 * t) / NP for t < kFfTab
 
 // One rule's include/exclude leaf intervals for one anchor (plan.go:723-734):
 // leaves(findAncestor(a, IncludeLevel)) = [alo, ahi), leaves(findAncestor(a, ExcludeLevel)) = [blo, bhi).

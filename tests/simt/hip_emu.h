@@ -169,6 +169,7 @@ void launch_serial(dim3 grid, dim3 block, F body) {
     emu::launch_serial(dim3(grid), dim3(block), [&]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::block_barrier(); }
+#define BLANCE_WAVE_SYNC() emu::wave_barrier()   /* fibers are not in lockstep: model it */
 
 inline int __shfl_xor(int v, int mask, int = 64) {
     return (int)(uint32_t)emu::wave_exchange((uint32_t)v, (threadIdx.x & 63) ^ mask);
