@@ -534,6 +534,10 @@ __device__ __forceinline__ int wave_argmin(double s, int n) {
 #define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
 #define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
     printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
+#elif defined(BLANCE_ASM_MARKS)   // developer build only: phase markers as comments in the ISA
+#define PH_DECL
+#define PH(i) asm volatile("; PHASE_MARK " #i)
+#define PH_DUMP(steps)
 #else
 #define PH_DECL
 #define PH(i)
@@ -568,7 +572,29 @@ __device__ __forceinline__ double chain_score(int cnt, int ntn, int tot, int has
     return r;
 }
 
-template <int NPTC, int KM>
+// 32-bit minimum over one wave64 (wave-uniform result)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    unsigned t;
+    t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x141>((int)v); v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x140>((int)v); v = t < v ? t : v;
+    unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    r0 = r1 < r0 ? r1 : r0;
+    r2 = r3 < r2 ? r3 : r2;
+    return r2 < r0 ? r2 : r0;
+}
+
+// FAST = the pass has NP == 0 and no node weights: nodeSorter.Score is then
+// double(count) - currentFactor with currentFactor in {1.5, integers}, so
+// 2 * score is an exact small integer and (score, position) packs into one
+// 32-bit key: [ 2*count - 2*currentFactor + 2^17 | node id (13 bits) ].  Lanes
+// whose counters leave the representable range make the chain escape.
+constexpr int kKeyBias = 1 << 17;
+constexpr unsigned kKeyNone = 0xffffffffu;
+
+template <int NPTC, int KM, bool FAST>
 __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     BLANCE_DYN_LDS(lds);
     if (q.flags[0]) return;
@@ -577,43 +603,44 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
     if (cbeg >= cend) return;
-    const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k;
-    const int SW = 1 + L;
-    // LDS: quotient tables, a 64-step staging area for step records and outputs (no
-    // global memory operation inside the step loop), the region's nodeToNodeCounts rows
+    const int N = q.N, NX = q.NX, M = q.M, NP = q.NP, s = q.s, k = q.k;
+    // LDS: quotient tables, mirrors of the per-leaf registers (read by the stay
+    // validators), a 64-step staging area for records and outputs (no global memory
+    // operation inside the step loop), the region's nodeToNodeCounts rows
     double* lp_tab = (double*)lds;                   // [kLpTab]
     double* ff_tab = lp_tab + kLpTab;                // [kFfTab]
-    double* gL = ff_tab + kFfTab;                    // [size] mirrors of the per-leaf registers,
-    double* ffL = gL + size;                         // [size] (0.001 * tot) / NP of the leaf
-    int* cntL = (int*)(ffL + size);                  // [size] read by the stay validators
+    double* gL = ff_tab + kFfTab;                    // [size]
+    int* cntL = (int*)(gL + size);                   // [size]
     int* totL = cntL + size;
     int* nidL = totL + size;
     int* wgtL = nidL + size;
     int* flgL = wgtL + size;                         // bit 0 alive (in nodesNext), bit 1 has weight
-    int* xloL = flgL + size;                         // exclude interval of the leaf's node as an anchor
-    int* xhiL = xloL + size;
-    int* recbuf = xhiL + size;                       // [64][RW]
-    int* outbuf = recbuf + 64 * q.RW;                // [64][OW]
+    int* clsL = flgL + size;                         // exclude class of the leaf's node, -1 if none
+    int* cszL = clsL + size;                         // leaves covered by class c
+    int* recbuf = cszL + size;                       // [64][kCW]
+    int* outbuf = recbuf + 64 * kCW;                 // [64][OW]
     int* ntn_l = outbuf + 64 * q.OW;                 // [size][ST] nodeToNodeCounts rows, padded stride
     const int ST = size + 1;
-    if (NP > 0) {
+    if (!FAST && NP > 0) {
         for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = (double)i / (double)NP;
         for (int i = lane; i < kFfTab; i += 64) ff_tab[i] = (0.001 * (double)i) / (double)NP;
         if (q.ntn_in_lds)
             for (int i = lane; i < size * ST; i += 64) ntn_l[i] = 0;
     }
+    for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
     __syncthreads();
 
-    // lane l owns leaves lo + l + 64 u: node id, counters, exclude interval as an anchor
-    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], xsl[NPTC], xsh[NPTC], pos[NPTC];
+    // lane l owns leaves lo + l + 64 u
+    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], cls[NPTC];
     unsigned alive_m = 0, hasw_m = 0;
     double g[NPTC];
+    bool range_bad = false;
 #pragma unroll
     for (int u = 0; u < NPTC; u++) {
-        pos[u] = lo + lane + 64 * u;
-        nid[u] = -2; cntv[u] = 0; totv[u] = 0; wv[u] = 0; xsl[u] = 0; xsh[u] = 0; g[u] = 0.0;
-        if (pos[u] < hi) {
-            int n = q.leaf_node[pos[u]];
+        const int pos = lo + lane + 64 * u;
+        nid[u] = -2; cntv[u] = 0; totv[u] = 0; wv[u] = 0; cls[u] = -1; g[u] = 0.0;
+        if (pos < hi) {
+            int n = q.leaf_node[pos];
             if (n >= 0) {
                 nid[u] = n;
                 cntv[u] = q.cnt[s * NX + n];
@@ -624,16 +651,16 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 if (q.node_has_weight[n]) hasw_m |= 1u << u;
                 if (n < N && q.alive[n]) alive_m |= 1u << u;
                 g[u] = chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind, lp_tab, ff_tab);
-                xsl[u] = q.anchors[n].blo; xsh[u] = q.anchors[n].bhi;
+                cls[u] = q.leaf_cls[pos];
+                if (FAST && (cntv[u] >= (1 << 15) || cntv[u] <= -(1 << 15))) range_bad = true;
             }
             const int i = lane + 64 * u;
             gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u]; nidL[i] = nid[u]; wgtL[i] = wv[u];
-            ffL[i] = NP > 0 ? (0.001 * (double)totv[u]) / (double)NP : 0.0;
             flgL[i] = ((alive_m >> u) & 1) | (((hasw_m >> u) & 1) << 1);
-            xloL[i] = xsl[u]; xhiL[i] = xsh[u];
+            clsL[i] = cls[u];
         }
     }
-    bool escaped = false;
+    bool escaped = __ballot(range_bad) != 0;
     // stay speculation: tried again whenever the last general step turned out to be a stay
     const bool spec_ok = q.ntn_in_lds || NP == 0;
     bool try_spec = true, gmin_dirty = true;
@@ -645,7 +672,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     for (int base = cbeg; base < cend && !escaped; base += 64) {
       const int nb = cend - base < 64 ? cend - base : 64;
       PH(0);
-      for (int i = lane; i < nb * q.RW; i += 64) recbuf[i] = q.rec[(size_t)base * q.RW + i];
+      for (int i = lane; i < nb * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
       __syncthreads();
       int b = 0;
       while (b < nb) {
@@ -684,74 +711,60 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const int a = lane;
             const int sb = b + a;
             const bool active = sb < nb;
-            const int* rp = recbuf + (active ? sb : b) * q.RW;
+            const int* rp = recbuf + (active ? sb : b) * kCW;
             bool fail = false;
             const double vstick = __hiloint2double(rp[3], rp[2]);
-            const int vtl = rp[4] - lo;
-            const int hs = rp[kRecHead + s * SW];
-            if ((hs >> 16) == kListAbsent || (hs & 0xffff) != k) fail = true;
-            int o[KM], oi[KM], blo[KM], bhi[KM];
+            const int vtl = rp[4];
+            const int cn = rp[5];
+            if (!((cn >> 24) & 1) || (cn & 0xff) != k) fail = true;      // must hold exactly k nodes
+            int oi[KM], oc[KM + 1];
+            int on[KM];
             double so[KM];
-#pragma unroll
-            for (int j = 0; j < KM; j++) { o[j] = -3; oi[j] = 0; so[j] = 0.0; blo[j] = 0; bhi[j] = 0; }
-            blo[0] = rp[5]; bhi[0] = rp[6];
+            oc[0] = rp[6];
 #pragma unroll
             for (int j = 0; j < KM; j++) {
+                on[j] = -3; so[j] = 0.0; oi[j] = 0; oc[j + 1] = -1;
                 if (j < k) {
-                    o[j] = rp[kRecHead + s * SW + 1 + j];
-                    int li = rp[kRecHead + M * SW + j] - lo;
-                    if (li < 0 || li >= size || o[j] < 0) { fail = true; li = 0; }
+                    int li = rp[kCOwn + j];
+                    if (li < 0 || li >= size) { fail = true; li = 0; }
                     oi[j] = li;
-                    if (j + 1 < KM) { blo[j + 1] = xloL[li]; bhi[j + 1] = xhiL[li]; }
+                    on[j] = nidL[li];
+                    oc[j + 1] = clsL[li];
                 }
             }
-            // nodes of the other states: a node held twice would move (plan.go:290-297);
-            // a higher priority node is no candidate (plan.go:146-154)
-            for (int t = 0; t < M; t++) {
-                if (t == s) continue;
-                const int hdr = rp[kRecHead + t * SW];
-                if ((hdr >> 16) == kListAbsent) continue;
-                for (int j = 0; j < L; j++) {
-                    const int x = rp[kRecHead + t * SW + 1 + j];
-#pragma unroll
-                    for (int jj = 0; jj < KM; jj++) if (x >= 0 && x == o[jj]) fail = true;
-                }
-            }
-            // the anchors' exclude intervals must be representable exactly (as in the general step)
+            // anchors top, own_0 .. own_{k-2}: their exclude classes must leave candidates,
+            // and own_j must not sit in a class excluded before its slot
             {
                 int cov = 0;
 #pragma unroll
-                for (int j = 0; j < KM; j++) {               // anchors 0..k-1 decide the k picks
+                for (int j = 0; j < KM; j++) {
                     if (j < k) {
+                        if (oc[j] < 0) fail = true;
                         bool dup = false;
 #pragma unroll
-                        for (int e = 0; e < KM; e++) {
-                            if (e < j) {
-                                if (blo[e] == blo[j] && bhi[e] == bhi[j]) dup = true;
-                                else if (!(bhi[j] <= blo[e] || blo[j] >= bhi[e])) fail = true;
-                            }
-                        }
-                        if (blo[j] < lo || bhi[j] > hi || bhi[j] - blo[j] >= size) fail = true;
-                        if (!dup) cov += bhi[j] - blo[j];
+                        for (int e = 0; e < KM; e++) if (e < j && oc[e] == oc[j]) dup = true;
+                        if (!dup) cov += cszL[oc[j] < 0 ? 0 : oc[j]];
                         if (cov >= size) fail = true;
+#pragma unroll
+                        for (int e = 0; e < KM; e++) if (e <= j && oc[e] == oc[j + 1]) fail = true;
                     }
                 }
             }
-            // the partition's own nodes: candidates of their slot, in list order, below the bound
+            // the partition's own nodes: candidates, in list order, below the bound
 #pragma unroll
             for (int j = 0; j < KM; j++) {
                 if (j < k) {
-                    const int li = oi[j], p = lo + li;
-                    if (!(flgL[li] & 1) || nidL[li] != o[j]) fail = true;
-#pragma unroll
-                    for (int e = 0; e < KM; e++) if (e <= j && p >= blo[e] && p < bhi[e]) fail = true;
-                    const int nt = NP > 0 ? ntn_l[vtl * ST + li] : 0;
+                    const int li = oi[j];
+                    if (!(flgL[li] & 1)) fail = true;
+                    const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
                     so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
                                         q.booster_kind, lp_tab, ff_tab);
-                    if (j > 0 && !better(so[j - 1], o[j - 1], so[j], o[j])) fail = true;
-                    if (!better(so[j], o[j], gmin_s, gmin_n)) fail = true;
+                    if (j > 0 && !better(so[j - 1], on[j - 1], so[j], on[j])) fail = true;
+                    if (!better(so[j], on[j], gmin_s, gmin_n)) fail = true;
                 }
             }
+            // an own node also listed in a higher priority state is no candidate (the
+            // record keeps such leaves under "higher"; gather refuses nodes held twice)
             // an earlier step of the batch with the same top priority node would have bumped my row
             if (NP > 0) {
                 for (int e = 0; e < 64; e++) {
@@ -769,8 +782,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
 #pragma unroll
                 for (int j = 0; j < KM; j++) {
                     if (j < k) {
-                        op[1 + j] = o[j];
-                        if (NP > 0) ntn_l[vtl * ST + oi[j]] += 1;      // plan.go:238-245
+                        op[1 + j] = on[j];
+                        if (!FAST && NP > 0) ntn_l[vtl * ST + oi[j]] += 1;      // plan.go:238-245
                     }
                 }
             }
@@ -780,48 +793,55 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             if (b >= nb) break;
             if (nok == 64) continue;
         }
+        // ---- general step: findBestNodes (plan.go:98-248) + commit (plan.go:290-301)
         PH(1);
-        const int recw = lane < q.RW ? recbuf[b * q.RW + lane] : 0;
+        const int recw = lane < kCW ? recbuf[b * kCW + lane] : 0;
 #define REC(i) __builtin_amdgcn_readlane(recw, (i))
         const int w = REC(1);
         const double stick = __hiloint2double(REC(3), REC(2));
-        const int tl = REC(4) - lo;                      // local leaf index of the top priority node
-        const int top = REC(kRecHead + q.top_state * SW + 1);
+        const int tl = REC(4);
+        const int cn = REC(5);
+        const int n_low = (cn >> 16) & 0xff;
+        bool esc = false;
         int ntnv[NPTC];
 #pragma unroll
         for (int u = 0; u < NPTC; u++) {
             ntnv[u] = 0;
-            if (NP > 0) {
+            if (!FAST && NP > 0) {
                 if (q.ntn_in_lds) { if (lane + 64 * u < size) ntnv[u] = ntn_l[tl * ST + lane + 64 * u]; }
-                else if (nid[u] >= 0 && nid[u] < N) ntnv[u] = q.ntn[(size_t)top * N + nid[u]];
+                else if (nid[u] >= 0 && nid[u] < N) ntnv[u] = q.ntn[(size_t)nidL[tl] * N + nid[u]];
             }
         }
         PH(2);
-        // my leaves in the higher priority lists (plan.go:146-154) / in this state's list (plan.go:654-662)
         unsigned inh_m = 0, own_m = 0;
-        for (int t = 0; t < M; t++) {
-            const int hdr = REC(kRecHead + t * SW);
-            const bool present = (hdr >> 16) != kListAbsent;
-            const unsigned hi_t = (present && ((q.higher_mask >> t) & 1)) ? 1u : 0u;
-            const unsigned own_t = (present && t == s) ? 1u : 0u;
-            if (!(hi_t | own_t)) continue;
-            for (int j = 0; j < L; j++) {
-                const int x = REC(kRecHead + t * SW + 1 + j);          // -1 past the end of the list
 #pragma unroll
-                for (int u = 0; u < NPTC; u++) {
-                    const unsigned eq = x == nid[u] ? 1u : 0u;
-                    inh_m |= (eq & hi_t) << u;
-                    own_m |= (eq & own_t) << u;
-                }
+        for (int j = 0; j < kChainOwn; j++) {
+            const int oj = REC(kCOwn + j), hj = REC(kCHigh + j);
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                own_m |= (oj == lane + 64 * u ? 1u : 0u) << u;
+                inh_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
             }
         }
         PH(3);
         const unsigned elig_m = alive_m & ~inh_m;
         double sc[NPTC];
-        {
+        unsigned key[NPTC];
+        if (FAST) {
+            // 2 * stickiness: 3 or an even integer; out of range -> let the sequential pass do it
+            const double s2 = stick + stick;
+            const int stick2 = (s2 >= 0.0 && s2 < 32768.0) ? (int)s2 : 0;
+            if (!(s2 >= 0.0 && s2 < 32768.0) || (double)stick2 != s2) esc = true;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                const int v = 2 * cntv[u] - (((own_m >> u) & 1) ? stick2 : 0) + kKeyBias;
+                key[u] = ((elig_m >> u) & 1) ? (((unsigned)v << 13) | (unsigned)nid[u]) : kKeyNone;
+                sc[u] = 0.0;
+            }
+        } else {
             unsigned need_m = own_m;
 #pragma unroll
-            for (int u = 0; u < NPTC; u++) if (ntnv[u] != 0) need_m |= 1u << u;
+            for (int u = 0; u < NPTC; u++) { if (ntnv[u] != 0) need_m |= 1u << u; key[u] = 0; }
             if (__ballot(need_m != 0)) {
 #pragma unroll
                 for (int u = 0; u < NPTC; u++) {
@@ -836,119 +856,115 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         }
         PH(4);
         // The rule's k picks (plan.go:177-223).  Every anchor's include set is this
-        // region, so the running set is the region minus the anchors' exclude
-        // intervals; anything the simple bookkeeping below cannot represent exactly
-        // (empty set -> reset, nested intervals, fallback picks) escapes.
-        int xb_lo[KM], xb_hi[KM];
+        // region, so the running set is the region minus the anchors' exclude classes;
+        // an empty running set (plan.go:746 would reset it), an anchor without a
+        // proper class, a fallback to candidateNodes[0] or a duplicate pick escape.
+        int ec[KM];
 #pragma unroll
-        for (int j = 0; j < KM; j++) { xb_lo[j] = 0; xb_hi[j] = 0; }
-        int n_x = 0, covered = 0;
+        for (int j = 0; j < KM; j++) ec[j] = -2;
+        int covered = 0;
         unsigned excl_m = 0;
-        bool esc = false;
-        int chosen[KM];
+        int chosen[KM], chosen_l[KM];
 #pragma unroll
-        for (int j = 0; j < KM; j++) chosen[j] = -1;
+        for (int j = 0; j < KM; j++) { chosen[j] = -1; chosen_l[j] = -1; }
         int n_out = 0;
-        int alo = REC(5), ahi = REC(6);                  // exclude interval of the top priority node
+        int acls = REC(6);                           // exclude class of the current anchor
         PH(5);
-        for (int slot = 0; slot < k; slot++) {
-            {   // add the anchor's exclude interval
-                bool dup = false, clash = false;
 #pragma unroll
-                for (int j = 0; j < KM; j++) {
-                    if (j < n_x) {
-                        if (xb_lo[j] == alo && xb_hi[j] == ahi) dup = true;
-                        else if (!(ahi <= xb_lo[j] || alo >= xb_hi[j])) clash = true;
-                    }
-                }
-                if (alo < lo || ahi > hi || ahi - alo >= size || clash) esc = true;
+        for (int slot = 0; slot < KM; slot++) {
+            if (slot < k) {
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
+                if (acls < 0) esc = true;
                 if (!dup) {
+                    ec[slot] = acls;
+                    covered += cszL[acls < 0 ? 0 : acls];
 #pragma unroll
-                    for (int j = 0; j < KM; j++) if (j == n_x) { xb_lo[j] = alo; xb_hi[j] = ahi; }
-                    n_x++;
-                    covered += ahi - alo;
-#pragma unroll
-                    for (int u = 0; u < NPTC; u++) excl_m |= (pos[u] >= alo && pos[u] < ahi) ? (1u << u) : 0u;
+                    for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
                 }
                 if (covered >= size) esc = true;
-            }
-            double bs = pos_inf();
-            int bn = INT_MAX;
+                int best;
+                if (FAST) {
+                    unsigned km = kKeyNone;
 #pragma unroll
-            for (int u = 0; u < NPTC; u++) {
-                const bool ok = ((elig_m & ~excl_m) >> u) & 1;
-                const bool take = ok && better(sc[u], nid[u], bs, bn);
-                bs = take ? sc[u] : bs;
-                bn = take ? nid[u] : bn;
-            }
-            PH(6);
-            const int best = wave_argmin(bs, bn);
-            PH(7);
-            if (best == INT_MAX) esc = true;
-            // the winner's exclude interval becomes the next anchor
-            int wlo = 0, whi = 0;
+                    for (int u = 0; u < NPTC; u++) {
+                        const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
+                        km = kv < km ? kv : km;
+                    }
+                    PH(6);
+                    const unsigned kb = wave_min_u32(km);
+                    best = kb == kKeyNone ? INT_MAX : (int)(kb & 0x1fff);
+                } else {
+                    double bs = pos_inf();
+                    int bn = INT_MAX;
 #pragma unroll
-            for (int u = 0; u < NPTC; u++) {
-                unsigned long long bm = __ballot(nid[u] == best);
-                if (bm) {
-                    int wl = __ffsll((long long)bm) - 1;
-                    wlo = __builtin_amdgcn_readlane(xsl[u], wl);
-                    whi = __builtin_amdgcn_readlane(xsh[u], wl);
+                    for (int u = 0; u < NPTC; u++) {
+                        const bool ok = ((elig_m & ~excl_m) >> u) & 1;
+                        const bool take = ok && better(sc[u], nid[u], bs, bn);
+                        bs = take ? sc[u] : bs;
+                        bn = take ? nid[u] : bn;
+                    }
+                    PH(6);
+                    best = wave_argmin(bs, bn);
                 }
+                PH(7);
+                if (best == INT_MAX) esc = true;
+                int wcls = -1, wloc = -1;
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    unsigned long long bm = __ballot(nid[u] == best);
+                    if (bm) {
+                        int wl = __ffsll((long long)bm) - 1;
+                        wcls = __builtin_amdgcn_readlane(cls[u], wl);
+                        wloc = wl + 64 * u;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < KM; c++) if (c < slot && chosen[c] == best) esc = true;   // duplicate pick
+                chosen[slot] = best;
+                chosen_l[slot] = wloc;
+                n_out = slot + 1;
+                acls = wcls;
+                PH(8);
             }
-#pragma unroll
-            for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == best) esc = true;   // duplicate pick
-#pragma unroll
-            for (int c = 0; c < KM; c++) if (c == n_out) chosen[c] = best;
-            n_out++;
-            alo = wlo; ahi = whi;
-            PH(8);
         }
-        if (esc) { escaped = true; break; }
+        if (__ballot(esc)) { escaped = true; break; }
 
-        // ---- commit (plan.go:238-245, :290-301): the owner lane of a leaf updates it
+        // ---- commit: the owner lane of a leaf updates it
         int dc[NPTC], dt[NPTC];
 #pragma unroll
         for (int u = 0; u < NPTC; u++) { dc[u] = 0; dt[u] = 0; }
-        {
-            const int hs = REC(kRecHead + s * SW);
-            const bool s_present = (hs >> 16) != kListAbsent;
-            for (int j = 0; j < L; j++) {                 // old nodes of this state leave it
-                const int x = s_present ? REC(kRecHead + s * SW + 1 + j) : -1;
 #pragma unroll
-                for (int u = 0; u < NPTC; u++) { int d = x == nid[u] ? w : 0; dc[u] -= d; dt[u] -= d; }
-            }
-            for (int t = 0; t < M; t++) {                 // a node of another state that also held this
-                if (t == s) continue;                     // state or is chosen now leaves that state
-                const int hdr = REC(kRecHead + t * SW);
-                if ((hdr >> 16) == kListAbsent) continue;
-                for (int j = 0; j < L; j++) {
-                    const int x = REC(kRecHead + t * SW + 1 + j);
-                    if (x < 0) continue;
-                    bool hit = false;
-                    if (s_present)
-                        for (int jj = 0; jj < L; jj++) if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
+        for (int u = 0; u < NPTC; u++) {             // old nodes of this state leave it (plan.go:290-293)
+            const int d = ((own_m >> u) & 1) ? w : 0;
+            dc[u] -= d; dt[u] -= d;
+        }
 #pragma unroll
-                    for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == x) hit = true;
-                    if (!hit) continue;
+        for (int c = 0; c < KM; c++) {               // chosen nodes enter it (plan.go:299-301)
+            if (c < k) {
 #pragma unroll
-                    for (int u = 0; u < NPTC; u++) dt[u] -= x == nid[u] ? w : 0;
-                    if (lane == 0) q.cnt[t * NX + x] -= w;
+                for (int u = 0; u < NPTC; u++) {
+                    const bool mine = chosen_l[c] == lane + 64 * u;
+                    dc[u] += mine ? w : 0;
+                    dt[u] += mine ? w : 0;
+                    if (!FAST && NP > 0 && mine) {
+                        if (q.ntn_in_lds) ntn_l[tl * ST + lane + 64 * u] = ntnv[u] + 1;      // plan.go:238-245
+                        else q.ntn[(size_t)nidL[tl] * N + nid[u]] = ntnv[u] + 1;
+                    }
                 }
             }
         }
+        if (n_low > 0) {                             // a chosen node leaves its lower priority state (plan.go:294-297)
+            for (int e = 0; e < kChainLow; e++) {
+                const int le = REC(kCLow + e), lt = REC(kCLowState + e);
+                if (le < 0) continue;
 #pragma unroll
-        for (int c = 0; c < KM; c++) {
-            if (c < n_out) {
-                const int x = chosen[c];
+                for (int c = 0; c < KM; c++) {
+                    if (c < k && chosen_l[c] == le) {
 #pragma unroll
-                for (int u = 0; u < NPTC; u++) {
-                    const bool mine = x == nid[u];
-                    dc[u] += mine ? w : 0;
-                    dt[u] += mine ? w : 0;
-                    if (NP > 0 && mine) {
-                        if (q.ntn_in_lds) ntn_l[tl * ST + lane + 64 * u] = ntnv[u] + 1;
-                        else q.ntn[(size_t)top * N + x] = ntnv[u] + 1;
+                        for (int u = 0; u < NPTC; u++) dt[u] -= le == lane + 64 * u ? w : 0;
+                        if (lane == 0) q.cnt[lt * NX + chosen[c]] -= w;
                     }
                 }
             }
@@ -961,6 +977,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 cntv[u] += dc[u];
                 totv[u] += dt[u];
                 if (dc[u] | dt[u]) changed_m |= 1u << u;
+                if (FAST && (cntv[u] >= (1 << 15) || cntv[u] <= -(1 << 15))) range_bad = true;
             }
             if (__ballot(changed_m != 0)) {
 #pragma unroll
@@ -971,12 +988,6 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     if ((changed_m >> u) & 1) {
                         const int i = lane + 64 * u;
                         gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u];
-                        double f = 0.0;
-                        if (NP > 0) {
-                            f = ff_tab[(unsigned)totv[u] < (unsigned)kFfTab ? totv[u] : 0];
-                            if ((unsigned)totv[u] >= (unsigned)kFfTab) f = (0.001 * (double)totv[u]) / (double)NP;
-                        }
-                        ffL[i] = f;
                     }
                 }
             }
@@ -984,11 +995,9 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         PH(10);
         {
             // did this step keep its nodes?  then the next ones probably do, too
-            const int hs2 = REC(kRecHead + s * SW);
-            bool same = (hs2 >> 16) != kListAbsent && (hs2 & 0xffff) == n_out;
+            bool same = ((cn >> 24) & 1) && (cn & 0xff) == n_out;
 #pragma unroll
-            for (int c = 0; c < KM; c++)
-                if (c < n_out && c < L && REC(kRecHead + s * SW + 1 + c) != chosen[c]) same = false;
+            for (int c = 0; c < KM; c++) if (c < n_out && REC(kCOwn + c) != chosen_l[c]) same = false;
             try_spec = same;
             gmin_dirty = true;
         }
@@ -1001,6 +1010,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         PH(11);
 #undef REC
         BLANCE_WAVE_SYNC();
+        if (__ballot(range_bad)) { escaped = true; break; }
         b++;
       }
       __syncthreads();
@@ -1506,6 +1516,68 @@ __global__ void k_chain_classify(DevProblem d, int m, int top_state, const int32
     regid[oi] = rg;
 }
 
+// Compact chain records (layout: blance_kernels.h): the step's nodes as leaf
+// indices local to its region.  Steps the chain kernel cannot represent raise flags[0].
+__global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
+                               const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
+                               const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
+                               const int32_t* leaf_cls, int32_t* crec, int32_t* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.P) return;
+    int p = chain_order[i];
+    int32_t* r = crec + (size_t)i * kCW;
+    for (int j = 0; j < kCW; j++) r[j] = -1;
+    int w = 1;
+    double stick = 1.5;
+    if (!d.weights_nil) {
+        if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
+        else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
+    }
+    r[0] = p; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    int idxT = p * d.M + top_state;
+    int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
+    int rg = top >= 0 ? node_region[top] : -1;
+    if (rg < 0) { flags[0] = 1; r[4] = 0; r[5] = 0; r[6] = -1; return; }
+    const int lo = reg_lo[rg];
+    r[4] = node_leaf_pos[top] - lo;
+    r[6] = leaf_cls[node_leaf_pos[top]];
+    bool bad = false;
+    int own_nodes[kChainOwn];
+    int n_own = 0, n_h = 0, n_low = 0, present = 0;
+    int idx = p * d.M + m;
+    if (d.live_kind[idx] != kListAbsent) {
+        present = 1;
+        for (int j = 0; j < d.live_len[idx]; j++) {
+            int x = d.live[(size_t)idx * d.L + j];
+            if (n_own >= kChainOwn || node_region[x] != rg) { bad = true; break; }
+            own_nodes[n_own] = x;
+            r[kCOwn + n_own++] = node_leaf_pos[x] - lo;
+        }
+    }
+    for (int t = 0; t < d.M && !bad; t++) {
+        if (t == m) continue;
+        int ix = p * d.M + t;
+        if (d.live_kind[ix] == kListAbsent) continue;
+        const bool higher = (higher_mask >> t) & 1;
+        for (int j = 0; j < d.live_len[ix]; j++) {
+            int x = d.live[(size_t)ix * d.L + j];
+            for (int e = 0; e < n_own; e++) if (own_nodes[e] == x) bad = true;   // a node held in two states
+            if (node_region[x] != rg) continue;      // never a candidate of this region's chain
+            int loc = node_leaf_pos[x] - lo;
+            if (higher) {
+                if (n_h >= kChainHigh) { bad = true; break; }
+                r[kCHigh + n_h++] = loc;
+            } else {
+                if (n_low >= kChainLow) { bad = true; break; }
+                r[kCLow + n_low] = loc;
+                r[kCLowState + n_low++] = t;
+            }
+        }
+    }
+    r[5] = n_own | (n_h << 8) | (n_low << 16) | (present << 24);
+    if (bad) flags[0] = 1;
+}
+
 // Stable partition of the pass order by region: chunk counts -> scan -> scatter.
 constexpr int kBChunk = 256;
 
@@ -1699,13 +1771,14 @@ struct blance_ctx {
     std::vector<int32_t> state_priority, state_constraints, rule_off;
     int L = 1, np_later = 0, n_alive = 0, any_removed = 0;
     int chain_min_parts = 2048;
+    int any_node_weight = 0;
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
-        DevBuf node_region, reg_lo, reg_hi;
+        DevBuf node_region, reg_lo, reg_hi, leaf_cls, cls_size;
     };
     std::vector<RuleRegions> rule_regions;
-    DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save;
+    DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save, crec;
     DevBuf f_tot, f_g, f_top_g, f_top_n, f_row_count, f_m, f_moff, f_keys_a, f_keys_b, f_vals_a, f_vals_b, f_hist;
     int64_t steps_batched = 0;
     int64_t out_capacity = 0;
@@ -1736,9 +1809,9 @@ struct blance_ctx {
                          &cnt, &ntn, &cat, &order, &chunk_counts, &rec, &out, &warn_part,
                          &warn_state, &scalars};
         for (DevBuf* b : all) b->release();
-        for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); }
+        for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
         rule_regions.clear();
-        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &f_tot, &f_g,
+        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &f_tot, &f_g,
                           &f_top_g, &f_top_n, &f_row_count, &f_m, &f_moff, &f_keys_a, &f_keys_b, &f_vals_a,
                           &f_vals_b, &f_hist};
         for (DevBuf* b : more) b->release();
@@ -1943,8 +2016,10 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     PUT(state_has_stick, pb->state_has_stickiness, M);
     PUT(rule_inc, pb->rule_inc, pb->n_rules);
     PUT(rule_exc, pb->rule_exc, pb->n_rules);
-    for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); }
+    for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
     c->rule_regions.clear();
+    c->any_node_weight = 0;
+    for (int n = 0; n < NX; n++) if (pb->node_has_weight[n]) c->any_node_weight = 1;
     if (!pb->hierarchy_rules_nil) {
         // leaf-interval table of every (rule, anchor): plan.go:723-734, :755-774
         const int R = pb->n_rules;
@@ -1999,6 +2074,33 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
                 }
             }
             if (max_size > 256) ok = false;
+            // Exclude classes: inside a region the anchors' exclude intervals must be
+            // pairwise disjoint (racks inside a zone), so "leaf is excluded by anchor a"
+            // is "leaf has a's class".  Intervals that cover the region get class -1.
+            std::vector<int32_t> leaf_cls((size_t)n_leaves, -1), cls_size((size_t)n_leaves, 0);
+            for (size_t g = 0; g < rlo.size() && ok; g++) {
+                std::vector<std::pair<int, int>> cl;
+                for (int lp = rlo[g]; lp < rhi[g]; lp++) {
+                    int a = leaf_node[lp];
+                    if (a < 0) continue;
+                    int bl = t[a].blo, bh = t[a].bhi;
+                    if (rlo[g] <= bl && bh <= rhi[g] && bh - bl < rhi[g] - rlo[g]) cl.emplace_back(bl, bh);
+                }
+                std::sort(cl.begin(), cl.end());
+                cl.erase(std::unique(cl.begin(), cl.end()), cl.end());
+                for (size_t i = 1; i < cl.size() && ok; i++) if (cl[i].first < cl[i - 1].second) ok = false;
+                for (size_t i = 0; i < cl.size() && ok; i++) cls_size[rlo[g] + i] = cl[i].second - cl[i].first;
+                for (int lp = rlo[g]; lp < rhi[g] && ok; lp++) {
+                    int a = leaf_node[lp];
+                    if (a < 0) continue;
+                    // the class whose interval holds this leaf must be the node's own exclude interval
+                    size_t j = std::upper_bound(cl.begin(), cl.end(), std::make_pair(lp, INT_MAX)) - cl.begin();
+                    if (j > 0 && lp < cl[j - 1].second) {
+                        if (t[a].blo != cl[j - 1].first || t[a].bhi != cl[j - 1].second) ok = false;
+                        leaf_cls[lp] = (int)j - 1;
+                    }
+                }
+            }
             rr.ok = ok;
             rr.n_regions = ok ? (int)rlo.size() : 0;
             rr.max_size = max_size;
@@ -2006,6 +2108,8 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
                 if (put(c, rr.node_region, node_region.data(), node_region.size())) return BLANCE_ERR_DEVICE;
                 if (put(c, rr.reg_lo, rlo.data(), rlo.size())) return BLANCE_ERR_DEVICE;
                 if (put(c, rr.reg_hi, rhi.data(), rhi.size())) return BLANCE_ERR_DEVICE;
+                if (put(c, rr.leaf_cls, leaf_cls.data(), leaf_cls.size())) return BLANCE_ERR_DEVICE;
+                if (put(c, rr.cls_size, cls_size.data(), cls_size.size())) return BLANCE_ERR_DEVICE;
             }
         }
     }
@@ -2038,6 +2142,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
         RESERVE(bucket_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv(P, kBChunk) + 1) + 1));
         RESERVE(reg_off, sizeof(int32_t) * ((size_t)maxB + 2));
         RESERVE(cnt_save, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1));
+        if (maxB > 1) RESERVE(crec, sizeof(int32_t) * ((size_t)P * kCW + 64));
         RESERVE(f_tot, sizeof(int32_t) * ((size_t)NX + 1));
         RESERVE(f_g, sizeof(double) * ((size_t)NX + 1));
         RESERVE(f_top_g, sizeof(double) * kTopList);
@@ -2185,10 +2290,16 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     return 0;
 }
 
-template <int NPTC, int KM>
+template <int NPTC, int KM, bool FAST>
 static void launch_chain(blance_ctx* c, const ChainParams& q, size_t lds) {
-    auto kern = k_pass_chain<NPTC, KM>;
+    auto kern = k_pass_chain<NPTC, KM, FAST>;
     BLANCE_LAUNCH(kern, q.n_regions, 64, lds, c->stream, q);
+}
+
+template <int NPTC, int KM>
+static void launch_chain_mode(blance_ctx* c, const ChainParams& q, size_t lds, bool fast) {
+    if (fast) launch_chain<NPTC, KM, true>(c, q, lds);
+    else launch_chain<NPTC, KM, false>(c, q, lds);
 }
 
 // one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
@@ -2196,17 +2307,16 @@ static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
     int nptc = cdiv(max_size, 64);
     size_t ntn_bytes = sizeof(int32_t) * (size_t)max_size * (max_size + 1);
     q.ntn_in_lds = ntn_bytes <= 100 * 1024;
-    size_t lds = sizeof(double) * (kLpTab + kFfTab + 2 * (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
-                 sizeof(int32_t) * 64 * (size_t)(q.RW + q.OW) + (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
+    const bool fast = q.NP == 0 && !c->any_node_weight;
+    size_t lds = sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
+                 sizeof(int32_t) * 64 * (size_t)(kCW + q.OW) + (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
     if (q.k <= 2) {
-        if (nptc <= 1) launch_chain<1, 2>(c, q, lds);
-        else if (nptc <= 2) launch_chain<2, 2>(c, q, lds);
-        else if (nptc <= 4) launch_chain<4, 2>(c, q, lds);
+        if (nptc <= 2) launch_chain_mode<2, 2>(c, q, lds, fast);
+        else if (nptc <= 4) launch_chain_mode<4, 2>(c, q, lds, fast);
         else return false;
     } else if (q.k <= 4) {
-        if (nptc <= 1) launch_chain<1, 4>(c, q, lds);
-        else if (nptc <= 2) launch_chain<2, 4>(c, q, lds);
-        else if (nptc <= 4) launch_chain<4, 4>(c, q, lds);
+        if (nptc <= 2) launch_chain_mode<2, 4>(c, q, lds, fast);
+        else if (nptc <= 4) launch_chain_mode<4, 4>(c, q, lds, fast);
         else return false;
     } else {
         return false;
@@ -2316,27 +2426,33 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                                      c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
                                      c->node_leaf_pos.as<int32_t>(),
                                      c->anchors.as<AnchorSet>() + (size_t)r0 * (NX + 1), c->rec.as<int32_t>());
+                BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
+                                     c->chain_order.as<int32_t>(), c->state_stick.as<int32_t>(),
+                                     c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
+                                     rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
+                                     c->crec.as<int32_t>(), scal + 4);
                 HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                       hipMemcpyDeviceToDevice, sm));
                 ChainParams cq;
                 memset(&cq, 0, sizeof cq);
-                cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k; cq.top_state = h.top_state;
-                cq.NP = NP; cq.RW = RW; cq.OW = OW; cq.higher_mask = higher_mask; cq.booster_kind = h.booster_kind;
+                cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
+                cq.NP = NP; cq.OW = OW; cq.booster_kind = h.booster_kind;
                 cq.n_regions = B;
                 cq.reg_lo = rr.reg_lo.as<int32_t>(); cq.reg_hi = rr.reg_hi.as<int32_t>();
                 cq.reg_off = c->reg_off.as<int32_t>();
                 cq.leaf_node = c->leaf_node.as<int32_t>();
-                cq.anchors = c->anchors.as<AnchorSet>() + (size_t)r0 * (NX + 1);
+                cq.leaf_cls = rr.leaf_cls.as<int32_t>();
+                cq.cls_size = rr.cls_size.as<int32_t>();
                 cq.alive = c->alive.as<uint8_t>();
                 cq.node_weight = c->node_weight.as<int32_t>();
                 cq.node_has_weight = c->node_has_weight.as<uint8_t>();
                 cq.cnt = c->cnt.as<int32_t>(); cq.ntn = c->ntn.as<int32_t>();
-                cq.rec = c->rec.as<int32_t>(); cq.out = c->out.as<int32_t>();
+                cq.crec = c->crec.as<int32_t>(); cq.out = c->out.as<int32_t>();
                 cq.flags = scal + 4;
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
                 bool launched = dispatch_chain(c, cq, rr.max_size);
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
-                launches += 7;
+                launches += 8;
                 if (launched) {
                     n_pass++;
                     int32_t fl[4] = {0, 0, 0, 0};

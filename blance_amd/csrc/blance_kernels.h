@@ -53,24 +53,39 @@ struct PassParams {
 
 // Parameters of a state pass run as independent per-region chains (DESIGN.md
 // "Region chains"): one wave64 per hierarchy region walks that region's steps.
+//
+// Compact chain step record (k_gather_chain), kCW words, everything already
+// translated to leaf indices local to the region:
+//   0 partition   1 weight   2,3 stickiness (fp64)   4 top priority node's leaf
+//   5 counts: own | higher << 8 | lower << 16 | (state list present) << 24
+//   6 exclude class of the top priority node
+//   7..10  leaves of the nodes the partition holds in this state (-1 padded)
+//   11..14 leaves of its higher priority nodes inside the region (never candidates)
+//   15..18 leaves of its lower priority nodes inside the region, 19..22 their states
+constexpr int kChainOwn = 4, kChainHigh = 4, kChainLow = 4;
+constexpr int kCW = 24;
+constexpr int kCOwn = 7, kCHigh = 11, kCLow = 15, kCLowState = 19;
+
 struct ChainParams {
     int32_t N, NX, M, L;
-    int32_t s, k, top_state, NP, RW, OW;
-    int32_t higher_mask, booster_kind;
+    int32_t s, k, NP, OW;
+    int32_t booster_kind;
     int32_t n_regions, ntn_in_lds;
     const int32_t* reg_lo;         // [n_regions] leaf interval of the region
     const int32_t* reg_hi;
     const int32_t* reg_off;        // [n_regions + 1] step range of the region in chain order
     const int32_t* leaf_node;      // [n_leaves] node id at a leaf position, -1 if none
-    const AnchorSet* anchors;      // the state's single rule: [NX + 1]
+    const int32_t* leaf_cls;       // [n_leaves] exclude class of the leaf's node inside its region, -1 if none
+    const int32_t* cls_size;       // [n_leaves] leaves covered by class c of the region at reg_lo + c
     const uint8_t* alive;
     const int32_t* node_weight;
     const uint8_t* node_has_weight;
     int32_t* cnt;
     int32_t* ntn;
-    const int32_t* rec;            // [P * RW] step records in chain order
+    const int32_t* crec;           // [P * kCW] compact step records in chain order
     int32_t* out;                  // [P * OW]
-    int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape
+    int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape,
+                                   // [2] steps committed as verified stays, [3] stay batches
 };
 
 // Flat (no hierarchy rule) passes resolved in bulk: DESIGN.md "Flat bulk engine".
