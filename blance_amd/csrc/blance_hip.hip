@@ -982,8 +982,9 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             if (__ballot(changed_m != 0)) {
 #pragma unroll
                 for (int u = 0; u < NPTC; u++) {
-                    double gn = chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind,
-                                            lp_tab, ff_tab);
+                    double gn = FAST ? (double)cntv[u]       // no quotients, no weights: plan.go:664-670 only
+                                     : chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0,
+                                                   q.booster_kind, lp_tab, ff_tab);
                     g[u] = ((changed_m >> u) & 1) ? gn : g[u];
                     if ((changed_m >> u) & 1) {
                         const int i = lane + 64 * u;
@@ -1094,11 +1095,13 @@ __global__ __launch_bounds__(1024) void k_flat_prepare(FlatParams q, int32_t* to
 // steps of the pass per nodeToNodeCounts row: an upper bound of any entry of that row
 __global__ void k_flat_row_count(FlatParams q, int32_t* row_count) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (oi >= q.P) return;
-    const int32_t* r = q.rec + (size_t)oi * q.RW;
+    if (oi >= q.P) oi = -1;
+    const int32_t* r = q.rec + (size_t)(oi < 0 ? 0 : oi) * q.RW;
     int hdr = r[kRecHead + q.top_state * (1 + q.L)];
     int top = ((hdr >> 16) != kListAbsent && (hdr & 0xffff) > 0) ? r[kRecHead + q.top_state * (1 + q.L) + 1] : -1;
-    atomicAdd(&row_count[top < 0 ? q.NX : top], 1);
+    if (oi >= 0 && top >= 0) atomicAdd(&row_count[top], 1);
+    unsigned long long none = __ballot(oi >= 0 && top < 0);    // the "" row: one atomic per wave
+    if (none && (int)(threadIdx.x & 63) == __ffsll((long long)none) - 1) atomicAdd(&row_count[q.NX], __popcll(none));
 }
 
 // Classify the steps [beg, end): record the first one that is not a certain
@@ -1459,39 +1462,58 @@ __global__ void k_category(DevProblem d, int m, int any_removed, int add_nil, ui
     cat[p] = (uint8_t)cv;
 }
 
-// Stable 3-way partition of the static order by category (the per-pass part of
-// partitionSorter, plan.go:519-562): chunk counts -> scan -> stable scatter.
-constexpr int kChunk = 1024;
+// Stable partition of a sequence by a small key (the per-pass category of
+// partitionSorter, plan.go:519-562; the region of a step): per-chunk bucket
+// counts -> exclusive scan (bucket major) -> stable scatter.  One wave64 per
+// chunk of kPartChunk elements; ranks inside a round of 64 come from ballots.
+constexpr int kPartChunk = 1024;
 
-__global__ void k_order_count(int P, const int32_t* static_order, const uint8_t* cat, int n_chunks,
-                              int32_t* counts /* [3][n_chunks] */) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    int beg = c * kChunk, end = beg + kChunk < P ? beg + kChunk : P;
-    int k0 = 0, k1 = 0, k2 = 0;
-    for (int i = beg; i < end; i++) {
-        int cv = cat[static_order[i]];
-        k0 += cv == 0; k1 += cv == 1; k2 += cv == 2;
+__device__ __forceinline__ int part_key(const int32_t* key32, const uint8_t* key8, const int32_t* index, int i) {
+    int j = index ? index[i] : i;
+    return key8 ? (int)key8[j] : key32[j];
+}
+
+__global__ __launch_bounds__(64) void k_part_count(int n, const int32_t* key32, const uint8_t* key8,
+                                                   const int32_t* index, int n_chunks, int B,
+                                                   int32_t* counts /* [B][n_chunks] */) {
+    BLANCE_DYN_LDS(lds);
+    int* hist = (int*)lds;                           // [B]
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    for (int i = lane; i < B; i += 64) hist[i] = 0;
+    __syncthreads();
+    int beg = chunk * kPartChunk, end = beg + kPartChunk < n ? beg + kPartChunk : n;
+    for (int base = beg; base < end; base += 64) {
+        int i = base + lane;
+        if (i < end) atomicAdd(&hist[part_key(key32, key8, index, i)], 1);
     }
-    counts[c] = k0; counts[n_chunks + c] = k1; counts[2 * n_chunks + c] = k2;
+    __syncthreads();
+    for (int i = lane; i < B; i += 64) counts[(size_t)i * n_chunks + chunk] = hist[i];
 }
 
-__global__ void k_order_scan(int n, int32_t* counts) {   // exclusive scan, single thread: n = 3 * P / 1024
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int acc = 0;
-    for (int i = 0; i < n; i++) { int v = counts[i]; counts[i] = acc; acc += v; }
-}
-
-__global__ void k_order_scatter(int P, const int32_t* static_order, const uint8_t* cat, int n_chunks,
-                                const int32_t* offsets, int32_t* order) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    int beg = c * kChunk, end = beg + kChunk < P ? beg + kChunk : P;
-    int o0 = offsets[c], o1 = offsets[n_chunks + c], o2 = offsets[2 * n_chunks + c];
-    for (int i = beg; i < end; i++) {
-        int p = static_order[i];
-        int cv = cat[p];
-        if (cv == 0) order[o0++] = p; else if (cv == 1) order[o1++] = p; else order[o2++] = p;
+__global__ __launch_bounds__(64) void k_part_scatter(int n, const int32_t* key32, const uint8_t* key8,
+                                                     const int32_t* index, const int32_t* values, int n_chunks,
+                                                     int B, int nbits, const int32_t* offsets, int32_t* out) {
+    BLANCE_DYN_LDS(lds);
+    int* pos = (int*)lds;                            // [B] next output slot per bucket
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    for (int i = lane; i < B; i += 64) pos[i] = offsets[(size_t)i * n_chunks + chunk];
+    __syncthreads();
+    int beg = chunk * kPartChunk, end = beg + kPartChunk < n ? beg + kPartChunk : n;
+    for (int base = beg; base < end; base += 64) {
+        int i = base + lane;
+        bool valid = i < end;
+        int key = valid ? part_key(key32, key8, index, i) : 0;
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < nbits; bit++) {
+            unsigned long long m = __ballot((key >> bit) & 1);
+            peers &= ((key >> bit) & 1) ? m : ~m;
+        }
+        unsigned long long lower = peers & ((1ull << lane) - 1);
+        int dst = valid ? pos[key] + __popcll(lower) : 0;
+        __syncthreads();
+        if (valid && lower == 0) pos[key] += __popcll(peers);
+        __syncthreads();
+        if (valid) out[dst] = values[i];
     }
 }
 
@@ -1578,52 +1600,49 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
     if (bad) flags[0] = 1;
 }
 
-// Stable partition of the pass order by region: chunk counts -> scan -> scatter.
-constexpr int kBChunk = 256;
-
-__global__ void k_bucket_count(int P, const int32_t* regid, int n_chunks, int32_t* counts /* [B][n_chunks], zeroed */) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    int beg = c * kBChunk, end = beg + kBChunk < P ? beg + kBChunk : P;
-    for (int i = beg; i < end; i++) counts[(size_t)regid[i] * n_chunks + c]++;
-}
-
-// exclusive scan of n ints by one workgroup of 1024 threads (n up to a few million)
+// exclusive scan of n ints by one workgroup of 1024 threads: tiles of 8192
+// elements, 8 contiguous per thread (coalesced), carry across tiles
 __global__ __launch_bounds__(1024) void k_scan_excl(int n, int32_t* data) {
     BLANCE_DYN_LDS(lds);
-    int* part = (int*)lds;                       // [1024]
-    const int tid = threadIdx.x, T = 1024;
-    int per = (n + T - 1) / T;
-    int beg = tid * per, end = beg + per < n ? beg + per : n;
-    int sum = 0;
-    for (int i = beg; i < end; i++) sum += data[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < T; off <<= 1) {
-        int v = tid >= off ? part[tid - off] : 0;
+    int* wsum = (int*)lds;                       // [16] wave totals, [16] carry
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 8192) {
+        int v[8];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int i = base + tid * 8 + j;
+            v[j] = i < n ? data[i] : 0;
+            sum += v[j];
+        }
+        int incl = sum;                          // inclusive scan of the thread sums inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        part[tid] += v;
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { int x = wsum[w]; if (w < wave) wbase += x; total += x; }
+        int acc = carry + wbase + incl - sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int i = base + tid * 8 + j;
+            if (i < n) data[i] = acc;
+            acc += v[j];
+        }
+        carry += total;
         __syncthreads();
     }
-    int acc = part[tid] - sum;
-    for (int i = beg; i < end; i++) { int v = data[i]; data[i] = acc; acc += v; }
 }
 
 __global__ void k_region_offsets(int B, int n_chunks, int P, const int32_t* offsets, int32_t* reg_off) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > B) return;
     reg_off[b] = b == B ? P : offsets[(size_t)b * n_chunks];
-}
-
-__global__ void k_bucket_scatter(int P, const int32_t* regid, const int32_t* order, int n_chunks,
-                                 int32_t* offsets, int32_t* chain_order) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    int beg = c * kBChunk, end = beg + kBChunk < P ? beg + kBChunk : P;
-    for (int i = beg; i < end; i++) {
-        int pos = offsets[(size_t)regid[i] * n_chunks + c]++;
-        chain_order[pos] = order[i];
-    }
 }
 
 // Step records in pass order: what findBestNodes needs to know about its partition.
@@ -2128,7 +2147,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     RESERVE(ntn, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1));
     RESERVE(cat, (size_t)P + 1);
     RESERVE(order, sizeof(int32_t) * ((size_t)P + 1));
-    RESERVE(chunk_counts, sizeof(int32_t) * 3 * (size_t)(cdiv(P, kChunk) + 1));
+    RESERVE(chunk_counts, sizeof(int32_t) * 3 * (size_t)(cdiv(P, kPartChunk) + 1));
     RESERVE(rec, sizeof(int32_t) * ((size_t)P * RW + 64));
     RESERVE(out, sizeof(int32_t) * ((size_t)P * (1 + kmax) + 1));
     RESERVE(warn_part, sizeof(int32_t) * (size_t)(PM + 1));
@@ -2139,7 +2158,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
         for (auto& rr : c->rule_regions) if (rr.ok && rr.n_regions > maxB) maxB = rr.n_regions;
         RESERVE(regid, sizeof(int32_t) * ((size_t)P + 1));
         RESERVE(chain_order, sizeof(int32_t) * ((size_t)P + 1));
-        RESERVE(bucket_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv(P, kBChunk) + 1) + 1));
+        RESERVE(bucket_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv(P, kPartChunk) + 1) + 1));
         RESERVE(reg_off, sizeof(int32_t) * ((size_t)maxB + 2));
         RESERVE(cnt_save, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1));
         if (maxB > 1) RESERVE(crec, sizeof(int32_t) * ((size_t)P * kCW + 64));
@@ -2204,7 +2223,7 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
     int32_t* vb = c->f_vals_b.as<int32_t>();
     for (int shift = 0; shift < 64; shift += 8) {
         BLANCE_LAUNCH(k_sort_hist, n_tiles, 64, 1024 + 64, c->stream, n, shift, ka, n_tiles, c->f_hist.as<int32_t>());
-        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 4096 + 64, c->stream, 256 * n_tiles, c->f_hist.as<int32_t>());
+        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, 256 * n_tiles, c->f_hist.as<int32_t>());
         BLANCE_LAUNCH(k_sort_scatter, n_tiles, 64, 1024 + 64, c->stream, n, shift, ka, va, kb, vb, n_tiles,
                       c->f_hist.as<int32_t>());
         std::swap(ka, kb);
@@ -2231,9 +2250,11 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     fq.top_g = c->f_top_g.as<double>(); fq.top_n = c->f_top_n.as<int32_t>();
     fq.row_count = c->f_row_count.as<int32_t>();
     fq.ntn = q.ntn; fq.rec = q.rec; fq.out = q.out; fq.scan = scal + 8;
-    HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)q.NX + 1), sm));
-    BLANCE_LAUNCH_NOSYNC(k_flat_row_count, cdiv(P, 256), 256, 0, sm, fq, c->f_row_count.as<int32_t>());
-    *launches += 1;
+    if (q.NP > 0) {                                 // only read by the stay test when NP > 0
+        HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)q.NX + 1), sm));
+        BLANCE_LAUNCH(k_flat_row_count, cdiv(P, 256), 256, 0, sm, fq, c->f_row_count.as<int32_t>());
+        *launches += 1;
+    }
     // bulk paths have fixed costs (a host round trip, a sort): short runs stay sequential
     const int kMinStayRun = c->chain_min_parts < 64 ? c->chain_min_parts : 64;
     const int kMinFreshRun = c->chain_min_parts < 512 ? c->chain_min_parts : 512;
@@ -2384,13 +2405,14 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         for (int m = 0; m < M; m++) {                               // plan.go:307-324
             const int k = c->state_constraints[m];
             if (k <= 0 || P == 0) continue;
-            const int n_chunks = cdiv(P, kChunk);
+            const int n_chunks = cdiv(P, kPartChunk);
             BLANCE_LAUNCH_NOSYNC(k_category, cdiv(P, 256), 256, 0, sm, d, m, any_removed, add_nil, c->cat.as<uint8_t>());
-            BLANCE_LAUNCH_NOSYNC(k_order_count, cdiv(n_chunks, 64), 64, 0, sm, P, c->part_order.as<int32_t>(),
-                                 c->cat.as<uint8_t>(), n_chunks, c->chunk_counts.as<int32_t>());
-            BLANCE_LAUNCH_NOSYNC(k_order_scan, 1, 64, 0, sm, 3 * n_chunks, c->chunk_counts.as<int32_t>());
-            BLANCE_LAUNCH_NOSYNC(k_order_scatter, cdiv(n_chunks, 64), 64, 0, sm, P, c->part_order.as<int32_t>(),
-                                 c->cat.as<uint8_t>(), n_chunks, c->chunk_counts.as<int32_t>(), c->order.as<int32_t>());
+            BLANCE_LAUNCH(k_part_count, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
+                          c->part_order.as<int32_t>(), n_chunks, 3, c->chunk_counts.as<int32_t>());
+            BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, 3 * n_chunks, c->chunk_counts.as<int32_t>());
+            BLANCE_LAUNCH(k_part_scatter, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
+                          c->part_order.as<int32_t>(), c->part_order.as<int32_t>(), n_chunks, 3, 2,
+                          c->chunk_counts.as<int32_t>(), c->order.as<int32_t>());
             if (NP > 0)                                             // nodeToNodeCounts := fresh, plan.go:266
                 HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
             const int OW = 1 + k;
@@ -2409,19 +2431,20 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
                 c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
                 blance_ctx::RuleRegions& rr = c->rule_regions[r0];
-                const int B = rr.n_regions, nbc = cdiv(P, kBChunk);
+                const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
-                HIPTRY(hipMemsetAsync(c->bucket_counts.p, 0, sizeof(int32_t) * (size_t)B * nbc, sm));
                 BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
                                      rr.node_region.as<int32_t>(), c->regid.as<int32_t>(), scal + 4);
-                BLANCE_LAUNCH_NOSYNC(k_bucket_count, cdiv(nbc, 64), 64, 0, sm, P, c->regid.as<int32_t>(), nbc,
-                                     c->bucket_counts.as<int32_t>());
-                BLANCE_LAUNCH(k_scan_excl, 1, 1024, 4096 + 64, sm, B * nbc, c->bucket_counts.as<int32_t>());
+                int nbits = 1;
+                while ((1 << nbits) < B) nbits++;
+                BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
+                              (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, B, c->bucket_counts.as<int32_t>());
+                BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, B * nbc, c->bucket_counts.as<int32_t>());
                 BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nbc, P,
                                      c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
-                BLANCE_LAUNCH_NOSYNC(k_bucket_scatter, cdiv(nbc, 64), 64, 0, sm, P, c->regid.as<int32_t>(),
-                                     c->order.as<int32_t>(), nbc, c->bucket_counts.as<int32_t>(),
-                                     c->chain_order.as<int32_t>());
+                BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
+                              (const uint8_t*)nullptr, (const int32_t*)nullptr, c->order.as<int32_t>(), nbc, B, nbits,
+                              c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>());
                 BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->chain_order.as<int32_t>(),
                                      c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
                                      c->node_leaf_pos.as<int32_t>(),

@@ -181,6 +181,11 @@ inline double __shfl_xor(double v, int mask, int = 64) {
     memcpy(&v, &u, 8);
     return v;
 }
+inline int __shfl_up(int v, int delta, int = 64) {
+    int l = threadIdx.x & 63;
+    int r = (int)(uint32_t)emu::wave_exchange((uint32_t)v, l >= delta ? l - delta : l);
+    return r;
+}
 inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)emu::wave_exchange((uint32_t)v, src); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)emu::wave_exchange((uint32_t)v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
