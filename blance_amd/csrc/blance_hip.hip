@@ -814,13 +814,20 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         }
         PH(2);
         unsigned inh_m = 0, own_m = 0;
+        if (cn & 0xff) {
 #pragma unroll
-        for (int j = 0; j < kChainOwn; j++) {
-            const int oj = REC(kCOwn + j), hj = REC(kCHigh + j);
+            for (int j = 0; j < kChainOwn; j++) {
+                const int oj = REC(kCOwn + j);
 #pragma unroll
-            for (int u = 0; u < NPTC; u++) {
-                own_m |= (oj == lane + 64 * u ? 1u : 0u) << u;
-                inh_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+                for (int u = 0; u < NPTC; u++) own_m |= (oj == lane + 64 * u ? 1u : 0u) << u;
+            }
+        }
+        if (cn & 0xff00) {
+#pragma unroll
+            for (int j = 0; j < kChainHigh; j++) {
+                const int hj = REC(kCHigh + j);
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) inh_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
             }
         }
         PH(3);
@@ -997,8 +1004,10 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         {
             // did this step keep its nodes?  then the next ones probably do, too
             bool same = ((cn >> 24) & 1) && (cn & 0xff) == n_out;
+            if (same) {
 #pragma unroll
-            for (int c = 0; c < KM; c++) if (c < n_out && REC(kCOwn + c) != chosen_l[c]) same = false;
+                for (int c = 0; c < KM; c++) if (c < n_out && REC(kCOwn + c) != chosen_l[c]) same = false;
+            }
             try_spec = same;
             gmin_dirty = true;
         }
@@ -1587,6 +1596,8 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
             if (node_region[x] != rg) continue;      // never a candidate of this region's chain
             int loc = node_leaf_pos[x] - lo;
             if (higher) {
+                // the top priority node's exclude class is excluded in every slot anyway
+                if (r[6] >= 0 && leaf_cls[node_leaf_pos[x]] == r[6]) continue;
                 if (n_h >= kChainHigh) { bad = true; break; }
                 r[kCHigh + n_h++] = loc;
             } else {
