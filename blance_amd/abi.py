@@ -59,6 +59,7 @@ class Result(C.Structure):
         ("steps_total", C.c_int64), ("steps_sequential", C.c_int64), ("steps_batched", C.c_int64),
         ("kernel_launches", C.c_int64),
         ("pass_kernel_ms", C.c_double), ("pass_kernel_launches", C.c_int64),
+        ("flat_pass_ms", C.c_double), ("flat_passes", C.c_int64),
     ]
 
 

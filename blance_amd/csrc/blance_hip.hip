@@ -1828,6 +1828,9 @@ struct blance_ctx {
     int64_t n_warnings = 0, steps_total = 0, kernel_launches = 0, pass_launches = 0;
     double device_ms = 0.0, pass_ms = 0.0;
     std::vector<hipEvent_t> pass_events;     // begin/end pairs around every pass kernel
+    std::vector<int> pass_kind;              // 0 = one pass kernel, 1 = flat bulk driver
+    double flat_ms = 0.0;
+    int64_t flat_passes = 0;
 
     void free_all() {
         DevBuf* all[] = {&node_removed, &node_added, &node_weight, &node_has_weight, &alive, &zeros_nx,
@@ -2488,6 +2491,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
                 launches += 8;
                 if (launched) {
+                    c->pass_kind.resize(n_pass + 1);
+                    c->pass_kind[n_pass] = 0;
                     n_pass++;
                     int32_t fl[4] = {0, 0, 0, 0};
                     HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
@@ -2537,11 +2542,15 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             q.beg = 0; q.end = P;
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
             int e;
+            c->pass_kind.resize(n_pass + 1);
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && (h.hierarchy_rules_nil || r1 == r0) && k == 1 &&
-                P >= c->chain_min_parts)
+                P >= c->chain_min_parts) {
+                c->pass_kind[n_pass] = 1;
                 e = run_flat_pass(c, q, scal, &launches, &batched);
-            else
+            } else {
+                c->pass_kind[n_pass] = 0;
                 e = dispatch_pass(c, q);
+            }
             if (e) return e;
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
             n_pass++;
@@ -2569,15 +2578,19 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     HIPTRY(hipEventSynchronize(c->ev1));
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    double pass_ms = 0.0;
+    double pass_ms = 0.0, flat_ms = 0.0;
+    int n_kernel_pass = 0, n_flat = 0;
     for (int i = 0; i < n_pass; i++) {
         float pm = 0.f;
         HIPTRY(hipEventElapsedTime(&pm, c->pass_events[2 * i], c->pass_events[2 * i + 1]));
-        pass_ms += pm;
-        if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] pass kernel %d: %.3f ms\n", i, pm);
+        if (c->pass_kind[i] == 0) { pass_ms += pm; n_kernel_pass++; } else { flat_ms += pm; n_flat++; }
+        if (getenv("BLANCE_TRACE"))
+            fprintf(stderr, "[blance] pass %d (%s): %.3f ms\n", i, c->pass_kind[i] ? "flat bulk driver" : "pass kernel", pm);
     }
     c->pass_ms = pass_ms;
-    c->pass_launches = n_pass;
+    c->pass_launches = n_kernel_pass;
+    c->flat_ms = flat_ms;
+    c->flat_passes = n_flat;
     c->iterations = iterations;
     c->converged = converged;
     c->device_ms = ms;
@@ -2597,7 +2610,9 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         res->kernel_launches = launches;
         res->n_warnings = c->n_warnings;
         res->pass_kernel_ms = pass_ms;
-        res->pass_kernel_launches = n_pass;
+        res->pass_kernel_launches = n_kernel_pass;
+        res->flat_pass_ms = flat_ms;
+        res->flat_passes = n_flat;
     }
     return BLANCE_OK;
 }
@@ -2652,6 +2667,8 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     res->kernel_launches = c->kernel_launches;
     res->pass_kernel_ms = c->pass_ms;
     res->pass_kernel_launches = c->pass_launches;
+    res->flat_pass_ms = c->flat_ms;
+    res->flat_passes = c->flat_passes;
     return BLANCE_OK;
 }
 

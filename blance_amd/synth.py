@@ -178,17 +178,31 @@ def assignments(fp):
     return int(fp.scalars["n_parts"]) * int(k.sum())
 
 
-def algorithmic_bytes_per_sweep(fp):
-    """per findBestNodes call N*(16 + 4*k*[rules]) + 40."""
+def _state_has_rules(fp, m):
+    roff = fp.arrays["rule_off"]
+    return (not fp.scalars["hierarchy_rules_nil"]) and int(roff[m + 1]) > int(roff[m])
+
+
+def algorithmic_bytes_per_state(fp):
+    """one state pass reads P * (N*(16 + 4*k*[rules]) + 40)
+    bytes in the reference's dense formulation (0 for states without a pass)."""
     N = int(fp.scalars["n_nodes"])
     P = int(fp.scalars["n_parts"])
     cons = fp.arrays["state_constraints"]
-    roff = fp.arrays["rule_off"]
-    total = 0
+    out = []
     for m in range(int(fp.scalars["n_states"])):
         k = int(cons[m])
-        if k <= 0:
-            continue
-        has_rules = (not fp.scalars["hierarchy_rules_nil"]) and int(roff[m + 1]) > int(roff[m])
-        total += N * (16 + (4 * k if has_rules else 0)) + 40
-    return P * total
+        out.append(P * (N * (16 + (4 * k if _state_has_rules(fp, m) else 0)) + 40) if k > 0 else 0)
+    return out
+
+
+def algorithmic_bytes_per_sweep(fp):
+    return sum(algorithmic_bytes_per_state(fp))
+
+
+def pass_kernel_states(fp):
+    """States whose pass is ONE kernel launch (k_pass_chain / k_pass_seq); single
+    constraint states without hierarchy rules go through the flat bulk driver."""
+    cons = fp.arrays["state_constraints"]
+    return [m for m in range(int(fp.scalars["n_states"]))
+            if int(cons[m]) > 0 and (_state_has_rules(fp, m) or int(cons[m]) != 1)]

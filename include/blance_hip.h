@@ -169,10 +169,15 @@ typedef struct blance_result {
     int64_t  steps_sequential;    /* steps resolved one at a time                        */
     int64_t  steps_batched;       /* steps resolved by an exact parallel schedule        */
     int64_t  kernel_launches;
-    /* out: the dominant kernel (one launch per state pass), timed with hipEvents
-     * on the planner's stream: sum of its launch durations and launch count */
+    /* out: the dominant kernel -- the state-pass kernel (k_pass_chain, or
+     * k_pass_seq over a whole pass), one launch per hierarchy-rule state pass --
+     * timed with hipEvents on the planner's stream: sum of its launch durations
+     * and launch count; and the same for passes run by the flat bulk driver
+     * (several small kernels + host round trips per pass) */
     double   pass_kernel_ms;
     int64_t  pass_kernel_launches;
+    double   flat_pass_ms;
+    int64_t  flat_passes;
 } blance_result;
 
 typedef struct blance_options {

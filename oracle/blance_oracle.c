@@ -551,6 +551,8 @@ int blance_oracle_plan_ex(const blance_problem* pb, blance_result* res, int64_t 
             res->kernel_launches = 0;
             res->pass_kernel_ms = 0.0;
             res->pass_kernel_launches = 0;
+            res->flat_pass_ms = 0.0;
+            res->flat_passes = 0;
         }
     }
     free(c.zeros); free(c.alive); free(c.live); free(c.live_len); free(c.live_kind);
