@@ -1,0 +1,120 @@
+"""Host-side mirror of the reference's planner API (api.go:24-190) over the HIP
+library: same names, argument meaning, warnings text and caller-visible
+mutations -- PlanNextMapEx() here is what `plan_hip.go` does
+in Go.  Partition maps are dicts {name: Partition}.
+
+There is no CPU fallback in this package: inputs outside the device envelope
+raise problem.Unsupported / hip.BlanceError (the Go shim would call the Go
+planner there).
+"""
+from . import hip, problem
+
+MaxIterationsPerPlan = 10            # plan.go:21
+
+
+class Partition:
+    """api.go:28-36"""
+    __slots__ = ("Name", "NodesByState")
+
+    def __init__(self, Name="", NodesByState=None):
+        self.Name = Name
+        self.NodesByState = NodesByState
+
+    def __eq__(self, other):
+        return isinstance(other, Partition) and self.Name == other.Name and self.NodesByState == other.NodesByState
+
+    def __repr__(self):
+        return "Partition(%r, %r)" % (self.Name, self.NodesByState)
+
+
+class PartitionModelState:
+    """api.go:46-62"""
+    __slots__ = ("Priority", "Constraints")
+
+    def __init__(self, Priority=0, Constraints=0):
+        self.Priority = Priority
+        self.Constraints = Constraints
+
+
+class HierarchyRule:
+    """api.go:96-105"""
+    __slots__ = ("IncludeLevel", "ExcludeLevel")
+
+    def __init__(self, IncludeLevel=0, ExcludeLevel=0):
+        self.IncludeLevel = IncludeLevel
+        self.ExcludeLevel = ExcludeLevel
+
+
+class PlanNextMapOptions:
+    """api.go:183-190; every field may be None (a nil map)."""
+
+    def __init__(self, ModelStateConstraints=None, PartitionWeights=None, StateStickiness=None,
+                 NodeWeights=None, NodeHierarchy=None, HierarchyRules=None):
+        self.ModelStateConstraints = ModelStateConstraints
+        self.PartitionWeights = PartitionWeights
+        self.StateStickiness = StateStickiness
+        self.NodeWeights = NodeWeights
+        self.NodeHierarchy = NodeHierarchy
+        self.HierarchyRules = HierarchyRules
+
+
+_planner = None
+
+
+def default_planner():
+    global _planner
+    if _planner is None:
+        _planner = hip.Planner(device_id=0)
+    return _planner
+
+
+def PlanNextMapEx(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model, options=None,
+                  booster=None, planner=None):
+    """api.go:147-157.  Returns (nextMap, warnings); mutates prevMap and
+    partitionsToAssign the way planNextMapEx does (plan.go:49-52)."""
+    options = options or PlanNextMapOptions()
+    fp = problem.build_problem(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model,
+                               options.ModelStateConstraints, options.PartitionWeights,
+                               options.StateStickiness, options.NodeWeights, options.NodeHierarchy,
+                               options.HierarchyRules, booster, max_iterations=MaxIterationsPerPlan)
+    res = (planner or default_planner()).plan(fp)
+    if res.iterations == 0:                     # MaxIterationsPerPlan <= 0: (nil, nil)
+        return None, None
+    flat, warnings = problem.decode_result(fp, res)
+    nextMap = {name: Partition(name, p["nodesByState"]) for name, p in flat.items()}
+    # plan.go:49-52: every non-converged sweep stores its partitions into BOTH input maps.
+    # The last such store holds the final map's content.
+    if res.iterations > 1 or not res.converged:
+        for name, part in nextMap.items():
+            prevMap[name] = part
+            partitionsToAssign[name] = part
+    return nextMap, warnings
+
+
+def PlanNextMap(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model,
+                modelStateConstraints=None, partitionWeights=None, stateStickiness=None, nodeWeights=None,
+                nodeHierarchy=None, hierarchyRules=None, planner=None):
+    """api.go:109-132 (deprecated positional wrapper)."""
+    return PlanNextMapEx(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model,
+                         PlanNextMapOptions(modelStateConstraints, partitionWeights, stateStickiness, nodeWeights,
+                                            nodeHierarchy, hierarchyRules), planner=planner)
+
+
+# misc.go:13-51, exported helpers callers may use
+def StringsToMap(strs):
+    return None if strs is None else {s: True for s in strs}
+
+
+def StringsRemoveStrings(stringArr, removeArr):
+    rm = StringsToMap(removeArr) or {}
+    return [s for s in (stringArr or []) if s not in rm]
+
+
+def StringsIntersectStrings(a, b):
+    bm = StringsToMap(b) or {}
+    rv, seen = [], set()
+    for s in (a or []):
+        if s in bm and s not in seen:
+            seen.add(s)
+            rv.append(s)
+    return rv

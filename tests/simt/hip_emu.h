@@ -11,7 +11,6 @@
 // scratch area.  Single OS thread, deterministic, only meant for tiny problems.
 #pragma once
 #include <stdio.h>
-#include <ucontext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,12 +37,17 @@ struct dim3 {
 };
 
 namespace emu {
-// GPU threads of one workgroup are fibers (ucontext) of the calling OS thread,
+// GPU threads of one workgroup are fibers of the calling OS thread,
 // resumed round-robin; a barrier parks the fiber until its generation advances.
+constexpr size_t kStackBytes = 256 * 1024;
 struct Barrier { int expected = 0, arrived = 0; unsigned gen = 0; };
+// minimal x86-64 context switch (callee-saved registers + stack pointer; defined in
+// emu_lib.cpp) -- ucontext's swapcontext costs two sigprocmask system calls per switch
+extern "C" void emu_switch(void** save_sp, void* new_sp);
+
 struct Fiber {
-    ucontext_t ctx;
-    std::vector<unsigned char> stack;
+    void* sp = nullptr;
+    unsigned char* stack = nullptr;       // from a pool reused across launches (never zero-filled)
     bool done = false;
     Barrier* wait_bar = nullptr;
     unsigned wait_gen = 0;
@@ -56,7 +60,7 @@ struct Block {
     std::vector<uint64_t> xch;      // [n_waves][64] exchange slots
     unsigned char* lds = nullptr;
     std::vector<Fiber> fibers;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     int cur = -1;
     std::function<void()> body;
 };
@@ -70,7 +74,7 @@ inline void barrier_wait(Barrier& b) {
     Fiber& f = blk->fibers[blk->cur];
     f.wait_bar = &b;
     f.wait_gen = b.gen;
-    swapcontext(&f.ctx, &blk->sched);
+    emu_switch(&f.sp, blk->sched_sp);
 }
 inline void block_barrier() { if (t_block) barrier_wait(t_block->bar); }
 inline void wave_barrier() { if (t_block) barrier_wait(t_block->wave_bar[t_threadIdx.x >> 6]); }
@@ -90,7 +94,8 @@ inline void fiber_entry() {
     blk->body();
     Fiber& f = blk->fibers[blk->cur];
     f.done = true;
-    swapcontext(&f.ctx, &blk->sched);
+    emu_switch(&f.sp, blk->sched_sp);
+    abort();
 }
 
 template <class F>
@@ -115,13 +120,18 @@ void launch_threads(dim3 grid, dim3 block, size_t lds_bytes, F body) {
         t_blockIdx = dim3(b);
         for (unsigned t = 0; t < block.x; t++) {
             Fiber& f = blk.fibers[t];
-            f.stack.resize(256 * 1024);
+            static std::vector<unsigned char*> pool;
+            if (pool.size() <= t) pool.resize(t + 1, nullptr);
+            if (!pool[t]) pool[t] = (unsigned char*)malloc(kStackBytes);
+            f.stack = pool[t];
             f.tid = dim3(t);
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack.data();
-            f.ctx.uc_stack.ss_size = f.stack.size();
-            f.ctx.uc_link = nullptr;
-            makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+            // initial frame: six callee-saved registers, then the entry point as return address
+            uintptr_t top = ((uintptr_t)f.stack + kStackBytes) & ~(uintptr_t)15;
+            void** frame = (void**)(top - 64);
+            for (int r = 0; r < 6; r++) frame[r] = nullptr;
+            frame[6] = (void*)fiber_entry;
+            frame[7] = nullptr;
+            f.sp = frame;
         }
         int remaining = (int)block.x;
         while (remaining > 0) {
@@ -135,7 +145,7 @@ void launch_threads(dim3 grid, dim3 block, size_t lds_bytes, F body) {
                 }
                 blk.cur = (int)t;
                 t_threadIdx = f.tid;
-                swapcontext(&blk.sched, &f.ctx);
+                emu_switch(&blk.sched_sp, f.sp);
                 progressed = true;
                 if (f.done) remaining--;
             }

@@ -10,7 +10,7 @@ import pytest
 
 from blance_amd import hip, problem, synth
 from helpers import build_from_case
-from randgen import random_case
+from randgen import random_case, random_regular_case
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_SRC = os.path.join(HERE, "simt", "emu_lib.cpp")
@@ -21,14 +21,18 @@ DEPS = [EMU_SRC, os.path.join(HERE, "simt", "hip_emu.h"),
         os.path.join(HERE, "..", "include", "blance_hip.h")]
 
 
-@pytest.fixture(scope="module")
-def emu_lib():
+def build_emu():
     stale = (not os.path.exists(EMU_SO)) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in DEPS)
     if stale:
         os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared",
                                "-ffp-contract=off", "-Wno-unknown-pragmas", "-o", EMU_SO, EMU_SRC])
     return EMU_SO
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    return build_emu()
 
 
 def _oracle(fp):
@@ -49,23 +53,95 @@ def test_golden_cases_wave64(emu_lib, golden_cases):
 
 def test_golden_cases_multi_wave(emu_lib, golden_cases):
     pl = hip.Planner(lib_path=emu_lib, force_threads=256)
-    for c in golden_cases[::4]:
+    for c in golden_cases:
         fp = build_from_case(c)
         assert pl.plan(fp).digest() == _oracle(fp).digest(), c["source"]
+    pl.close()
+
+
+def test_golden_cases_bulk_engines(emu_lib, golden_cases):
+    """Flat bulk driver (certain stays, fresh identical runs, radix sort) and region
+    chains switched on for passes of any size."""
+    pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
+    bulk = 0
+    for c in golden_cases:
+        fp = build_from_case(c)
+        got = pl.plan(fp)
+        assert got.digest() == _oracle(fp).digest(), c["source"]
+        bulk += got.struct.steps_batched > 0
+    assert bulk > 40
     pl.close()
 
 
 def test_random_instances(emu_lib):
     pl = hip.Planner(lib_path=emu_lib, force_threads=64)
     n = 0
-    for seed in range(0, 120):
+    for seed in range(0, 600):
         try:
             fp = build_from_case(random_case(seed))
         except problem.Unsupported:
             continue
         assert pl.plan(fp).digest() == _oracle(fp).digest(), seed
         n += 1
-    assert n > 80
+    assert n > 400
+    pl.close()
+
+
+def test_region_chains(emu_lib):
+    """Uniform rack/zone trees: the chain kernel (general and integer-key mode,
+    verified-stay speculation) and its escape to the sequential pass."""
+    pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
+    chains = 0
+    for seed in range(0, 300):
+        try:
+            fp = build_from_case(random_regular_case(seed))
+        except problem.Unsupported:
+            continue
+        got = pl.plan(fp)
+        assert got.digest() == _oracle(fp).digest(), seed
+        chains += got.struct.steps_batched > 0
+    assert chains >= 150
+    fp = synth.config_flat(3, P=160, N=200)
+    got = pl.plan(fp)
+    assert got.digest() == _oracle(fp).digest() and got.struct.steps_batched > 0
+    pl.close()
+
+
+def test_random_instances_bulk_engines(emu_lib):
+    pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
+    n = bulk = 0
+    for seed in range(600, 1200):
+        try:
+            fp = build_from_case(random_case(seed))
+        except problem.Unsupported:
+            continue
+        got = pl.plan(fp)
+        assert got.digest() == _oracle(fp).digest(), seed
+        n += 1
+        bulk += got.struct.steps_batched > 0
+    assert n > 400 and bulk > 100
+    pl.close()
+
+
+def test_multi_wave_random(emu_lib):
+    pl = hip.Planner(lib_path=emu_lib, force_threads=256, chain_min_parts=1)
+    for seed in range(2000, 2060):
+        try:
+            fp = build_from_case(random_case(seed, max_nodes=40, max_parts=40))
+        except problem.Unsupported:
+            continue
+        assert pl.plan(fp).digest() == _oracle(fp).digest(), seed
+    pl.close()
+
+
+def test_reduced_configs(emu_lib):
+    """BASELINE.json shapes at a size the emulator finishes in seconds."""
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=64)
+    for fp in (synth.config_flat(1), synth.config_flat(2, P=2048, N=32), synth.config_flat(3, P=1024, N=256),
+               synth.config_flat(3, P=700, N=300)):
+        got = pl.plan(fp)
+        assert got.digest() == _oracle(fp).digest()
+        assert got.struct.steps_batched > 0
     pl.close()
 
 
