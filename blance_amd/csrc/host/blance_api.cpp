@@ -1,0 +1,507 @@
+// Host-side mirror of the reference's planner API over the C ABI: interning of
+// strings to the int32 SoA problem (the work the reference does implicitly with Go
+// maps keyed by strings), the blance_plan() call, un-interning, and the
+// caller-visible mutations of plan.go:49-52.  Counterpart of blance_amd/problem.py;
+// tests/test_host_cpp.py drives both on the reference's golden inputs.
+#include "blance_api.hpp"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <set>
+#include <unordered_map>
+
+#include "../../../include/blance_hip.h"
+
+namespace blance {
+
+int MaxIterationsPerPlan = 10;                 // plan.go:21
+Booster NodeScoreBooster = Booster::None;      // plan.go:693
+
+namespace {
+
+struct Abi {
+    int (*validate)(const blance_problem*) = nullptr;
+    int64_t (*result_capacity)(const blance_problem*) = nullptr;
+    int (*ctx_create)(const blance_options*, blance_ctx**) = nullptr;
+    void (*ctx_destroy)(blance_ctx*) = nullptr;
+    int (*plan)(blance_ctx*, const blance_problem*, blance_result*) = nullptr;
+    const char* (*last_error)(void) = nullptr;
+};
+std::unordered_map<void*, Abi> g_abi;
+
+struct Unsupported {
+    std::string why;
+};
+
+struct Intern {
+    std::unordered_map<std::string, int> ids;
+    std::vector<std::string> names;
+    int add(const std::string& s) {
+        auto it = ids.find(s);
+        if (it != ids.end()) return it->second;
+        int i = (int)names.size();
+        ids.emplace(s, i);
+        names.push_back(s);
+        return i;
+    }
+};
+
+bool atoi_go(const std::string& s, long long* out) {       // strconv.Atoi, plan.go:525
+    size_t i = 0;
+    if (s.empty()) return false;
+    if (s[0] == '+' || s[0] == '-') i = 1;
+    if (i >= s.size()) return false;
+    for (size_t j = i; j < s.size(); j++) if (s[j] < '0' || s[j] > '9') return false;
+    errno = 0;
+    char* end = nullptr;
+    long long v = strtoll(s.c_str(), &end, 10);
+    if (errno != 0) return false;
+    *out = v;
+    return true;
+}
+
+std::string pad10(long long v) {
+    char buf[40];
+    snprintf(buf, sizeof buf, "%10lld", v);
+    return buf;
+}
+
+// stateNameSorter.Less, plan.go:459-470
+bool state_less(const PartitionModel& model, const std::string& a, const std::string& b) {
+    auto ia = model.find(a), ib = model.find(b);
+    if (ia != model.end() && ib != model.end() && ia->second && ib->second &&
+        ia->second->Priority < ib->second->Priority)
+        return true;
+    return a < b;
+}
+
+struct Flat {
+    blance_problem pb{};
+    std::vector<int32_t> state_priority, state_constraints, state_stickiness;
+    std::vector<uint8_t> state_has_stickiness;
+    std::vector<uint8_t> node_removed, node_added, node_has_weight;
+    std::vector<int32_t> node_weight;
+    std::vector<int32_t> part_order, part_weight;
+    std::vector<uint8_t> part_has_weight, part_in_prev, never_equal;
+    std::vector<int32_t> a_off, a_nodes, p_off, p_nodes;
+    std::vector<uint8_t> a_kind, p_kind;
+    std::vector<int32_t> load_state, load_node, load_weight;
+    std::vector<uint8_t> load_first;
+    std::vector<int32_t> rule_off, rule_inc, rule_exc, v_parent, v_lo, v_hi, leaf_pos;
+    std::vector<std::string> node_names, state_names, part_names;
+};
+
+template <class T>
+const T* ptr(const std::vector<T>& v) {
+    static T dummy[1] = {};
+    return v.empty() ? dummy : v.data();
+}
+
+void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, const std::vector<std::string>& nodesAll,
+           const StringList& nodesToRemove, const StringList& nodesToAdd, const PartitionModel& model,
+           const PlanNextMapOptions& o) {
+    static const PartitionMap empty_map;
+    if (!prevMapIn && !assign.empty())
+        throw Unsupported{"nil prevMap with partitions to assign (reference panics, plan.go:50)"};
+    const PartitionMap& prevMap = prevMapIn ? *prevMapIn : empty_map;
+
+    // ---- states: sortStateNames, plan.go:437-474
+    std::vector<std::string> states;
+    for (auto& kv : model) {
+        if (!kv.second) throw Unsupported{"nil *PartitionModelState"};
+        states.push_back(kv.first);
+    }
+    for (auto& a : states)
+        for (auto& b : states)
+            if (a != b && state_less(model, a, b) && state_less(model, b, a))
+                throw Unsupported{"state priority order contradicts state name order"};
+    for (size_t i = 1; i < states.size(); i++)
+        for (size_t j = i; j > 0 && state_less(model, states[j], states[j - 1]); j--) std::swap(states[j], states[j - 1]);
+    const int M = (int)states.size();
+    std::unordered_map<std::string, int> sid;
+    for (int i = 0; i < M; i++) sid[states[i]] = i;
+    bool any_pass = false;
+    for (auto& s : states) {
+        const auto& ms = model.at(s);
+        int k = ms->Constraints;
+        if (o.ModelStateConstraints) {                      // plan.go:314-319
+            auto it = o.ModelStateConstraints->find(s);
+            if (it != o.ModelStateConstraints->end()) k = it->second;
+        }
+        f.state_priority.push_back(ms->Priority);
+        f.state_constraints.push_back(k);
+        if (k > 0) any_pass = true;
+    }
+    int top_state = 0;
+    if (M) {
+        int mn = *std::min_element(f.state_priority.begin(), f.state_priority.end());
+        int n_top = 0;
+        for (int i = M - 1; i >= 0; i--) if (f.state_priority[i] == mn) { top_state = i; n_top++; }
+        if (n_top > 1 && any_pass) throw Unsupported{"several states share the top priority"};
+    }
+
+    // ---- nodes
+    Intern nodes;
+    for (auto& n : nodesAll) {
+        if (nodes.ids.count(n)) throw Unsupported{"duplicate node name in nodesAll"};
+        nodes.add(n);
+    }
+    const int N = (int)nodes.names.size();
+
+    // ---- partitions
+    const bool weights_nil = !o.PartitionWeights.has_value();
+    std::vector<std::string> pnames;
+    for (auto& kv : assign) {
+        if (!kv.second) throw Unsupported{"nil *Partition in partitionsToAssign"};
+        if (kv.second->Name != kv.first) throw Unsupported{"partition key != Partition.Name"};
+        pnames.push_back(kv.first);
+    }
+    const int P = (int)pnames.size();
+    f.part_weight.assign(P, 1);
+    f.part_has_weight.assign(P, 0);
+    f.part_in_prev.assign(P, 0);
+    f.never_equal.assign(P, 0);
+    if (!weights_nil)
+        for (int i = 0; i < P; i++) {
+            auto it = o.PartitionWeights->find(pnames[i]);
+            if (it != o.PartitionWeights->end()) { f.part_weight[i] = it->second; f.part_has_weight[i] = 1; }
+        }
+    std::set<std::string> removed_set;
+    if (nodesToRemove) removed_set.insert(nodesToRemove->begin(), nodesToRemove->end());
+    f.a_off.push_back(0);
+    f.p_off.push_back(0);
+    long long abs_load = 0;
+    auto labs64 = [](long long v) { return v < 0 ? -v : v; };
+    for (int i = 0; i < P; i++) {
+        const std::string& name = pnames[i];
+        const Partition& pa = *assign.at(name);
+        static const std::map<std::string, StringList> no_states;
+        const auto& nbs = pa.NodesByState ? *pa.NodesByState : no_states;
+        for (auto& kv : nbs)
+            if (!sid.count(kv.first)) throw Unsupported{"partition carries a state that is not in the model"};
+        for (auto& s : states) {
+            auto it = nbs.find(s);
+            if (it != nbs.end()) {
+                if (it->second) {
+                    std::set<std::string> seen(it->second->begin(), it->second->end());
+                    if (seen.size() != it->second->size()) throw Unsupported{"duplicate node inside a state list"};
+                    for (auto& x : *it->second) f.a_nodes.push_back(nodes.add(x));
+                }
+                f.a_kind.push_back(it->second ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
+            } else {
+                f.a_kind.push_back(BLANCE_LIST_ABSENT);
+            }
+            f.a_off.push_back((int32_t)f.a_nodes.size());
+        }
+        auto ip = prevMap.find(name);
+        const long long w = f.part_weight[i];
+        if (ip == prevMap.end()) {
+            if (!removed_set.empty() && any_pass)
+                throw Unsupported{"nodesToRemove non-empty but a partition is missing from prevMap (plan.go:545)"};
+            for (int m = 0; m < M; m++) { f.p_kind.push_back(BLANCE_LIST_ABSENT); f.p_off.push_back((int32_t)f.p_nodes.size()); }
+            continue;
+        }
+        if (!ip->second) throw Unsupported{"nil *Partition in prevMap"};
+        f.part_in_prev[i] = 1;
+        const Partition& pp = *ip->second;
+        if (!pp.NodesByState || pp.Name != name) f.never_equal[i] = 1;
+        const auto& pn = pp.NodesByState ? *pp.NodesByState : no_states;
+        for (auto& s : states) {
+            auto it = pn.find(s);
+            if (it != pn.end()) {
+                f.p_kind.push_back(it->second ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
+                if (it->second)
+                    for (auto& x : *it->second) { f.p_nodes.push_back(nodes.add(x)); abs_load += labs64(w); }
+            } else {
+                f.p_kind.push_back(BLANCE_LIST_ABSENT);
+            }
+            f.p_off.push_back((int32_t)f.p_nodes.size());
+        }
+        for (auto& kv : pn) {
+            if (sid.count(kv.first)) continue;
+            f.never_equal[i] = 1;
+            if (kv.second)
+                for (auto& x : *kv.second) {
+                    f.load_state.push_back(M); f.load_node.push_back(nodes.add(x));
+                    f.load_weight.push_back((int32_t)w); f.load_first.push_back(1);
+                    abs_load += labs64(w);
+                }
+        }
+    }
+    for (auto& kv : prevMap) {                              // partitions only in prevMap
+        if (assign.count(kv.first)) continue;
+        if (!kv.second) throw Unsupported{"nil *Partition in prevMap"};
+        long long w = 1;
+        if (!weights_nil) {
+            auto it = o.PartitionWeights->find(kv.first);
+            if (it != o.PartitionWeights->end()) w = it->second;
+        }
+        if (kv.second->NodesByState)
+            for (auto& sl : *kv.second->NodesByState) {
+                if (!sl.second) continue;
+                auto is = sid.find(sl.first);
+                for (auto& x : *sl.second) {
+                    f.load_state.push_back(is == sid.end() ? M : is->second); f.load_node.push_back(nodes.add(x));
+                    f.load_weight.push_back((int32_t)w); f.load_first.push_back(0);
+                    abs_load += labs64(w);
+                }
+            }
+    }
+    {
+        long long sumw = 0, maxw = 0, ksum = 0;
+        for (int i = 0; i < P; i++) { sumw += labs64(f.part_weight[i]); maxw = std::max<long long>(maxw, labs64(f.part_weight[i])); }
+        for (int k : f.state_constraints) ksum += std::max(k, 0);
+        abs_load += sumw * std::max<long long>(1, ksum) * 2;
+        if (abs_load > 2147483647LL || maxw > 2147483647LL)
+            throw Unsupported{"partition weights overflow the device's int32 load tables"};
+    }
+
+    // ---- node attributes (may still add names that are not in nodesAll)
+    if (nodesToRemove) for (auto& x : *nodesToRemove) nodes.add(x);
+    if (nodesToAdd) for (auto& x : *nodesToAdd) nodes.add(x);
+    if (o.NodeWeights) for (auto& kv : *o.NodeWeights) nodes.add(kv.first);
+    const int NX = (int)nodes.names.size();
+    f.node_removed.assign(NX, 0); f.node_added.assign(NX, 0); f.node_weight.assign(NX, 0); f.node_has_weight.assign(NX, 0);
+    if (nodesToRemove) for (auto& x : *nodesToRemove) f.node_removed[nodes.ids[x]] = 1;
+    if (nodesToAdd) for (auto& x : *nodesToAdd) f.node_added[nodes.ids[x]] = 1;
+    if (o.NodeWeights)
+        for (auto& kv : *o.NodeWeights) { f.node_weight[nodes.ids[kv.first]] = kv.second; f.node_has_weight[nodes.ids[kv.first]] = 1; }
+
+    f.state_stickiness.assign(M, 0); f.state_has_stickiness.assign(M, 0);
+    if (o.StateStickiness)
+        for (auto& kv : *o.StateStickiness) {
+            auto it = sid.find(kv.first);
+            if (it != sid.end()) { f.state_stickiness[it->second] = kv.second; f.state_has_stickiness[it->second] = 1; }
+        }
+
+    // ---- hierarchy rules and the tree as DFS leaf intervals (plan.go:703-774)
+    const bool rules_nil = !o.HierarchyRules_.has_value();
+    int VX = 0, v_empty = 0;
+    f.rule_off.push_back(0);
+    if (!rules_nil) {
+        for (int m = 0; m < M; m++) {
+            auto it = o.HierarchyRules_->find(states[m]);
+            if (it != o.HierarchyRules_->end())
+                for (auto& r : it->second) {
+                    if (!r) throw Unsupported{"nil *HierarchyRule"};
+                    f.rule_inc.push_back(std::max(r->IncludeLevel, 0));   // findAncestor: `for level > 0`
+                    f.rule_exc.push_back(std::max(r->ExcludeLevel, 0));
+                }
+            f.rule_off.push_back((int32_t)f.rule_inc.size());
+            int k = f.state_constraints[m];
+            if (k > 0 && (f.rule_off[m + 1] - f.rule_off[m]) * k > 64) throw Unsupported{"more than 64 hierarchy picks"};
+        }
+        if (nodes.ids.count("")) throw Unsupported{"\"\" used as a node name"};
+        Intern v = nodes;
+        static const std::map<std::string, std::string> no_hier;
+        const auto& hier = o.NodeHierarchy ? *o.NodeHierarchy : no_hier;
+        for (auto& kv : hier) { v.add(kv.first); v.add(kv.second); }
+        v_empty = v.add("");
+        VX = (int)v.names.size();
+        f.v_parent.assign(VX, v_empty);                     // findAncestor: missing -> ""
+        std::vector<std::vector<int>> children(VX);
+        std::vector<char> has_parent(VX, 0);
+        for (auto& kv : hier) {                             // std::map: children in name order (plan.go:705-715)
+            int c = v.ids[kv.first], p = v.ids[kv.second];
+            f.v_parent[c] = p;
+            children[p].push_back(c);
+            has_parent[c] = 1;
+        }
+        f.v_lo.assign(VX, -1); f.v_hi.assign(VX, -1);
+        int pos = 0;
+        for (int root = 0; root < VX; root++) {
+            if (has_parent[root]) continue;
+            std::vector<std::pair<int, size_t>> stack{{root, 0}};
+            while (!stack.empty()) {
+                auto [u, ci] = stack.back();
+                stack.pop_back();
+                if (ci == 0) {
+                    f.v_lo[u] = pos;
+                    if (children[u].empty()) { pos++; f.v_hi[u] = pos; continue; }   // a childless vertex is its own leaf
+                }
+                if (ci < children[u].size()) {
+                    stack.push_back({u, ci + 1});
+                    stack.push_back({children[u][ci], 0});
+                } else {
+                    f.v_hi[u] = pos;
+                }
+            }
+        }
+        for (int u = 0; u < VX; u++) if (f.v_lo[u] < 0 || f.v_hi[u] < 0) throw Unsupported{"cycle in NodeHierarchy"};
+        f.leaf_pos.assign(NX, -1);
+        for (int n = 0; n < NX; n++) if (children[n].empty()) f.leaf_pos[n] = f.v_lo[n];
+    } else {
+        f.rule_off.assign(M + 1, 0);
+        f.leaf_pos.assign(NX, -1);
+    }
+
+    // ---- static part of partitionSorter's key (plan.go:519-540), compared as the reference's strings
+    {
+        struct Key { std::string w, n, name; int i; };
+        std::vector<Key> keys;
+        for (int i = 0; i < P; i++) {
+            long long v = 0;
+            std::string nkey = (atoi_go(pnames[i], &v) && v >= 0) ? pad10(v) : pnames[i];
+            long long w = 1;
+            if (!weights_nil) {
+                auto it = o.PartitionWeights->find(pnames[i]);
+                if (it != o.PartitionWeights->end()) w = it->second;
+            }
+            keys.push_back({pad10(999999999LL - w), nkey, pnames[i], i});
+        }
+        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+            if (a.w != b.w) return a.w < b.w;
+            if (a.n != b.n) return a.n < b.n;
+            if (a.name != b.name) return a.name < b.name;
+            return a.i < b.i;
+        });
+        for (auto& k : keys) f.part_order.push_back(k.i);
+    }
+
+    blance_problem& pb = f.pb;
+    pb.n_nodes = N; pb.n_nodes_ext = NX; pb.n_states = M; pb.n_parts = P; pb.n_prev = (int32_t)prevMap.size();
+    pb.n_loads = (int32_t)f.load_state.size(); pb.n_rules = (int32_t)f.rule_inc.size(); pb.n_vertices = VX;
+    pb.max_iterations = MaxIterationsPerPlan;
+    pb.partition_weights_nil = weights_nil; pb.nodes_to_add_nil = !nodesToAdd.has_value();
+    pb.hierarchy_rules_nil = rules_nil; pb.booster_kind = (int32_t)NodeScoreBooster; pb.top_state = top_state;
+    pb.vertex_empty = v_empty;
+    pb.state_priority = ptr(f.state_priority); pb.state_constraints = ptr(f.state_constraints);
+    pb.state_stickiness = ptr(f.state_stickiness); pb.state_has_stickiness = ptr(f.state_has_stickiness);
+    pb.node_removed = ptr(f.node_removed); pb.node_added = ptr(f.node_added);
+    pb.node_weight = ptr(f.node_weight); pb.node_has_weight = ptr(f.node_has_weight);
+    pb.part_order = ptr(f.part_order); pb.part_weight = ptr(f.part_weight); pb.part_has_weight = ptr(f.part_has_weight);
+    pb.part_in_prev = ptr(f.part_in_prev); pb.part_prev_never_equal = ptr(f.never_equal);
+    if (P * M == 0) { f.a_off.assign(1, 0); f.p_off.assign(1, 0); }
+    pb.assign_off = ptr(f.a_off); pb.assign_nodes = ptr(f.a_nodes); pb.assign_kind = ptr(f.a_kind);
+    pb.prev_off = ptr(f.p_off); pb.prev_nodes = ptr(f.p_nodes); pb.prev_kind = ptr(f.p_kind);
+    pb.load_state = ptr(f.load_state); pb.load_node = ptr(f.load_node); pb.load_weight = ptr(f.load_weight);
+    pb.load_first_sweep_only = ptr(f.load_first);
+    pb.rule_off = ptr(f.rule_off); pb.rule_inc = ptr(f.rule_inc); pb.rule_exc = ptr(f.rule_exc);
+    pb.vertex_parent = ptr(f.v_parent); pb.vertex_leaf_lo = ptr(f.v_lo); pb.vertex_leaf_hi = ptr(f.v_hi);
+    pb.node_leaf_pos = ptr(f.leaf_pos);
+    f.node_names = nodes.names; f.state_names = states; f.part_names = pnames;
+}
+
+}  // namespace
+
+bool Library::open(const std::string& path, std::string* err) {
+    handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!handle) { if (err) *err = dlerror(); return false; }
+    Abi a;
+    a.validate = (int (*)(const blance_problem*))dlsym(handle, "blance_validate");
+    a.result_capacity = (int64_t (*)(const blance_problem*))dlsym(handle, "blance_result_capacity");
+    a.ctx_create = (int (*)(const blance_options*, blance_ctx**))dlsym(handle, "blance_ctx_create");
+    a.ctx_destroy = (void (*)(blance_ctx*))dlsym(handle, "blance_ctx_destroy");
+    a.plan = (int (*)(blance_ctx*, const blance_problem*, blance_result*))dlsym(handle, "blance_plan");
+    a.last_error = (const char* (*)(void))dlsym(handle, "blance_last_error");
+    if (!a.validate || !a.result_capacity || !a.ctx_create || !a.ctx_destroy || !a.plan || !a.last_error) {
+        if (err) *err = "library does not export the blance C ABI";
+        return false;
+    }
+    blance_options opt{};
+    const char* eager = getenv("BLANCE_HOST_EAGER_BULK");     // tests: bulk engines for passes of any size
+    if (eager && *eager) opt.reserved[1] = 1;
+    blance_ctx* c = nullptr;
+    if (a.ctx_create(&opt, &c) != BLANCE_OK) {               // no device: fail loudly, there is no CPU path
+        if (err) *err = std::string("blance_ctx_create: ") + a.last_error();
+        return false;
+    }
+    ctx = c;
+    g_abi[handle] = a;
+    return true;
+}
+
+void Library::close() {
+    if (handle) {
+        auto it = g_abi.find(handle);
+        if (it != g_abi.end()) {
+            if (ctx) it->second.ctx_destroy((blance_ctx*)ctx);
+            g_abi.erase(it);
+        }
+        dlclose(handle);
+    }
+    handle = nullptr;
+    ctx = nullptr;
+}
+
+PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& partitionsToAssign,
+                          const std::vector<std::string>& nodesAll, const StringList& nodesToRemove,
+                          const StringList& nodesToAdd, const PartitionModel& model,
+                          const PlanNextMapOptions& options) {
+    PlanOutcome out;
+    Flat f;
+    try {
+        build(f, prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model, options);
+    } catch (const Unsupported& u) {
+        out.why = u.why;
+        return out;
+    }
+    const Abi& abi = g_abi.at(lib.handle);
+    if (abi.validate(&f.pb) != BLANCE_OK) { out.why = abi.last_error(); return out; }
+    const int M = f.pb.n_states, P = f.pb.n_parts;
+    const size_t PM = (size_t)P * M;
+    int64_t cap = abi.result_capacity(&f.pb);
+    std::vector<int32_t> out_off(PM + 1), out_nodes((size_t)cap + 1), warn_part(PM + 1), warn_state(PM + 1);
+    std::vector<uint8_t> out_kind(PM + 1);
+    blance_result res{};
+    res.out_off = out_off.data(); res.out_nodes = out_nodes.data(); res.out_kind = out_kind.data();
+    res.out_capacity = cap;
+    res.warn_part = warn_part.data(); res.warn_state = warn_state.data(); res.warn_capacity = (int64_t)PM;
+    if (abi.plan((blance_ctx*)lib.ctx, &f.pb, &res) != BLANCE_OK) { out.why = abi.last_error(); return out; }
+    out.handled = true;
+    out.iterations = res.iterations;
+    out.converged = res.converged != 0;
+    if (res.iterations == 0) { out.nil_result = true; return out; }
+    for (int p = 0; p < P; p++) {
+        auto part = std::make_shared<Partition>();
+        part->Name = f.part_names[p];
+        part->NodesByState.emplace();
+        for (int m = 0; m < M; m++) {
+            size_t i = (size_t)p * M + m;
+            if (out_kind[i] == BLANCE_LIST_ABSENT) continue;
+            if (out_kind[i] == BLANCE_LIST_NIL) { (*part->NodesByState)[f.state_names[m]] = std::nullopt; continue; }
+            std::vector<std::string> lst;
+            for (int32_t j = out_off[i]; j < out_off[i + 1]; j++) lst.push_back(f.node_names[out_nodes[j]]);
+            (*part->NodesByState)[f.state_names[m]] = std::move(lst);
+        }
+        out.nextMap[part->Name] = part;
+    }
+    for (int64_t i = 0; i < res.n_warnings; i++) {           // plan.go:231-234
+        const std::string& name = f.part_names[warn_part[i]];
+        char buf[64];
+        snprintf(buf, sizeof buf, "%d", f.state_constraints[warn_state[i]]);
+        out.warnings[name].push_back(std::string("could not meet constraints: ") + buf + ", stateName: " +
+                                     f.state_names[warn_state[i]] + ", partitionName: " + name);
+    }
+    // plan.go:49-52: every non-converged sweep stores its partitions into both input maps;
+    // the last such store has the final map's content
+    if ((res.iterations > 1 || !res.converged) && prevMap)
+        for (auto& kv : out.nextMap) { (*prevMap)[kv.first] = kv.second; partitionsToAssign[kv.first] = kv.second; }
+    return out;
+}
+
+std::map<std::string, bool> StringsToMap(const std::vector<std::string>& strs) {          // misc.go:13-22
+    std::map<std::string, bool> m;
+    for (auto& s : strs) m[s] = true;
+    return m;
+}
+
+std::vector<std::string> StringsRemoveStrings(const std::vector<std::string>& a, const std::vector<std::string>& remove) {
+    auto rm = StringsToMap(remove);                                                       // misc.go:27-36
+    std::vector<std::string> rv;
+    for (auto& s : a) if (!rm.count(s)) rv.push_back(s);
+    return rv;
+}
+
+std::vector<std::string> StringsIntersectStrings(const std::vector<std::string>& a, const std::vector<std::string>& b) {
+    auto bm = StringsToMap(b);                                                            // misc.go:40-51
+    std::set<std::string> seen;
+    std::vector<std::string> rv;
+    for (auto& s : a) if (bm.count(s) && seen.insert(s).second) rv.push_back(s);
+    return rv;
+}
+
+}  // namespace blance

@@ -1,0 +1,160 @@
+// Test driver of the C++ API mirror: reads one PlanNextMapEx() call in a line
+// oriented text form from stdin (written by tests/test_host_cpp.py), runs it
+// through blance::PlanNextMapEx over the library given as argv[1], prints the
+// result, the warnings and the (mutated) input maps as JSON.
+#include <iostream>
+#include <sstream>
+
+#include "blance_api.hpp"
+
+using namespace blance;
+
+static std::string line() {
+    std::string s;
+    if (!std::getline(std::cin, s)) { fprintf(stderr, "unexpected end of input\n"); exit(2); }
+    return s;
+}
+static bool is_nil(const std::string& s) { return s == "NIL"; }
+
+static StringList read_list() {
+    std::string h = line();
+    if (is_nil(h)) return std::nullopt;
+    std::vector<std::string> v;
+    for (int i = 0, n = std::stoi(h); i < n; i++) v.push_back(line());
+    return v;
+}
+
+static PartitionMap read_map() {
+    PartitionMap m;
+    int n = std::stoi(line());
+    for (int i = 0; i < n; i++) {
+        std::string key = line();
+        auto p = std::make_shared<Partition>();
+        p->Name = line();
+        std::string h = line();
+        if (!is_nil(h)) {
+            p->NodesByState.emplace();
+            for (int j = 0, ns = std::stoi(h); j < ns; j++) {
+                std::string state = line();
+                (*p->NodesByState)[state] = read_list();
+            }
+        }
+        m[key] = p;
+    }
+    return m;
+}
+
+static std::optional<std::map<std::string, int>> read_int_map() {
+    std::string h = line();
+    if (is_nil(h)) return std::nullopt;
+    std::map<std::string, int> m;
+    for (int i = 0, n = std::stoi(h); i < n; i++) { std::string k = line(); m[k] = std::stoi(line()); }
+    return m;
+}
+
+static std::string q(const std::string& s) {
+    std::string o = "\"";
+    for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; }
+    return o + "\"";
+}
+
+static std::string dump_map(const PartitionMap& m) {
+    std::ostringstream o;
+    o << "{";
+    bool first = true;
+    for (auto& kv : m) {
+        if (!first) o << ",";
+        first = false;
+        o << q(kv.first) << ":{\"name\":" << q(kv.second->Name) << ",\"nodesByState\":";
+        if (!kv.second->NodesByState) o << "null";
+        else {
+            o << "{";
+            bool f2 = true;
+            for (auto& sl : *kv.second->NodesByState) {
+                if (!f2) o << ",";
+                f2 = false;
+                o << q(sl.first) << ":";
+                if (!sl.second) o << "null";
+                else {
+                    o << "[";
+                    for (size_t i = 0; i < sl.second->size(); i++) o << (i ? "," : "") << q((*sl.second)[i]);
+                    o << "]";
+                }
+            }
+            o << "}";
+        }
+        o << "}";
+    }
+    o << "}";
+    return o.str();
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: blance_host_cli <libblance_hip.so>\n"); return 2; }
+    Library lib;
+    std::string err;
+    if (!lib.open(argv[1], &err)) { fprintf(stderr, "cannot use %s: %s\n", argv[1], err.c_str()); return 3; }
+    int n_cases = std::stoi(line());
+    std::cout << "[";
+    for (int ci = 0; ci < n_cases; ci++) {
+        PartitionMap prev = read_map();
+        std::string a = line();
+        bool alias = a == "ALIAS";
+        PartitionMap assign_own;
+        if (!alias) assign_own = read_map();
+        PartitionMap& assign = alias ? prev : assign_own;
+        std::vector<std::string> nodesAll = *read_list();
+        StringList rm = read_list(), add = read_list();
+        PartitionModel model;
+        for (int i = 0, n = std::stoi(line()); i < n; i++) {
+            std::string s = line();
+            auto ms = std::make_shared<PartitionModelState>();
+            ms->Priority = std::stoi(line());
+            ms->Constraints = std::stoi(line());
+            model[s] = ms;
+        }
+        PlanNextMapOptions o;
+        o.ModelStateConstraints = read_int_map();
+        o.PartitionWeights = read_int_map();
+        o.StateStickiness = read_int_map();
+        o.NodeWeights = read_int_map();
+        {
+            std::string h = line();
+            if (!is_nil(h)) {
+                o.NodeHierarchy.emplace();
+                for (int i = 0, n = std::stoi(h); i < n; i++) { std::string c = line(); (*o.NodeHierarchy)[c] = line(); }
+            }
+        }
+        {
+            std::string h = line();
+            if (!is_nil(h)) {
+                o.HierarchyRules_.emplace();
+                for (int i = 0, n = std::stoi(h); i < n; i++) {
+                    std::string s = line();
+                    auto& v = (*o.HierarchyRules_)[s];
+                    for (int j = 0, nr = std::stoi(line()); j < nr; j++) {
+                        auto r = std::make_shared<HierarchyRule>();
+                        r->IncludeLevel = std::stoi(line());
+                        r->ExcludeLevel = std::stoi(line());
+                        v.push_back(r);
+                    }
+                }
+            }
+        }
+        NodeScoreBooster = line() == "cbgt" ? Booster::Cbgt : Booster::None;
+        PlanOutcome r = PlanNextMapEx(lib, &prev, assign, nodesAll, rm, add, model, o);
+        std::cout << (ci ? "," : "") << "{\"handled\":" << (r.handled ? "true" : "false") << ",\"why\":" << q(r.why)
+                  << ",\"iterations\":" << r.iterations << ",\"converged\":" << (r.converged ? "true" : "false")
+                  << ",\"nextMap\":" << dump_map(r.nextMap) << ",\"warnings\":{";
+        bool first = true;
+        for (auto& kv : r.warnings) {
+            std::cout << (first ? "" : ",") << q(kv.first) << ":[";
+            first = false;
+            for (size_t i = 0; i < kv.second.size(); i++) std::cout << (i ? "," : "") << q(kv.second[i]);
+            std::cout << "]";
+        }
+        std::cout << "},\"prevMap\":" << dump_map(prev) << ",\"partitionsToAssign\":" << dump_map(assign) << "}\n";
+    }
+    std::cout << "]\n";
+    return 0;
+}

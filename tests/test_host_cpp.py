@@ -1,0 +1,146 @@
+"""The C++ host mirror of the reference API (blance_amd/csrc/host): interning,
+the C-ABI call, un-interning, warnings text and caller-visible mutations, on the
+reference's golden inputs -- through the emulated kernels on CPU, and through
+the real library on a GPU box."""
+import copy
+import json
+import os
+import subprocess
+
+import pytest
+
+from oracle import blance_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "blance_amd", "csrc", "host")
+CLI = os.path.join(ROOT, "blance_amd", "lib", "blance_host_cli")
+
+
+def build_cli():
+    srcs = [os.path.join(HOST, "blance_host_cli.cpp"), os.path.join(HOST, "blance_api.cpp")]
+    deps = srcs + [os.path.join(HOST, "blance_api.hpp"), os.path.join(ROOT, "include", "blance_hip.h")]
+    if not os.path.exists(CLI) or any(os.path.getmtime(d) > os.path.getmtime(CLI) for d in deps):
+        os.makedirs(os.path.dirname(CLI), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", CLI] + srcs + ["-ldl"])
+    return CLI
+
+
+def _list(out, lst):
+    if lst is None:
+        out.append("NIL")
+    else:
+        out.append(str(len(lst)))
+        out.extend(lst)
+
+
+def _map(out, m):
+    out.append(str(len(m)))
+    for key, p in m.items():
+        out.append(key)
+        out.append(p.get("name", ""))
+        nbs = p.get("nodesByState")
+        if nbs is None:
+            out.append("NIL")
+        else:
+            out.append(str(len(nbs)))
+            for s, lst in nbs.items():
+                out.append(s)
+                _list(out, lst)
+
+
+def _imap(out, m):
+    if m is None:
+        out.append("NIL")
+    else:
+        out.append(str(len(m)))
+        for k, v in m.items():
+            out.extend([k, str(v)])
+
+
+def serialize(cases):
+    out = [str(len(cases))]
+    for c in cases:
+        _map(out, c["prevMap"])
+        if c.get("aliased"):
+            out.append("ALIAS")
+        else:
+            out.append("OWN")
+            _map(out, c["partitionsToAssign"])
+        _list(out, c["nodesAll"])
+        _list(out, c["nodesToRemove"])
+        _list(out, c["nodesToAdd"])
+        out.append(str(len(c["model"])))
+        for s, ms in c["model"].items():
+            out.extend([s, str(ms["priority"]), str(ms["constraints"])])
+        for k in ("modelStateConstraints", "partitionWeights", "stateStickiness", "nodeWeights"):
+            _imap(out, c.get(k))
+        nh = c.get("nodeHierarchy")
+        if nh is None:
+            out.append("NIL")
+        else:
+            out.append(str(len(nh)))
+            for k, v in nh.items():
+                out.extend([k, v])
+        hr = c.get("hierarchyRules")
+        if hr is None:
+            out.append("NIL")
+        else:
+            out.append(str(len(hr)))
+            for s, rl in hr.items():
+                out.extend([s, str(len(rl))])
+                for r in rl:
+                    out.extend([str(r["includeLevel"]), str(r["excludeLevel"])])
+        out.append(c.get("booster") or "none")
+    return "\n".join(out) + "\n"
+
+
+def run_cli(lib, cases, eager=False):
+    env = dict(os.environ)
+    if eager:
+        env["BLANCE_HOST_EAGER_BULK"] = "1"
+    p = subprocess.run([build_cli(), lib], input=serialize(cases), capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr
+    return json.loads(p.stdout)
+
+
+def _check(cases, results):
+    for c, got in zip(cases, results):
+        prev_o = R.partition_map_from_json(copy.deepcopy(c["prevMap"]))
+        assign_o = prev_o if c.get("aliased") else R.partition_map_from_json(copy.deepcopy(c["partitionsToAssign"]))
+        opts_o = R.Options(c.get("modelStateConstraints"), c.get("partitionWeights"), c.get("stateStickiness"),
+                           c.get("nodeWeights"), c.get("nodeHierarchy"), c.get("hierarchyRules"))
+        info = {}
+        want, want_w = R.plan_next_map_ex(prev_o, assign_o, list(c["nodesAll"]), c["nodesToRemove"], c["nodesToAdd"],
+                                          c["model"], opts_o, c.get("booster"), info=info)
+        assert got["handled"], (c["source"], got["why"])
+        assert got["nextMap"] == R.partition_map_to_json(want) == c["exp"], c["source"]
+        assert got["warnings"] == (want_w or {}), c["source"]
+        assert got["iterations"] == info["iterations"] and got["converged"] == info["converged"], c["source"]
+        assert got["prevMap"] == R.partition_map_to_json(prev_o), c["source"]          # plan.go:49-52
+        assert got["partitionsToAssign"] == R.partition_map_to_json(assign_o), c["source"]
+
+
+def test_cpp_mirror_on_golden_cases_emulated(golden_cases):
+    from test_simt_emulated import build_emu
+    _check(golden_cases, run_cli(build_emu(), golden_cases))
+    _check(golden_cases, run_cli(build_emu(), golden_cases, eager=True))
+
+
+def test_cpp_mirror_refuses_what_python_refuses():
+    from test_simt_emulated import build_emu
+    base = {"prevMap": {}, "partitionsToAssign": {"0": {"name": "0", "nodesByState": {}}}, "aliased": False,
+            "nodesAll": ["a", "b"], "nodesToRemove": [], "nodesToAdd": [],
+            "model": {"primary": {"priority": 0, "constraints": 1}}}
+    bad = [dict(base, nodesAll=["a", "a"]),
+           dict(base, partitionsToAssign={"0": {"name": "0", "nodesByState": {"dead": ["a"]}}}),
+           dict(base, model={"a": {"priority": 1, "constraints": 1}, "b": {"priority": 0, "constraints": 1}}),
+           dict(base, partitionsToAssign={"0": {"name": "zero", "nodesByState": {}}})]
+    for got in run_cli(build_emu(), bad):
+        assert not got["handled"] and got["why"]
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_golden_cases_gpu(golden_cases):
+    from blance_amd import hip
+    _check(golden_cases, run_cli(hip.LIB_PATH, golden_cases))
+    _check(golden_cases, run_cli(hip.LIB_PATH, golden_cases, eager=True))
