@@ -793,6 +793,113 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             if (b >= nb) break;
             if (nok == 64) continue;
         }
+        // ---- FAST mode, runs of blank steps (a partition that holds no node in any
+        // state, apart from higher priority nodes already inside the top node's exclude
+        // class): nothing to match, demote or un-count, so a step is k masked minima over
+        // the packed keys plus two counter bumps.  Lane a pre-scans step b + a; the run
+        // is walked with everything in registers.
+        if (FAST) {
+            const int sb = b + lane;
+            const bool active = sb < nb;
+            const int* rp = recbuf + (active ? sb : b) * kCW;
+            const int w0 = recbuf[b * kCW + 1];
+            const int tcv = rp[6];
+            const bool blank = active && (rp[5] & 0xffffff) == 0 && rp[1] == w0 && tcv >= 0;
+            const unsigned long long nm = __ballot(!blank);
+            int run = nm ? __ffsll((long long)nm) - 1 : 64;
+            if (run > nb - b) run = nb - b;
+            if (run > 0 && w0 > 0 && w0 < (1 << 14)) {
+                unsigned key[NPTC];
+#pragma unroll
+                for (int u = 0; u < NPTC; u++)
+                    key[u] = ((alive_m >> u) & 1) ? (((unsigned)(2 * cntv[u] + kKeyBias) << 13) | (unsigned)nid[u]) : kKeyNone;
+                const unsigned bump = (unsigned)(2 * w0) << 13;
+                bool esc = false;
+                int r = 0;
+                for (; r < run; r++) {
+                    int acls = __builtin_amdgcn_readlane(tcv, r);
+                    int ec[KM];
+#pragma unroll
+                    for (int j = 0; j < KM; j++) ec[j] = -2;
+                    int covered = 0;
+                    unsigned excl_m = 0;
+                    int chosen[KM];
+#pragma unroll
+                    for (int j = 0; j < KM; j++) chosen[j] = -1;
+                    unsigned picked_m = 0;
+#pragma unroll
+                    for (int slot = 0; slot < KM; slot++) {
+                        if (slot < k) {
+                            bool dup = false;
+#pragma unroll
+                            for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
+                            if (acls < 0) esc = true;
+                            if (!dup) {
+                                ec[slot] = acls;
+                                covered += cszL[acls < 0 ? 0 : acls];
+#pragma unroll
+                                for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
+                            }
+                            if (covered >= size) esc = true;
+                            unsigned km = kKeyNone;
+#pragma unroll
+                            for (int u = 0; u < NPTC; u++) {
+                                const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
+                                km = kv < km ? kv : km;
+                            }
+                            const unsigned kb = wave_min_u32(km);
+                            if (kb == kKeyNone) esc = true;
+                            int wcls = -1;
+#pragma unroll
+                            for (int u = 0; u < NPTC; u++) {
+                                const bool mine = key[u] == kb && kb != kKeyNone;
+                                unsigned long long bm = __ballot(mine);
+                                if (bm) wcls = __builtin_amdgcn_readlane(cls[u], __ffsll((long long)bm) - 1);
+                                picked_m |= (mine ? 1u : 0u) << u;
+                            }
+                            // a duplicate pick is impossible: the winner's own class is excluded next,
+                            // unless it has none (wcls < 0 -> escape)
+                            chosen[slot] = (int)(kb & 0x1fff);
+                            acls = wcls;
+                        }
+                    }
+                    if (__ballot(esc)) break;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) {
+                        if ((picked_m >> u) & 1) {
+                            key[u] += bump;
+                            cntv[u] += w0;
+                            totv[u] += w0;
+                            if (cntv[u] >= (1 << 15)) range_bad = true;
+                        }
+                    }
+                    if (lane == 0) {
+                        int* o = outbuf + (b + r) * q.OW;
+                        o[0] = k;
+#pragma unroll
+                        for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
+                    }
+                    if (__ballot(range_bad)) { r++; break; }
+                }
+                // refresh the mirrors and the partition-independent scores of my leaves
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    const int i = lane + 64 * u;
+                    if (i < size) {
+                        g[u] = (double)cntv[u];
+                        gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u];
+                    }
+                }
+                BLANCE_WAVE_SYNC();
+                gmin_dirty = true;
+                if (r > 0) try_spec = false;          // the run's steps were moves
+                b += r;
+                if (__ballot(range_bad)) { escaped = true; break; }
+                if (b >= nb) break;
+                if (r > 0 && !__ballot(esc)) continue;
+                // an escape inside the run: let the general step decide (it escapes the same way)
+            }
+        }
         // ---- general step: findBestNodes (plan.go:98-248) + commit (plan.go:290-301)
         PH(1);
         const int recw = lane < kCW ? recbuf[b * kCW + lane] : 0;
