@@ -804,20 +804,24 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const int* rp = recbuf + (active ? sb : b) * kCW;
             const int w0 = recbuf[b * kCW + 1];
             const int tcv = rp[6];
+            const int tcsz = cszL[tcv < 0 ? 0 : tcv];       // leaves covered by the top node's exclude class
             const bool blank = active && (rp[5] & 0xffffff) == 0 && rp[1] == w0 && tcv >= 0;
             const unsigned long long nm = __ballot(!blank);
             int run = nm ? __ffsll((long long)nm) - 1 : 64;
             if (run > nb - b) run = nb - b;
             if (run > 0 && w0 > 0 && w0 < (1 << 14)) {
                 unsigned key[NPTC];
+                int mycsz[NPTC];
 #pragma unroll
-                for (int u = 0; u < NPTC; u++)
+                for (int u = 0; u < NPTC; u++) {
                     key[u] = ((alive_m >> u) & 1) ? (((unsigned)(2 * cntv[u] + kKeyBias) << 13) | (unsigned)nid[u]) : kKeyNone;
+                    mycsz[u] = cszL[cls[u] < 0 ? 0 : cls[u]];
+                }
                 const unsigned bump = (unsigned)(2 * w0) << 13;
                 bool esc = false;
                 int r = 0;
                 for (; r < run; r++) {
-                    int acls = __builtin_amdgcn_readlane(tcv, r);
+                    int acls = __builtin_amdgcn_readlane(tcv, r), acsz = __builtin_amdgcn_readlane(tcsz, r);
                     int ec[KM];
 #pragma unroll
                     for (int j = 0; j < KM; j++) ec[j] = -2;
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                             if (acls < 0) esc = true;
                             if (!dup) {
                                 ec[slot] = acls;
-                                covered += cszL[acls < 0 ? 0 : acls];
+                                covered += acsz;
 #pragma unroll
                                 for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
                             }
@@ -849,18 +853,23 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                             }
                             const unsigned kb = wave_min_u32(km);
                             if (kb == kKeyNone) esc = true;
-                            int wcls = -1;
+                            int wcls = -1, wcsz = 0;
 #pragma unroll
                             for (int u = 0; u < NPTC; u++) {
                                 const bool mine = key[u] == kb && kb != kKeyNone;
                                 unsigned long long bm = __ballot(mine);
-                                if (bm) wcls = __builtin_amdgcn_readlane(cls[u], __ffsll((long long)bm) - 1);
+                                if (bm) {
+                                    const int wl = __ffsll((long long)bm) - 1;
+                                    wcls = __builtin_amdgcn_readlane(cls[u], wl);
+                                    wcsz = __builtin_amdgcn_readlane(mycsz[u], wl);
+                                }
                                 picked_m |= (mine ? 1u : 0u) << u;
                             }
                             // a duplicate pick is impossible: the winner's own class is excluded next,
                             // unless it has none (wcls < 0 -> escape)
                             chosen[slot] = (int)(kb & 0x1fff);
                             acls = wcls;
+                            acsz = wcsz;
                         }
                     }
                     if (__ballot(esc)) break;

@@ -206,3 +206,33 @@ def pass_kernel_states(fp):
     cons = fp.arrays["state_constraints"]
     return [m for m in range(int(fp.scalars["n_states"]))
             if int(cons[m]) > 0 and (_state_has_rules(fp, m) or int(cons[m]) != 1)]
+
+
+def rebalance_case(P=4096, N=128, seed=5, remove_frac=0.1, add_frac=0.1, hierarchy=False):
+    """BASELINE.json config 5 in miniature: Zipf-weighted partitions,
+    heterogeneous node weights, stickiness, and a rebalance that removes / adds a
+    tenth of the nodes.  Returns the API-level arguments WITHOUT a prevMap: the
+    caller plans once over the old nodes and feeds that plan back (see
+    tests/test_hip_parity.py::test_config5_miniature)."""
+    import random
+    rng = random.Random(seed)
+    nodes = ["n%04d" % i for i in range(N)]
+    order = nodes[:]
+    rng.shuffle(order)
+    n_rm = max(1, int(N * remove_frac))
+    n_add = max(1, int(N * add_frac))
+    to_add = sorted(order[:n_add])
+    to_remove = sorted(order[n_add:n_add + n_rm])
+    old_nodes = [n for n in nodes if n not in to_add]
+    ranks = list(range(1, P + 1))
+    rng.shuffle(ranks)
+    weights = {str(i): max(1, min(1000, 1000 // ranks[i])) for i in range(P)}
+    node_weights = {n: rng.choice([1, 1, 2, 4]) for n in nodes}
+    case = {"model": MODEL_P1R2, "nodesAll": nodes, "oldNodes": old_nodes, "nodesToRemove": to_remove,
+            "nodesToAdd": to_add, "partitionWeights": weights, "nodeWeights": node_weights,
+            "stateStickiness": {"primary": 100, "replica": 10}, "partitions": [str(i) for i in range(P)],
+            "nodeHierarchy": None, "hierarchyRules": None}
+    if hierarchy:
+        case["nodeHierarchy"] = hierarchy_names(N)
+        case["hierarchyRules"] = {"replica": [{"includeLevel": 2, "excludeLevel": 1}]}
+    return case

@@ -164,6 +164,36 @@ def test_config3_reduced(planner, P, N):
     _same(planner.plan(fp), _oracle(fp), ("cfg3", P, N))
 
 
+def _rebalance(planner_obj, P, N, hierarchy):
+    """Config 5 in miniature: plan over the old nodes, then rebalance with 10 % of the
+    nodes removed and 10 % added; both calls bit-exact against the oracle."""
+    c = synth.rebalance_case(P=P, N=N, hierarchy=hierarchy)
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"],
+                hierarchy_rules=c["hierarchyRules"])
+    fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
+    r1 = planner_obj.plan(fp1)
+    _same(r1, _oracle(fp1), ("initial plan", P, N))
+    plan1, _ = problem.decode_result(fp1, r1)
+    fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+    r2 = planner_obj.plan(fp2)
+    _same(r2, _oracle(fp2), ("rebalance", P, N))
+    plan2, _ = problem.decode_result(fp2, r2)
+    gone = set(c["nodesToRemove"])
+    assert not any(n in gone for p in plan2.values() for lst in p["nodesByState"].values() for n in lst)
+    return r1, r2
+
+
+def test_config5_miniature_flat(planner):
+    r1, r2 = _rebalance(planner, P=6000, N=96, hierarchy=False)
+    assert r1.iterations >= 2 and r2.iterations >= 2
+
+
+def test_config5_miniature_hierarchy(planner):
+    _rebalance(planner, P=6000, N=256, hierarchy=True)
+
+
 def test_resident_replan_is_deterministic(planner):
     fp = synth.config_flat(3, P=8192, N=512)
     planner.upload(fp)

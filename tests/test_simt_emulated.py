@@ -145,6 +145,24 @@ def test_reduced_configs(emu_lib):
     pl.close()
 
 
+def test_rebalance_miniature(emu_lib):
+    """Config 5's shape: weights, node weights, stickiness, remove + add nodes."""
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=8)
+    for hierarchy, N in ((False, 24), (True, 64)):
+        c = synth.rebalance_case(P=300, N=N, hierarchy=hierarchy)
+        fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+        opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                    node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"],
+                    hierarchy_rules=c["hierarchyRules"])
+        fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
+        r1 = pl.plan(fp1)
+        assert r1.digest() == _oracle(fp1).digest()
+        plan1, _ = problem.decode_result(fp1, r1)
+        fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+        assert pl.plan(fp2).digest() == _oracle(fp2).digest()
+    pl.close()
+
+
 def test_several_nodes_per_thread(emu_lib):
     """NX > T exercises the NPT > 1 register tiles."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64)
