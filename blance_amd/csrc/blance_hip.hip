@@ -2486,6 +2486,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int32_t* scal = c->scalars.as<int32_t>();
     int64_t launches = 0, steps = 0, batched = 0;
     int n_pass = 0;
+    unsigned chain_gave_up = 0;     // states whose chain pass had to be redone sequentially
 
     DevProblem d;
     d.N = N; d.NX = NX; d.M = M; d.L = L; d.P = P;
@@ -2559,7 +2560,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             // ---- region chains, when the state's single hierarchy rule allows them
             bool done = false;
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
-                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
+                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4 && !((chain_gave_up >> m) & 1)) {
                 blance_ctx::RuleRegions& rr = c->rule_regions[r0];
                 const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
@@ -2623,6 +2624,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                         batched += P;
                         done = true;
                     } else {                                        // not region-local after all: redo in order
+                        chain_gave_up |= 1u << m;                  // and do not try again in later sweeps
                         HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                               hipMemcpyDeviceToDevice, sm));
                     }
