@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = (double)i / (double)NP;
         for (int i = lane; i < kFfTab; i += 64) ff_tab[i] = (0.001 * (double)i) / (double)NP;
         if (q.ntn_in_lds)
-            for (int i = lane; i < size * ST; i += 64) ntn_l[i] = 0;
+            for (int i = lane; i < (size + 1) * ST; i += 64) ntn_l[i] = 0;    // last row: "" (flat mode)
     }
     for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
     __syncthreads();
@@ -661,6 +661,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         }
     }
     bool escaped = __ballot(range_bad) != 0;
+    int stop_at = cbeg;                            // flat mode: first step this launch did not do
+    bool stop_range = escaped;
     // stay speculation: tried again whenever the last general step turned out to be a stay
     const bool spec_ok = q.ntn_in_lds || NP == 0;
     bool try_spec = true, gmin_dirty = true;
@@ -739,14 +741,14 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
 #pragma unroll
                 for (int j = 0; j < KM; j++) {
                     if (j < k) {
-                        if (oc[j] < 0) fail = true;
+                        if (oc[j] < 0 && !(q.flat && j == 0)) fail = true;
                         bool dup = false;
 #pragma unroll
                         for (int e = 0; e < KM; e++) if (e < j && oc[e] == oc[j]) dup = true;
-                        if (!dup) cov += cszL[oc[j] < 0 ? 0 : oc[j]];
+                        if (!dup && oc[j] >= 0) cov += cszL[oc[j]];
                         if (cov >= size) fail = true;
 #pragma unroll
-                        for (int e = 0; e < KM; e++) if (e <= j && oc[e] == oc[j + 1]) fail = true;
+                        for (int e = 0; e < KM; e++) if (e <= j && oc[e] >= 0 && oc[e] == oc[j + 1]) fail = true;
                     }
                 }
             }
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const int w0 = recbuf[b * kCW + 1];
             const int tcv = rp[6];
             const int tcsz = cszL[tcv < 0 ? 0 : tcv];       // leaves covered by the top node's exclude class
-            const bool blank = active && (rp[5] & 0xffffff) == 0 && rp[1] == w0 && tcv >= 0;
+            const bool blank = active && (rp[5] & 0xffffff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
             const unsigned long long nm = __ballot(!blank);
             int run = nm ? __ffsll((long long)nm) - 1 : 64;
             if (run > nb - b) run = nb - b;
@@ -837,8 +839,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                             bool dup = false;
 #pragma unroll
                             for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
-                            if (acls < 0) esc = true;
-                            if (!dup) {
+                            if (acls < 0 && !(q.flat && slot == 0)) esc = true;
+                            if (!dup && acls >= 0) {
                                 ec[slot] = acls;
                                 covered += acsz;
 #pragma unroll
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 gmin_dirty = true;
                 if (r > 0) try_spec = false;          // the run's steps were moves
                 b += r;
-                if (__ballot(range_bad)) { escaped = true; break; }
+                if (__ballot(range_bad)) { escaped = true; stop_range = true; break; }
                 if (b >= nb) break;
                 if (r > 0 && !__ballot(esc)) continue;
                 // an escape inside the run: let the general step decide (it escapes the same way)
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             ntnv[u] = 0;
             if (!FAST && NP > 0) {
                 if (q.ntn_in_lds) { if (lane + 64 * u < size) ntnv[u] = ntn_l[tl * ST + lane + 64 * u]; }
-                else if (nid[u] >= 0 && nid[u] < N) ntnv[u] = q.ntn[(size_t)nidL[tl] * N + nid[u]];
+                else if (nid[u] >= 0 && nid[u] < N) ntnv[u] = q.ntn[(size_t)(tl < size ? nidL[tl] : NX) * N + nid[u]];
             }
         }
         PH(2);
@@ -999,10 +1001,10 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 bool dup = false;
 #pragma unroll
                 for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
-                if (acls < 0) esc = true;
-                if (!dup) {
+                if (acls < 0 && !(q.flat && slot == 0)) esc = true;
+                if (!dup && acls >= 0) {
                     ec[slot] = acls;
-                    covered += cszL[acls < 0 ? 0 : acls];
+                    covered += cszL[acls];
 #pragma unroll
                     for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
                 }
@@ -1073,7 +1075,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     dt[u] += mine ? w : 0;
                     if (!FAST && NP > 0 && mine) {
                         if (q.ntn_in_lds) ntn_l[tl * ST + lane + 64 * u] = ntnv[u] + 1;      // plan.go:238-245
-                        else q.ntn[(size_t)nidL[tl] * N + nid[u]] = ntnv[u] + 1;
+                        else q.ntn[(size_t)(tl < size ? nidL[tl] : NX) * N + nid[u]] = ntnv[u] + 1;
                     }
                 }
             }
@@ -1136,18 +1138,29 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         PH(11);
 #undef REC
         BLANCE_WAVE_SYNC();
-        if (__ballot(range_bad)) { escaped = true; break; }
         b++;
+        if (__ballot(range_bad)) { escaped = true; stop_range = true; break; }
       }
       __syncthreads();
-      if (!escaped)
-          for (int i = lane; i < nb * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
+      stop_at = base + b;
+      // flat mode keeps the steps done before a stop; a region chain's pass is redone as a whole
+      const int n_done = (!escaped || q.flat) ? b : 0;
+      for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
     }
     PH_DUMP(cend - cbeg);
     if (lane == 0 && spec_batches) { atomicAdd(&q.flags[2], spec_steps); atomicAdd(&q.flags[3], spec_batches); }
     if (escaped) {
-        if (lane == 0) q.flags[1] = 1;
-        return;
+        if (lane == 0) { q.flags[1] = 1; q.flags[4] = stop_at; q.flags[5] = stop_range ? 1 : 0; }
+        if (!q.flat) return;
+        // the rest of the pass continues from global memory: hand over the LDS rows
+        if (!FAST && NP > 0 && q.ntn_in_lds) {
+            __syncthreads();
+            for (int i = lane; i < (size + 1) * size; i += 64) {
+                const int row = i / size, col = i - row * size;
+                const int cn = nidL[col];
+                if (cn >= 0 && cn < N) q.ntn[(size_t)(row < size ? nidL[row] : NX) * N + cn] = ntn_l[row * ST + col];
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < NPTC; u++)
@@ -1668,7 +1681,7 @@ __global__ void k_chain_classify(DevProblem d, int m, int top_state, const int32
 __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
                                const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
                                const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
-                               const int32_t* leaf_cls, int32_t* crec, int32_t* flags) {
+                               const int32_t* leaf_cls, int flat, int32_t* crec, int32_t* flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.P) return;
     int p = chain_order[i];
@@ -1683,11 +1696,16 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
     r[0] = p; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
     int idxT = p * d.M + top_state;
     int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
-    int rg = top >= 0 ? node_region[top] : -1;
+    int rg = flat ? 0 : (top >= 0 ? node_region[top] : -1);
     if (rg < 0) { flags[0] = 1; r[4] = 0; r[5] = 0; r[6] = -1; return; }
     const int lo = reg_lo[rg];
-    r[4] = node_leaf_pos[top] - lo;
-    r[6] = leaf_cls[node_leaf_pos[top]];
+    if (flat) {
+        r[4] = top >= 0 ? top : d.NX;              // the "" row when there is no top priority node
+        r[6] = -1;                                 // no anchor: nothing is excluded in the first slot
+    } else {
+        r[4] = node_leaf_pos[top] - lo;
+        r[6] = leaf_cls[node_leaf_pos[top]];
+    }
     bool bad = false;
     int own_nodes[kChainOwn];
     int n_own = 0, n_h = 0, n_low = 0, present = 0;
@@ -1918,6 +1936,7 @@ struct blance_ctx {
     int L = 1, np_later = 0, n_alive = 0, any_removed = 0;
     int chain_min_parts = 2048;
     int any_node_weight = 0;
+    bool no_fast_keys = false;      // a chain left the packed keys' range during this pass
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -1925,6 +1944,8 @@ struct blance_ctx {
     };
     std::vector<RuleRegions> rule_regions;
     DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save, crec;
+    DevBuf fl_iota, fl_zero, fl_one, fl_reglo, fl_reghi;   // the whole cluster as one region (flat single chain)
+    bool flat_chain_ok = false;
     DevBuf f_tot, f_g, f_top_g, f_top_n, f_row_count, f_m, f_moff, f_keys_a, f_keys_b, f_vals_a, f_vals_b, f_hist;
     int64_t steps_batched = 0;
     int64_t out_capacity = 0;
@@ -1960,7 +1981,8 @@ struct blance_ctx {
         for (DevBuf* b : all) b->release();
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
         rule_regions.clear();
-        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &f_tot, &f_g,
+        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &fl_iota, &fl_zero,
+                          &fl_one, &fl_reglo, &fl_reghi, &f_tot, &f_g,
                           &f_top_g, &f_top_n, &f_row_count, &f_m, &f_moff, &f_keys_a, &f_keys_b, &f_vals_a,
                           &f_vals_b, &f_hist};
         for (DevBuf* b : more) b->release();
@@ -2291,7 +2313,18 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
         RESERVE(bucket_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv(P, kPartChunk) + 1) + 1));
         RESERVE(reg_off, sizeof(int32_t) * ((size_t)maxB + 2));
         RESERVE(cnt_save, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1));
-        if (maxB > 1) RESERVE(crec, sizeof(int32_t) * ((size_t)P * kCW + 64));
+        c->flat_chain_ok = NX >= 1 && NX <= 256 && L <= kChainOwn;
+        if (maxB > 1 || c->flat_chain_ok) RESERVE(crec, sizeof(int32_t) * ((size_t)P * kCW + 64));
+        if (c->flat_chain_ok) {
+            std::vector<int32_t> iota((size_t)NX + 1), zero((size_t)NX + 1, 0), one((size_t)NX + 1, 1);
+            for (int i = 0; i <= NX; i++) iota[i] = i;
+            int32_t lo0 = 0, hi0 = NX;
+            PUT(fl_iota, iota.data(), iota.size());
+            PUT(fl_zero, zero.data(), zero.size());
+            PUT(fl_one, one.data(), one.size());
+            PUT(fl_reglo, &lo0, 1);
+            PUT(fl_reghi, &hi0, 1);
+        }
         RESERVE(f_tot, sizeof(int32_t) * ((size_t)NX + 1));
         RESERVE(f_g, sizeof(double) * ((size_t)NX + 1));
         RESERVE(f_top_g, sizeof(double) * kTopList);
@@ -2364,11 +2397,56 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
 }
 
 static int dispatch_pass(blance_ctx* c, const PassParams& q);
+static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size);
+
+// Steps [beg, end) of a flat pass on ONE wave64 (clusters of <= 256 node names): the
+// chain kernel with the whole cluster as its region and every node its own exclude
+// class.  Where the chain cannot go on exactly it stops; k_pass_seq does a few steps
+// and the chain resumes.  crec must hold the pass's compact records in pass order.
+static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool lds_rows, int32_t* scal,
+                          int64_t* launches) {
+    hipStream_t sm = c->stream;
+    ChainParams cq;
+    memset(&cq, 0, sizeof cq);
+    cq.N = q.N; cq.NX = q.NX; cq.M = q.M; cq.L = q.L; cq.s = q.s; cq.k = q.k; cq.NP = q.NP; cq.OW = q.OW;
+    cq.booster_kind = q.booster_kind;
+    cq.n_regions = 1; cq.flat = 1;
+    cq.reg_lo = c->fl_reglo.as<int32_t>(); cq.reg_hi = c->fl_reghi.as<int32_t>();
+    cq.reg_off = c->reg_off.as<int32_t>();
+    cq.leaf_node = c->fl_iota.as<int32_t>(); cq.leaf_cls = c->fl_iota.as<int32_t>(); cq.cls_size = c->fl_one.as<int32_t>();
+    cq.alive = q.alive; cq.node_weight = q.node_weight; cq.node_has_weight = q.node_has_weight;
+    cq.cnt = q.cnt; cq.ntn = q.ntn; cq.crec = c->crec.as<int32_t>(); cq.out = q.out; cq.flags = scal + 4;
+    int pos = beg;
+    while (pos < end) {
+        int32_t range[2] = {pos, end};
+        HIPTRY(hipMemcpyAsync(c->reg_off.p, range, sizeof range, hipMemcpyHostToDevice, sm));
+        HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+        cq.ntn_in_lds = lds_rows ? 1 : 0;
+        if (!dispatch_chain(c, cq, q.NX)) return fail(BLANCE_ERR_UNSUPPORTED, "flat chain shape");
+        int32_t fl[8] = {0};
+        HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipStreamSynchronize(sm));
+        *launches += 1;
+        lds_rows = false;                          // a stopped chain handed its rows to global memory
+        if (fl[0]) return 1;                       // a step the compact record cannot hold: caller falls back
+        if (!fl[1]) break;                         // ran to the end
+        if (fl[5]) c->no_fast_keys = true;
+        int stop = fl[4];
+        int nseq = end - stop < 16 ? end - stop : 16;
+        q.beg = stop; q.end = stop + nseq;
+        int e = dispatch_pass(c, q);
+        if (e) return e;
+        *launches += 1;
+        pos = stop + nseq;
+    }
+    return 0;
+}
 
 // A flat pass (no hierarchy rule for the state): runs of certain stays and of
 // fresh identical partitions are resolved in bulk, the rest by k_pass_seq in
 // order on sub-ranges.  See the "Flat bulk engine" comment above the kernels.
-static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched) {
+static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
+                         bool chain_ok) {
     hipStream_t sm = c->stream;
     const int P = q.P;
     FlatParams fq;
@@ -2430,10 +2508,16 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             continue;
         }
         int B = P - pos < seq_batch ? P - pos : seq_batch;
-        q.beg = pos; q.end = pos + B;
-        int e = dispatch_pass(c, q);
-        if (e) return e;
-        *launches += 1;
+        int e;
+        if (chain_ok) {                               // small cluster: one wave64 walks the batch
+            e = run_flat_chain(c, q, pos, pos + B, false, scal, launches);
+            if (e < 0) return e;
+        } else {
+            q.beg = pos; q.end = pos + B;
+            e = dispatch_pass(c, q);
+            if (e) return e;
+            *launches += 1;
+        }
         pos += B;
         dirty = true;
         if (seq_batch < (1 << 20)) seq_batch *= 2;
@@ -2456,9 +2540,9 @@ static void launch_chain_mode(blance_ctx* c, const ChainParams& q, size_t lds, b
 // one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
 static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
     int nptc = cdiv(max_size, 64);
-    size_t ntn_bytes = sizeof(int32_t) * (size_t)max_size * (max_size + 1);
-    q.ntn_in_lds = ntn_bytes <= 100 * 1024;
-    const bool fast = q.NP == 0 && !c->any_node_weight;
+    size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
+    if (!q.flat || q.ntn_in_lds) q.ntn_in_lds = ntn_bytes <= 100 * 1024;   // flat mode may insist on global rows
+    const bool fast = q.NP == 0 && !c->any_node_weight && !c->no_fast_keys;
     size_t lds = sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
                  sizeof(int32_t) * 64 * (size_t)(kCW + q.OW) + (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
     if (q.k <= 2) {
@@ -2583,7 +2667,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
                                      c->chain_order.as<int32_t>(), c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
-                                     rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
+                                     rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(), 0,
                                      c->crec.as<int32_t>(), scal + 4);
                 HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                       hipMemcpyDeviceToDevice, sm));
@@ -2625,6 +2709,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                         done = true;
                     } else {                                        // not region-local after all: redo in order
                         chain_gave_up |= 1u << m;                  // and do not try again in later sweeps
+                        if (NP > 0)                                 // chains of big regions keep their rows in global memory
+                            HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
                         HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                               hipMemcpyDeviceToDevice, sm));
                     }
@@ -2658,13 +2744,36 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             q.warn_count = scal + 0;
             q.err = scal + 2;
             q.beg = 0; q.end = P;
+            // a flat pass (no rule for the state) of a small cluster can run on one wave64
+            const bool flat_state = h.hierarchy_rules_nil || r1 == r0;
+            bool flat_chain = c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && c->flat_chain_ok && k <= 4 &&
+                              P >= c->chain_min_parts;
+            c->no_fast_keys = false;
+            if (flat_chain) {
+                HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+                BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
+                                     c->order.as<int32_t>(), c->state_stick.as<int32_t>(),
+                                     c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
+                                     c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(), 1,
+                                     c->crec.as<int32_t>(), scal + 4);
+                int32_t bad = 0;
+                HIPTRY(hipMemcpyAsync(&bad, scal + 4, sizeof bad, hipMemcpyDeviceToHost, sm));
+                HIPTRY(hipStreamSynchronize(sm));
+                launches++;
+                if (bad) flat_chain = false;       // some step does not fit the compact record
+            }
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
             int e;
             c->pass_kind.resize(n_pass + 1);
-            if (c->engine != BLANCE_ENGINE_SEQUENTIAL && (h.hierarchy_rules_nil || r1 == r0) && k == 1 &&
-                P >= c->chain_min_parts) {
+            if (c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && k == 1 && P >= c->chain_min_parts) {
                 c->pass_kind[n_pass] = 1;
-                e = run_flat_pass(c, q, scal, &launches, &batched);
+                e = run_flat_pass(c, q, scal, &launches, &batched, flat_chain);
+            } else if (flat_chain) {
+                c->pass_kind[n_pass] = 0;
+                const size_t rows = sizeof(int32_t) * (size_t)(NX + 1) * (NX + 1);
+                e = run_flat_chain(c, q, 0, P, NP > 0 && rows <= 100 * 1024, scal, &launches);
+                if (e > 0) e = fail(BLANCE_ERR_DEVICE, "flat chain refused a checked pass");
+                if (!e) batched += P;
             } else {
                 c->pass_kind[n_pass] = 0;
                 e = dispatch_pass(c, q);

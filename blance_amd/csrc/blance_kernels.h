@@ -71,6 +71,9 @@ struct ChainParams {
     int32_t s, k, NP, OW;
     int32_t booster_kind;
     int32_t n_regions, ntn_in_lds;
+    int32_t flat;                  // the whole cluster is ONE region and every node its own exclude class:
+                                   // a state pass without hierarchy rules (leaf index = node id); a chain that
+                                   // cannot go on stops, keeps what it did and reports the step in flags[4]
     const int32_t* reg_lo;         // [n_regions] leaf interval of the region
     const int32_t* reg_hi;
     const int32_t* reg_off;        // [n_regions + 1] step range of the region in chain order
@@ -85,7 +88,8 @@ struct ChainParams {
     const int32_t* crec;           // [P * kCW] compact step records in chain order
     int32_t* out;                  // [P * OW]
     int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape,
-                                   // [2] steps committed as verified stays, [3] stay batches
+                                   // [2] steps committed as verified stays, [3] stay batches,
+                                   // [4] flat mode: first step not done, [5] stopped by the key range
 };
 
 // Flat (no hierarchy rule) passes resolved in bulk: DESIGN.md "Flat bulk engine".
