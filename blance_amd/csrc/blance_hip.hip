@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -807,7 +808,12 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const int w0 = recbuf[b * kCW + 1];
             const int tcv = rp[6];
             const int tcsz = cszL[tcv < 0 ? 0 : tcv];       // leaves covered by the top node's exclude class
-            const bool blank = active && (rp[5] & 0xffffff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
+            // no own node, no lower priority node; higher priority nodes are just masked out
+            const bool blank = active && (rp[5] & 0xff00ff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
+            int hv[kChainHigh];
+#pragma unroll
+            for (int j = 0; j < kChainHigh; j++) hv[j] = rp[kCHigh + j];
+            const bool any_high = __ballot(blank && (rp[5] & 0xff00) != 0) != 0;
             const unsigned long long nm = __ballot(!blank);
             int run = nm ? __ffsll((long long)nm) - 1 : 64;
             if (run > nb - b) run = nb - b;
@@ -822,6 +828,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 const unsigned bump = (unsigned)(2 * w0) << 13;
                 bool esc = false;
                 int r = 0;
+                // two instances of the loop: the common one carries no code for higher priority nodes
+                auto walk = [&](auto with_high) {
                 for (; r < run; r++) {
                     int acls = __builtin_amdgcn_readlane(tcv, r), acsz = __builtin_amdgcn_readlane(tcsz, r);
                     int ec[KM];
@@ -829,6 +837,14 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     for (int j = 0; j < KM; j++) ec[j] = -2;
                     int covered = 0;
                     unsigned excl_m = 0;
+                    if (decltype(with_high)::value) {   // plan.go:146-154
+#pragma unroll
+                        for (int j = 0; j < kChainHigh; j++) {
+                            const int hj = __builtin_amdgcn_readlane(hv[j], r);
+#pragma unroll
+                            for (int u = 0; u < NPTC; u++) excl_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+                        }
+                    }
                     int chosen[KM];
 #pragma unroll
                     for (int j = 0; j < KM; j++) chosen[j] = -1;
@@ -892,6 +908,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     }
                     if (__ballot(range_bad)) { r++; break; }
                 }
+                };
+                if (any_high) walk(std::true_type{}); else walk(std::false_type{});
                 // refresh the mirrors and the partition-independent scores of my leaves
 #pragma unroll
                 for (int u = 0; u < NPTC; u++) {
