@@ -1811,7 +1811,7 @@ __global__ void k_region_offsets(int B, int n_chunks, int P, const int32_t* offs
 // Step records in pass order: what findBestNodes needs to know about its partition.
 __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
                          const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
-                         const int32_t* node_leaf_pos, const AnchorSet* rule_anchors, int32_t* rec) {
+                         int32_t* rec) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
     if (oi >= d.P) return;
     int p = order[oi];
@@ -1824,22 +1824,12 @@ __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32
     }
     r[0] = p; r[1] = w;
     r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
-    {
-        int idxT = p * d.M + top_state;
-        int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
-        r[4] = top >= 0 ? node_leaf_pos[top] : -1;
-        r[5] = (top >= 0 && rule_anchors) ? rule_anchors[top].blo : 0;
-        r[6] = (top >= 0 && rule_anchors) ? rule_anchors[top].bhi : 0;
-    }
     for (int t = 0; t < d.M; t++) {
         int idx = p * d.M + t;
         int32_t* rs = r + kRecHead + t * (1 + d.L);
         int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
         rs[0] = len | ((int)d.live_kind[idx] << 16);
         for (int i = 0; i < d.L; i++) rs[1 + i] = i < len ? d.live[(size_t)idx * d.L + i] : -1;
-        if (t == m)                                    // leaf positions of this state's nodes (chain stay test)
-            for (int i = 0; i < d.L; i++)
-                r[kRecHead + d.M * (1 + d.L) + i] = i < len ? node_leaf_pos[d.live[(size_t)idx * d.L + i]] : -1;
     }
 }
 
@@ -2095,7 +2085,7 @@ extern "C" int blance_validate(const blance_problem* pb) {
         if (a > L) L = a;
         if (b > L) L = b;
     }
-    if (kRecHead + M * (1 + L) + L > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
+    if (kRecHead + M * (1 + L) > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
     if ((int64_t)(NX + 1) * (N > 0 ? N : 1) * 4 > (int64_t)64 << 30) return fail(BLANCE_ERR_UNSUPPORTED, "nodeToNodeCounts matrix > 64 GiB");
     return BLANCE_OK;
 }
@@ -2302,7 +2292,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
             }
         }
     }
-    const int RW = kRecHead + M * (1 + L) + L;   // header, per-state lists, leaf positions of this state's nodes
+    const int RW = kRecHead + M * (1 + L);       // header + per-state lists
     int kmax = 1;
     for (int m = 0; m < M; m++) if (pb->state_constraints[m] > kmax) kmax = pb->state_constraints[m];
     RESERVE(live, sizeof(int32_t) * (size_t)(PM * L + 1));
@@ -2583,7 +2573,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     const blance_problem& h = c->h;
     const int N = h.n_nodes, NX = h.n_nodes_ext, M = h.n_states, P = h.n_parts, L = c->L;
     const int64_t PM = (int64_t)P * M;
-    const int RW = kRecHead + M * (1 + L) + L;   // header, per-state lists, leaf positions of this state's nodes
+    const int RW = kRecHead + M * (1 + L);       // header + per-state lists
     hipStream_t sm = c->stream;
     int32_t* scal = c->scalars.as<int32_t>();
     int64_t launches = 0, steps = 0, batched = 0;
@@ -2679,9 +2669,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                               (const uint8_t*)nullptr, (const int32_t*)nullptr, c->order.as<int32_t>(), nbc, B, nbits,
                               c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>());
                 BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->chain_order.as<int32_t>(),
-                                     c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
-                                     c->node_leaf_pos.as<int32_t>(),
-                                     c->anchors.as<AnchorSet>() + (size_t)r0 * (NX + 1), c->rec.as<int32_t>());
+                                     c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
                 BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
                                      c->chain_order.as<int32_t>(), c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
@@ -2736,8 +2724,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             }
             if (!done) {
             BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->order.as<int32_t>(),
-                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(),
-                                 c->node_leaf_pos.as<int32_t>(), (const AnchorSet*)nullptr, c->rec.as<int32_t>());
+                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
             PassParams q;
             memset(&q, 0, sizeof q);
             q.N = N; q.NX = NX; q.M = M; q.L = L; q.P = P; q.s = m; q.k = k; q.top_state = h.top_state;

@@ -10,9 +10,7 @@ constexpr int kListAbsent = 0, kListNil = 1, kListSet = 2;   // include/blance_h
 constexpr int kMaxK = 8;         // largest supported Constraints per state
 constexpr int kMaxAnchors = 9;   // hierarchy anchors per fold: 1 + (#rules of a state) * k <= 9
 constexpr int kMaxStates = 16;
-constexpr int kRecHead = 7;      // step-record header words: partition, weight, stickiness (fp64),
-                                 // leaf position of the top priority node (-1 if none) and, for a
-                                 // region-chain pass, the exclude interval of that node under the rule
+constexpr int kRecHead = 4;      // step-record header words: partition, weight, stickiness (fp64)
 constexpr int kLpTab = 512;      // chain kernel LDS tables: c / NP for c < kLpTab ...
 constexpr int kFfTab = 2048;     // ... and (0.001 * t) / NP for t < kFfTab
 
@@ -39,7 +37,6 @@ struct PassParams {
     const int32_t* node_weight;    // [NX]
     const uint8_t* node_has_weight;
     const int32_t* node_leaf_pos;  // [NX]
-    const int32_t* rule_inc_unused;
     const AnchorSet* anchors;      // [n_rules][NX + 1]
     int32_t* cnt;                  // [(M + 1) * NX] stateNodeCounts
     int32_t* ntn;                  // [(NX + 1) * N] nodeToNodeCounts, zeroed per pass
