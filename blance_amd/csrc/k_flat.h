@@ -1,0 +1,354 @@
+// Flat bulk engine: certain-stay runs, fresh-identical runs (threshold search + stable radix sort).
+// Part of blance_hip.hip (one translation unit); see DESIGN.md section 4.
+#pragma once
+
+namespace blance {
+
+// ============================================================================
+// Flat bulk engine: passes of a state without hierarchy rules.  Two kinds of
+// steps are resolved without walking them one by one, both exactly:
+//
+//  * certain stays (k = 1): the partition keeps its node if even the largest
+//    score it could have (nodeToNodeCounts term bounded from above) beats the
+//    smallest partition-independent score of every other candidate, which is a
+//    lower bound of that candidate's true score (the skipped terms are >= 0
+//    and IEEE add / divide / subtract are monotone).  Stays change no counter,
+//    so a whole run of them is validated by independent threads.
+//  * fresh identical partitions (k = 1): partitions without nodes, exclusions
+//    or own rows all see the same candidate scores; each node's score grows
+//    with every pick it receives, so the greedy's picks are the R smallest
+//    elements of the merged per-node score sequences, in sorted order
+//    ((score, position) ascending).  A threshold search finds how many picks
+//    each node gets, a stable radix sort orders them.
+//
+// Everything else goes through k_pass_seq on a sub-range of the pass.
+// ============================================================================
+
+__device__ __forceinline__ unsigned long long sortable_key(double v) {
+    if (v == 0.0) v = 0.0;                         // -0.0 and +0.0 compare equal
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// tot[n], g[n] and the kTopList smallest (g, n) over nodesNext.  One workgroup.
+__global__ __launch_bounds__(1024) void k_flat_prepare(FlatParams q, int32_t* tot, double* g, double* top_g,
+                                                       int32_t* top_n) {
+    BLANCE_DYN_LDS(lds);
+    RedSlot* red = (RedSlot*)lds;
+    int round = 0;
+    const int tid = threadIdx.x;
+    for (int n = tid; n < q.NX; n += 1024) {
+        int tsum = 0;
+        for (int t = 0; t <= q.M; t++) tsum += q.cnt[t * q.NX + n];
+        tot[n] = tsum;
+        g[n] = node_score(q.cnt[q.s * q.NX + n], 0, tsum, q.node_has_weight[n], q.node_weight[n], q.NP, 0.0,
+                          q.booster_kind);
+    }
+    __syncthreads();
+    double last_s = 0.0;
+    int last_n = -1;
+    for (int r = 0; r < kTopList; r++) {
+        double bs = pos_inf();
+        int bn = INT_MAX;
+        for (int n = tid; n < q.N; n += 1024) {
+            if (!q.alive[n]) continue;
+            double v = g[n];
+            if (r > 0 && !better(last_s, last_n, v, n)) continue;     // already listed
+            if (better(v, n, bs, bn)) { bs = v; bn = n; }
+        }
+        int best = block_argmin<1024>(bs, bn, red, round);
+        if (best == INT_MAX) {
+            if (tid == 0) { top_g[r] = pos_inf(); top_n[r] = INT_MAX; }
+            last_s = pos_inf(); last_n = INT_MAX;
+        } else {
+            last_s = g[best]; last_n = best;
+            if (tid == 0) { top_g[r] = last_s; top_n[r] = best; }
+        }
+    }
+}
+
+// steps of the pass per nodeToNodeCounts row: an upper bound of any entry of that row
+__global__ void k_flat_row_count(FlatParams q, int32_t* row_count) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= q.P) oi = -1;
+    const int32_t* r = q.rec + (size_t)(oi < 0 ? 0 : oi) * q.RW;
+    int hdr = r[kRecHead + q.top_state * (1 + q.L)];
+    int top = ((hdr >> 16) != kListAbsent && (hdr & 0xffff) > 0) ? r[kRecHead + q.top_state * (1 + q.L) + 1] : -1;
+    if (oi >= 0 && top >= 0) atomicAdd(&row_count[top], 1);
+    unsigned long long none = __ballot(oi >= 0 && top < 0);    // the "" row: one atomic per wave
+    if (none && (int)(threadIdx.x & 63) == __ffsll((long long)none) - 1) atomicAdd(&row_count[q.NX], __popcll(none));
+}
+
+// Classify the steps [beg, end): record the first one that is not a certain
+// stay and the first one that is not "fresh identical" to step beg.
+__global__ void k_flat_scan(FlatParams q, int beg, int end) {
+    int oi = beg + blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= end) return;
+    const int SW = 1 + q.L;
+    const int32_t* r = q.rec + (size_t)oi * q.RW;
+    const int w = r[1];
+    const double stick = __hiloint2double(r[3], r[2]);
+    int hT = r[kRecHead + q.top_state * SW];
+    int top = ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) ? r[kRecHead + q.top_state * SW + 1] : -1;
+    int hs = r[kRecHead + q.s * SW];
+    int own_len = (hs >> 16) == kListAbsent ? 0 : (hs & 0xffff);
+    int all_len = 0;                                   // nodes the partition holds in any state
+    for (int t = 0; t < q.M; t++) {
+        int h = r[kRecHead + t * SW];
+        if ((h >> 16) != kListAbsent) all_len += h & 0xffff;
+    }
+    // ---- fresh identical to step beg?
+    {
+        const int32_t* r0 = q.rec + (size_t)beg * q.RW;
+        // no node anywhere: nothing to exclude, demote or promote (plan.go:290-297)
+        bool fresh = q.k == 1 && all_len == 0 && w > 0 && w == r0[1] && top < 0;
+        if (!fresh) atomicMin(&q.scan[1], oi);
+    }
+    // ---- certain stay?
+    bool stay = false;
+    if (q.k == 1 && own_len == 1) {
+        int o = r[kRecHead + q.s * SW + 1];
+        bool ok = o < q.N && q.alive[o];
+        for (int t = 0; t < q.M && ok; t++) {           // o in another list of the partition: promoted / excluded
+            if (t == q.s) continue;
+            int h = r[kRecHead + t * SW];
+            if ((h >> 16) == kListAbsent) continue;
+            for (int j = 0; j < (h & 0xffff); j++) if (r[kRecHead + t * SW + 1 + j] == o) ok = false;
+        }
+        if (ok) {
+            int ub = q.NP > 0 ? q.row_count[top < 0 ? q.NX : top] : 0;
+            double s_hi = node_score(q.cnt[q.s * q.NX + o], ub, q.tot[o], q.node_has_weight[o], q.node_weight[o],
+                                     q.NP, stick, q.booster_kind);
+            // smallest other candidate: first listed node that is neither o nor excluded
+            bool found = false;
+            for (int e = 0; e < kTopList && !found; e++) {
+                int n = q.top_n[e];
+                if (n == INT_MAX) { found = true; stay = true; break; }        // no other candidate at all
+                bool excl = n == o;
+                for (int t = 0; t < q.M && !excl; t++) {
+                    int h = r[kRecHead + t * SW];
+                    if ((h >> 16) == kListAbsent || !((q.higher_mask >> t) & 1)) continue;
+                    for (int j = 0; j < (h & 0xffff); j++) if (r[kRecHead + t * SW + 1 + j] == n) excl = true;
+                }
+                if (excl) continue;
+                found = true;
+                stay = better(s_hi, o, q.top_g[e], n);
+            }
+        }
+    }
+    if (!stay) atomicMin(&q.scan[0], oi);
+}
+
+// commit a run of certain stays: the lists do not change; nodeToNodeCounts does (plan.go:238-245)
+__global__ void k_flat_commit_stay(FlatParams q, int beg, int end) {
+    int oi = beg + blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= end) return;
+    const int SW = 1 + q.L;
+    const int32_t* r = q.rec + (size_t)oi * q.RW;
+    int o = r[kRecHead + q.s * SW + 1];
+    int* out = q.out + (size_t)oi * q.OW;
+    out[0] = 1;
+    out[1] = o;
+    if (q.NP > 0) {
+        int hT = r[kRecHead + q.top_state * SW];
+        int top = ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) ? r[kRecHead + q.top_state * SW + 1] : -1;
+        atomicAdd(&q.ntn[(size_t)(top < 0 ? q.NX : top) * q.N + o], 1);
+    }
+}
+
+// ---- fresh identical run: how many of the R picks each node receives --------
+__device__ __forceinline__ unsigned long long fresh_key(const FlatParams& q, int n, int cnt0, int tot0, int ntn0,
+                                                        int w, int c) {
+    return sortable_key(node_score(cnt0 + c * w, ntn0 + c, tot0 + c * w, q.node_has_weight[n], q.node_weight[n],
+                                   q.NP, 0.0, q.booster_kind));
+}
+
+// #{c in [0, R): key(n, c) <= tau}; the keys grow with c
+__device__ __forceinline__ int fresh_count_le(const FlatParams& q, int n, int cnt0, int tot0, int ntn0, int w, int R,
+                                              unsigned long long tau) {
+    int lo = 0, hi = R;                              // first c in [0, R] with key > tau
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        if (fresh_key(q, n, cnt0, tot0, ntn0, w, mid) <= tau) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg, int R, int32_t* m_out,
+                                                          int32_t* m_off) {
+    BLANCE_DYN_LDS(lds);
+    long long* part = (long long*)lds;               // [1024] partial sums, then [1024] scan scratch
+    const int tid = threadIdx.x;
+    const int w = q.rec[(size_t)beg * q.RW + 1];
+    unsigned long long lo = 0, hi = ~0ull;           // smallest tau with total(tau) >= R
+    while (lo < hi) {
+        unsigned long long mid = lo + (hi - lo) / 2;
+        long long sum = 0;
+        for (int n = tid; n < q.N; n += 1024) {
+            if (!q.alive[n]) continue;
+            int ntn0 = q.NP > 0 ? q.ntn[(size_t)q.NX * q.N + n] : 0;
+            sum += fresh_count_le(q, n, q.cnt[q.s * q.NX + n], q.tot[n], ntn0, w, R, mid);
+        }
+        part[tid] = sum;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) part[tid] += part[tid + off];
+            __syncthreads();
+        }
+        long long total = part[0];
+        __syncthreads();
+        if (total >= R) hi = mid; else lo = mid + 1;
+    }
+    const unsigned long long tau = lo;
+    // picks strictly below tau, then the ties at tau in node order
+    const int per = (q.N + 1023) / 1024;
+    const int nb = tid * per, ne = nb + per < q.N ? nb + per : q.N;
+    long long below = 0, ties = 0;
+    for (int n = nb; n < ne; n++) {
+        int lt = 0, le = 0;
+        if (q.alive[n]) {
+            int ntn0 = q.NP > 0 ? q.ntn[(size_t)q.NX * q.N + n] : 0;
+            int c0 = q.cnt[q.s * q.NX + n], t0 = q.tot[n];
+            lt = tau == 0 ? 0 : fresh_count_le(q, n, c0, t0, ntn0, w, R, tau - 1);
+            le = fresh_count_le(q, n, c0, t0, ntn0, w, R, tau);
+        }
+        m_out[n] = lt;
+        m_off[n] = le - lt;                          // ties of node n, consumed below
+        below += lt;
+        ties += le - lt;
+    }
+    // exclusive scans over threads (contiguous node slices keep node order)
+    long long* sb = part;
+    long long* st = part + 1024;
+    sb[tid] = below; st[tid] = ties;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        long long a = tid >= off ? sb[tid - off] : 0, b = tid >= off ? st[tid - off] : 0;
+        __syncthreads();
+        sb[tid] += a; st[tid] += b;
+        __syncthreads();
+    }
+    long long total_below = sb[1023];
+    long long rem = (long long)R - total_below;      // ties to hand out, in node order
+    long long ties_before = st[tid] - ties;
+    long long elems_before = sb[tid] - below;        // picks below tau of earlier nodes
+    for (int n = nb; n < ne; n++) {
+        long long avail = m_off[n];
+        long long left = rem - ties_before;
+        long long take = left <= 0 ? 0 : (avail < left ? avail : left);
+        int m = m_out[n] + (int)take;
+        ties_before += avail;
+        m_out[n] = m;
+    }
+    __syncthreads();
+    // element offsets: exclusive scan of the final counts
+    long long mine = 0;
+    for (int n = nb; n < ne; n++) mine += m_out[n];
+    sb[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        long long a = tid >= off ? sb[tid - off] : 0;
+        __syncthreads();
+        sb[tid] += a;
+        __syncthreads();
+    }
+    long long acc = sb[tid] - mine;
+    for (int n = nb; n < ne; n++) { m_off[n] = (int)acc; acc += m_out[n]; }
+    if (tid == 1023) m_off[q.N] = (int)sb[1023];
+    (void)elems_before;
+}
+
+// the R picked (score, node) elements in node-major order
+__global__ void k_fresh_emit(FlatParams q, int beg, int R, const int32_t* m_off, unsigned long long* keys,
+                             int32_t* vals) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R) return;
+    int lo = 0, hi = q.N;                            // last n with m_off[n] <= e
+    while (hi - lo > 1) {
+        int mid = (lo + hi) / 2;
+        if (m_off[mid] <= e) lo = mid; else hi = mid;
+    }
+    int n = lo, c = e - m_off[n];
+    int w = q.rec[(size_t)beg * q.RW + 1];
+    int ntn0 = q.NP > 0 ? q.ntn[(size_t)q.NX * q.N + n] : 0;
+    keys[e] = fresh_key(q, n, q.cnt[q.s * q.NX + n], q.tot[n], ntn0, w, c);
+    vals[e] = n;
+}
+
+__global__ void k_fresh_commit_steps(FlatParams q, int beg, int R, const int32_t* sorted_nodes) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    int* out = q.out + (size_t)(beg + j) * q.OW;
+    out[0] = 1;
+    out[1] = sorted_nodes[j];
+}
+
+__global__ void k_fresh_commit_nodes(FlatParams q, int beg, const int32_t* m, int32_t* cnt) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= q.N) return;
+    int w = q.rec[(size_t)beg * q.RW + 1];
+    if (m[n] == 0) return;
+    cnt[q.s * q.NX + n] += m[n] * w;                 // plan.go:299-301
+    if (q.NP > 0) q.ntn[(size_t)q.NX * q.N + n] += m[n];
+}
+
+// ---- stable LSD radix sort of (64-bit key, 32-bit value) pairs, 8 bits per pass.
+// One wave64 per tile of kSortTile elements; ranks inside a wave come from ballots.
+constexpr int kSortTile = 2048;
+
+__device__ __forceinline__ unsigned long long same_digit_lanes(int digit, bool valid) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        unsigned long long m = __ballot((digit >> b) & 1);
+        peers &= ((digit >> b) & 1) ? m : ~m;
+    }
+    return peers;
+}
+
+__global__ __launch_bounds__(64) void k_sort_hist(int n, int shift, const unsigned long long* keys, int n_tiles,
+                                                  int32_t* hist /* [256][n_tiles] */) {
+    BLANCE_DYN_LDS(lds);
+    int* cnt = (int*)lds;                            // [256]
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int i = lane; i < 256; i += 64) cnt[i] = 0;
+    __syncthreads();
+    int beg = tile * kSortTile, end = beg + kSortTile < n ? beg + kSortTile : n;
+    for (int base = beg; base < end; base += 64) {
+        int i = base + lane;
+        bool valid = i < end;
+        int digit = valid ? (int)((keys[i] >> shift) & 0xff) : 0;
+        unsigned long long peers = same_digit_lanes(digit, valid);
+        if (valid && (peers & ((1ull << lane) - 1)) == 0) cnt[digit] += __popcll(peers);   // lowest peer adds
+        __syncthreads();
+    }
+    for (int i = lane; i < 256; i += 64) hist[(size_t)i * n_tiles + tile] = cnt[i];
+}
+
+__global__ __launch_bounds__(64) void k_sort_scatter(int n, int shift, const unsigned long long* keys_in,
+                                                     const int32_t* vals_in, unsigned long long* keys_out,
+                                                     int32_t* vals_out, int n_tiles, const int32_t* offsets) {
+    BLANCE_DYN_LDS(lds);
+    int* pos = (int*)lds;                            // [256] next output slot per digit
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int i = lane; i < 256; i += 64) pos[i] = offsets[(size_t)i * n_tiles + tile];
+    __syncthreads();
+    int beg = tile * kSortTile, end = beg + kSortTile < n ? beg + kSortTile : n;
+    for (int base = beg; base < end; base += 64) {
+        int i = base + lane;
+        bool valid = i < end;
+        unsigned long long key = valid ? keys_in[i] : 0;
+        int digit = valid ? (int)((key >> shift) & 0xff) : 0;
+        unsigned long long peers = same_digit_lanes(digit, valid);
+        unsigned long long lower = peers & ((1ull << lane) - 1);
+        int dst = 0;
+        if (valid) dst = pos[digit] + __popcll(lower);
+        __syncthreads();
+        if (valid && lower == 0) pos[digit] += __popcll(peers);
+        __syncthreads();
+        if (valid) { keys_out[dst] = key; vals_out[dst] = vals_in[i]; }
+    }
+}
+
+
+}  // namespace blance

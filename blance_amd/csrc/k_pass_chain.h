@@ -1,0 +1,708 @@
+// k_pass_chain: region chains (one wave64 per hierarchy region), verified-stay speculation, integer-key mode.
+// Part of blance_hip.hip (one translation unit); see DESIGN.md section 4.
+#pragma once
+
+namespace blance {
+
+// ============================================================================
+// Region chains.  When the state's hierarchy rule cuts the cluster into regions
+// (every node's include set is the same leaf interval as its neighbours'), a
+// step whose top priority node and current nodes all live in one region reads
+// and writes only that region's counters.  Steps of different regions commute,
+// so each region's steps run as an independent in-order chain on one wave64:
+// lanes own the region's leaves, the region's slice of nodeToNodeCounts sits
+// in LDS, and the argmin is a DPP reduction -- no barrier, no global traffic
+// on the critical path.  A chain that would have to look outside its region
+// (fallback to candidateNodes[0], unmet constraints) raises flags[1] and the
+// host redoes the whole pass with k_pass_seq.
+// ============================================================================
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void argmin_stage(double& s, int& n) {
+    int lo2 = dpp_mov<CTRL>(__double2loint(s));
+    int hi2 = dpp_mov<CTRL>(__double2hiint(s));
+    int n2 = dpp_mov<CTRL>(n);
+    double s2 = __hiloint2double(hi2, lo2);
+    if (better(s2, n2, s, n)) { s = s2; n = n2; }
+}
+
+// (score, position) argmin over one wave64; result is wave-uniform.
+__device__ __forceinline__ int wave_argmin(double s, int n) {
+    argmin_stage<0xB1>(s, n);     // quad_perm [1,0,3,2]
+    argmin_stage<0x4E>(s, n);     // quad_perm [2,3,0,1]
+    argmin_stage<0x141>(s, n);    // row_half_mirror
+    argmin_stage<0x140>(s, n);    // row_mirror: every row of 16 now agrees
+    double bs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 0),
+                                 __builtin_amdgcn_readlane(__double2loint(s), 0));
+    int bn = __builtin_amdgcn_readlane(n, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        double s2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), r),
+                                     __builtin_amdgcn_readlane(__double2loint(s), r));
+        int n2 = __builtin_amdgcn_readlane(n, r);
+        if (better(s2, n2, bs, bn)) { bs = s2; bn = n2; }
+    }
+    return bn;
+}
+
+#ifdef BLANCE_PHASE_PROF     // developer build only: per-phase shader-clock totals of chain 0
+#define PH_DECL unsigned long long ph_acc[12] = {0}, ph_t0 = clock64(), ph_t1
+#define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
+#define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
+    printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
+#elif defined(BLANCE_ASM_MARKS)   // developer build only: phase markers as comments in the ISA
+#define PH_DECL
+#define PH(i) asm volatile("; PHASE_MARK " #i)
+#define PH_DUMP(steps)
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_DUMP(steps)
+#endif
+
+// nodeSorter.Score with the two quotients that do not depend on the node taken
+// from LDS tables filled by the same expressions (bit-identical by construction).
+__device__ __forceinline__ double chain_score(int cnt, int ntn, int tot, int hasw, int w, int NP, double cf,
+                                              int booster, const double* lp_tab, const double* ff_tab) {
+    double lp = 0.0, ff = 0.0;
+    if (NP > 0) {
+        bool lin = (unsigned)ntn < (unsigned)kLpTab, fin = (unsigned)tot < (unsigned)kFfTab;
+        lp = lp_tab[lin ? ntn : 0];
+        ff = ff_tab[fin ? tot : 0];
+        if (!lin) lp = (double)ntn / (double)NP;
+        if (!fin) ff = (0.001 * (double)tot) / (double)NP;
+    }
+    double r = (double)cnt;
+    r = r + lp;
+    r = r + ff;
+    if (hasw) {
+        if (w > 0) {
+            r = r / (double)w;
+        } else if (w < 0 && booster == BLANCE_BOOSTER_CBGT) {
+            double b = (double)(-w);
+            if (b < cf) b = cf;
+            r = r + b;
+        }
+    }
+    r = r - cf;
+    return r;
+}
+
+// 32-bit minimum over one wave64 (wave-uniform result)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    unsigned t;
+    t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x141>((int)v); v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x140>((int)v); v = t < v ? t : v;
+    unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    r0 = r1 < r0 ? r1 : r0;
+    r2 = r3 < r2 ? r3 : r2;
+    return r2 < r0 ? r2 : r0;
+}
+
+// FAST = the pass has NP == 0 and no node weights: nodeSorter.Score is then
+// double(count) - currentFactor with currentFactor in {1.5, integers}, so
+// 2 * score is an exact small integer and (score, position) packs into one
+// 32-bit key: [ 2*count - 2*currentFactor + 2^17 | node id (13 bits) ].  Lanes
+// whose counters leave the representable range make the chain escape.
+constexpr int kKeyBias = 1 << 17;
+constexpr unsigned kKeyNone = 0xffffffffu;
+
+template <int NPTC, int KM, bool FAST>
+__global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
+    BLANCE_DYN_LDS(lds);
+    if (q.flags[0]) return;
+    const int lane = threadIdx.x;
+    const int rg = blockIdx.x;
+    const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
+    const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
+    if (cbeg >= cend) return;
+    const int N = q.N, NX = q.NX, M = q.M, NP = q.NP, s = q.s, k = q.k;
+    // LDS: quotient tables, mirrors of the per-leaf registers (read by the stay
+    // validators), a 64-step staging area for records and outputs (no global memory
+    // operation inside the step loop), the region's nodeToNodeCounts rows
+    double* lp_tab = (double*)lds;                   // [kLpTab]
+    double* ff_tab = lp_tab + kLpTab;                // [kFfTab]
+    double* gL = ff_tab + kFfTab;                    // [size]
+    int* cntL = (int*)(gL + size);                   // [size]
+    int* totL = cntL + size;
+    int* nidL = totL + size;
+    int* wgtL = nidL + size;
+    int* flgL = wgtL + size;                         // bit 0 alive (in nodesNext), bit 1 has weight
+    int* clsL = flgL + size;                         // exclude class of the leaf's node, -1 if none
+    int* cszL = clsL + size;                         // leaves covered by class c
+    int* recbuf = cszL + size;                       // [64][kCW]
+    int* outbuf = recbuf + 64 * kCW;                 // [64][OW]
+    int* ntn_l = outbuf + 64 * q.OW;                 // [size][ST] nodeToNodeCounts rows, padded stride
+    const int ST = size + 1;
+    if (!FAST && NP > 0) {
+        for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = (double)i / (double)NP;
+        for (int i = lane; i < kFfTab; i += 64) ff_tab[i] = (0.001 * (double)i) / (double)NP;
+        if (q.ntn_in_lds)
+            for (int i = lane; i < (size + 1) * ST; i += 64) ntn_l[i] = 0;    // last row: "" (flat mode)
+    }
+    for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
+    __syncthreads();
+
+    // lane l owns leaves lo + l + 64 u
+    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], cls[NPTC];
+    unsigned alive_m = 0, hasw_m = 0;
+    double g[NPTC];
+    bool range_bad = false;
+#pragma unroll
+    for (int u = 0; u < NPTC; u++) {
+        const int pos = lo + lane + 64 * u;
+        nid[u] = -2; cntv[u] = 0; totv[u] = 0; wv[u] = 0; cls[u] = -1; g[u] = 0.0;
+        if (pos < hi) {
+            int n = q.leaf_node[pos];
+            if (n >= 0) {
+                nid[u] = n;
+                cntv[u] = q.cnt[s * NX + n];
+                int tsum = 0;
+                for (int t = 0; t <= M; t++) tsum += q.cnt[t * NX + n];
+                totv[u] = tsum;
+                wv[u] = q.node_weight[n];
+                if (q.node_has_weight[n]) hasw_m |= 1u << u;
+                if (n < N && q.alive[n]) alive_m |= 1u << u;
+                g[u] = chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind, lp_tab, ff_tab);
+                cls[u] = q.leaf_cls[pos];
+                if (FAST && (cntv[u] >= (1 << 15) || cntv[u] <= -(1 << 15))) range_bad = true;
+            }
+            const int i = lane + 64 * u;
+            gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u]; nidL[i] = nid[u]; wgtL[i] = wv[u];
+            flgL[i] = ((alive_m >> u) & 1) | (((hasw_m >> u) & 1) << 1);
+            clsL[i] = cls[u];
+        }
+    }
+    bool escaped = __ballot(range_bad) != 0;
+    int stop_at = cbeg;                            // flat mode: first step this launch did not do
+    bool stop_range = escaped;
+    // stay speculation: tried again whenever the last general step turned out to be a stay
+    const bool spec_ok = q.ntn_in_lds || NP == 0;
+    bool try_spec = true, gmin_dirty = true;
+    double gmin_s = 0.0;
+    int gmin_n = INT_MAX;
+    int spec_steps = 0, spec_batches = 0;          // statistics (lane 0)
+    PH_DECL;
+
+    for (int base = cbeg; base < cend && !escaped; base += 64) {
+      const int nb = cend - base < 64 ? cend - base : 64;
+      PH(0);
+      for (int i = lane; i < nb * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
+      __syncthreads();
+      int b = 0;
+      while (b < nb) {
+        // ---- Speculate that the next (up to 64) steps keep their nodes.  A stay
+        // changes no counter, so under that hypothesis every step sees the state as
+        // it is now and lane a can check step b + a on its own: the partition's
+        // nodes, scored exactly (stickiness, nodeToNodeCounts row), must beat a lower
+        // bound of every other candidate -- the smallest partition-independent score
+        // of the region (the terms it leaves out are >= 0 and IEEE add / divide /
+        // subtract are monotone).  The verified prefix is committed; the first step
+        // that is not a certain stay takes the general step below.
+        if (spec_ok && try_spec) {
+            if (gmin_dirty) {                      // smallest (g, node) over the region's live leaves
+                double ms = pos_inf();
+                int mn = INT_MAX;
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    const bool ok = (alive_m >> u) & 1;
+                    const bool take = ok && better(g[u], nid[u], ms, mn);
+                    ms = take ? g[u] : ms;
+                    mn = take ? nid[u] : mn;
+                }
+                gmin_n = wave_argmin(ms, mn);
+                gmin_s = pos_inf();
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    unsigned long long bm = __ballot(nid[u] == gmin_n);
+                    if (bm) {
+                        int wl = __ffsll((long long)bm) - 1;
+                        gmin_s = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(g[u]), wl),
+                                                  __builtin_amdgcn_readlane(__double2loint(g[u]), wl));
+                    }
+                }
+                gmin_dirty = false;
+            }
+            const int a = lane;
+            const int sb = b + a;
+            const bool active = sb < nb;
+            const int* rp = recbuf + (active ? sb : b) * kCW;
+            bool fail = false;
+            const double vstick = __hiloint2double(rp[3], rp[2]);
+            const int vtl = rp[4];
+            const int cn = rp[5];
+            if (!((cn >> 24) & 1) || (cn & 0xff) != k) fail = true;      // must hold exactly k nodes
+            int oi[KM], oc[KM + 1];
+            int on[KM];
+            double so[KM];
+            oc[0] = rp[6];
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                on[j] = -3; so[j] = 0.0; oi[j] = 0; oc[j + 1] = -1;
+                if (j < k) {
+                    int li = rp[kCOwn + j];
+                    if (li < 0 || li >= size) { fail = true; li = 0; }
+                    oi[j] = li;
+                    on[j] = nidL[li];
+                    oc[j + 1] = clsL[li];
+                }
+            }
+            // anchors top, own_0 .. own_{k-2}: their exclude classes must leave candidates,
+            // and own_j must not sit in a class excluded before its slot
+            {
+                int cov = 0;
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < k) {
+                        if (oc[j] < 0 && !(q.flat && j == 0)) fail = true;
+                        bool dup = false;
+#pragma unroll
+                        for (int e = 0; e < KM; e++) if (e < j && oc[e] == oc[j]) dup = true;
+                        if (!dup && oc[j] >= 0) cov += cszL[oc[j]];
+                        if (cov >= size) fail = true;
+#pragma unroll
+                        for (int e = 0; e < KM; e++) if (e <= j && oc[e] >= 0 && oc[e] == oc[j + 1]) fail = true;
+                    }
+                }
+            }
+            // the partition's own nodes: candidates, in list order, below the bound
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                if (j < k) {
+                    const int li = oi[j];
+                    if (!(flgL[li] & 1)) fail = true;
+                    const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
+                    so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
+                                        q.booster_kind, lp_tab, ff_tab);
+                    if (j > 0 && !better(so[j - 1], on[j - 1], so[j], on[j])) fail = true;
+                    if (!better(so[j], on[j], gmin_s, gmin_n)) fail = true;
+                }
+            }
+            // an own node also listed in a higher priority state is no candidate (the
+            // record keeps such leaves under "higher"; gather refuses nodes held twice)
+            // an earlier step of the batch with the same top priority node would have bumped my row
+            if (NP > 0) {
+                for (int e = 0; e < 64; e++) {
+                    const int t2 = __builtin_amdgcn_readlane(vtl, e);
+                    if (e < a && t2 == vtl) fail = true;
+                }
+            }
+            if (!active) fail = false;
+            const unsigned long long fm = __ballot(fail);
+            int nok = fm ? __ffsll((long long)fm) - 1 : 64;
+            if (nok > nb - b) nok = nb - b;
+            if (a < nok) {
+                int* op = outbuf + sb * q.OW;
+                op[0] = k;
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < k) {
+                        op[1 + j] = on[j];
+                        if (!FAST && NP > 0) ntn_l[vtl * ST + oi[j]] += 1;      // plan.go:238-245
+                    }
+                }
+            }
+            BLANCE_WAVE_SYNC();
+            if (lane == 0) { spec_steps += nok; spec_batches++; }
+            b += nok;
+            if (b >= nb) break;
+            if (nok == 64) continue;
+        }
+        // ---- FAST mode, runs of blank steps (a partition that holds no node in any
+        // state, apart from higher priority nodes already inside the top node's exclude
+        // class): nothing to match, demote or un-count, so a step is k masked minima over
+        // the packed keys plus two counter bumps.  Lane a pre-scans step b + a; the run
+        // is walked with everything in registers.
+        if (FAST) {
+            const int sb = b + lane;
+            const bool active = sb < nb;
+            const int* rp = recbuf + (active ? sb : b) * kCW;
+            const int w0 = recbuf[b * kCW + 1];
+            const int tcv = rp[6];
+            const int tcsz = cszL[tcv < 0 ? 0 : tcv];       // leaves covered by the top node's exclude class
+            // no own node, no lower priority node; higher priority nodes are just masked out
+            const bool blank = active && (rp[5] & 0xff00ff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
+            int hv[kChainHigh];
+#pragma unroll
+            for (int j = 0; j < kChainHigh; j++) hv[j] = rp[kCHigh + j];
+            const bool any_high = __ballot(blank && (rp[5] & 0xff00) != 0) != 0;
+            const unsigned long long nm = __ballot(!blank);
+            int run = nm ? __ffsll((long long)nm) - 1 : 64;
+            if (run > nb - b) run = nb - b;
+            if (run > 0 && w0 > 0 && w0 < (1 << 14)) {
+                unsigned key[NPTC];
+                int mycsz[NPTC];
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    key[u] = ((alive_m >> u) & 1) ? (((unsigned)(2 * cntv[u] + kKeyBias) << 13) | (unsigned)nid[u]) : kKeyNone;
+                    mycsz[u] = cszL[cls[u] < 0 ? 0 : cls[u]];
+                }
+                const unsigned bump = (unsigned)(2 * w0) << 13;
+                bool esc = false;
+                int r = 0;
+                // two instances of the loop: the common one carries no code for higher priority nodes
+                auto walk = [&](auto with_high) {
+                for (; r < run; r++) {
+                    int acls = __builtin_amdgcn_readlane(tcv, r), acsz = __builtin_amdgcn_readlane(tcsz, r);
+                    int ec[KM];
+#pragma unroll
+                    for (int j = 0; j < KM; j++) ec[j] = -2;
+                    int covered = 0;
+                    unsigned excl_m = 0;
+                    if (decltype(with_high)::value) {   // plan.go:146-154
+#pragma unroll
+                        for (int j = 0; j < kChainHigh; j++) {
+                            const int hj = __builtin_amdgcn_readlane(hv[j], r);
+#pragma unroll
+                            for (int u = 0; u < NPTC; u++) excl_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+                        }
+                    }
+                    int chosen[KM];
+#pragma unroll
+                    for (int j = 0; j < KM; j++) chosen[j] = -1;
+                    unsigned picked_m = 0;
+#pragma unroll
+                    for (int slot = 0; slot < KM; slot++) {
+                        if (slot < k) {
+                            bool dup = false;
+#pragma unroll
+                            for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
+                            if (acls < 0 && !(q.flat && slot == 0)) esc = true;
+                            if (!dup && acls >= 0) {
+                                ec[slot] = acls;
+                                covered += acsz;
+#pragma unroll
+                                for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
+                            }
+                            if (covered >= size) esc = true;
+                            unsigned km = kKeyNone;
+#pragma unroll
+                            for (int u = 0; u < NPTC; u++) {
+                                const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
+                                km = kv < km ? kv : km;
+                            }
+                            const unsigned kb = wave_min_u32(km);
+                            if (kb == kKeyNone) esc = true;
+                            int wcls = -1, wcsz = 0;
+#pragma unroll
+                            for (int u = 0; u < NPTC; u++) {
+                                const bool mine = key[u] == kb && kb != kKeyNone;
+                                unsigned long long bm = __ballot(mine);
+                                if (bm) {
+                                    const int wl = __ffsll((long long)bm) - 1;
+                                    wcls = __builtin_amdgcn_readlane(cls[u], wl);
+                                    wcsz = __builtin_amdgcn_readlane(mycsz[u], wl);
+                                }
+                                picked_m |= (mine ? 1u : 0u) << u;
+                            }
+                            // a duplicate pick is impossible: the winner's own class is excluded next,
+                            // unless it has none (wcls < 0 -> escape)
+                            chosen[slot] = (int)(kb & 0x1fff);
+                            acls = wcls;
+                            acsz = wcsz;
+                        }
+                    }
+                    if (__ballot(esc)) break;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) {
+                        if ((picked_m >> u) & 1) {
+                            key[u] += bump;
+                            cntv[u] += w0;
+                            totv[u] += w0;
+                            if (cntv[u] >= (1 << 15)) range_bad = true;
+                        }
+                    }
+                    if (lane == 0) {
+                        int* o = outbuf + (b + r) * q.OW;
+                        o[0] = k;
+#pragma unroll
+                        for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
+                    }
+                    if (__ballot(range_bad)) { r++; break; }
+                }
+                };
+                if (any_high) walk(std::true_type{}); else walk(std::false_type{});
+                // refresh the mirrors and the partition-independent scores of my leaves
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    const int i = lane + 64 * u;
+                    if (i < size) {
+                        g[u] = (double)cntv[u];
+                        gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u];
+                    }
+                }
+                BLANCE_WAVE_SYNC();
+                gmin_dirty = true;
+                if (r > 0) try_spec = false;          // the run's steps were moves
+                b += r;
+                if (__ballot(range_bad)) { escaped = true; stop_range = true; break; }
+                if (b >= nb) break;
+                if (r > 0 && !__ballot(esc)) continue;
+                // an escape inside the run: let the general step decide (it escapes the same way)
+            }
+        }
+        // ---- general step: findBestNodes (plan.go:98-248) + commit (plan.go:290-301)
+        PH(1);
+        const int recw = lane < kCW ? recbuf[b * kCW + lane] : 0;
+#define REC(i) __builtin_amdgcn_readlane(recw, (i))
+        const int w = REC(1);
+        const double stick = __hiloint2double(REC(3), REC(2));
+        const int tl = REC(4);
+        const int cn = REC(5);
+        const int n_low = (cn >> 16) & 0xff;
+        bool esc = false;
+        int ntnv[NPTC];
+#pragma unroll
+        for (int u = 0; u < NPTC; u++) {
+            ntnv[u] = 0;
+            if (!FAST && NP > 0) {
+                if (q.ntn_in_lds) { if (lane + 64 * u < size) ntnv[u] = ntn_l[tl * ST + lane + 64 * u]; }
+                else if (nid[u] >= 0 && nid[u] < N) ntnv[u] = q.ntn[(size_t)(tl < size ? nidL[tl] : NX) * N + nid[u]];
+            }
+        }
+        PH(2);
+        unsigned inh_m = 0, own_m = 0;
+        if (cn & 0xff) {
+#pragma unroll
+            for (int j = 0; j < kChainOwn; j++) {
+                const int oj = REC(kCOwn + j);
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) own_m |= (oj == lane + 64 * u ? 1u : 0u) << u;
+            }
+        }
+        if (cn & 0xff00) {
+#pragma unroll
+            for (int j = 0; j < kChainHigh; j++) {
+                const int hj = REC(kCHigh + j);
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) inh_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+            }
+        }
+        PH(3);
+        const unsigned elig_m = alive_m & ~inh_m;
+        double sc[NPTC];
+        unsigned key[NPTC];
+        if (FAST) {
+            // 2 * stickiness: 3 or an even integer; out of range -> let the sequential pass do it
+            const double s2 = stick + stick;
+            const int stick2 = (s2 >= 0.0 && s2 < 32768.0) ? (int)s2 : 0;
+            if (!(s2 >= 0.0 && s2 < 32768.0) || (double)stick2 != s2) esc = true;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                const int v = 2 * cntv[u] - (((own_m >> u) & 1) ? stick2 : 0) + kKeyBias;
+                key[u] = ((elig_m >> u) & 1) ? (((unsigned)v << 13) | (unsigned)nid[u]) : kKeyNone;
+                sc[u] = 0.0;
+            }
+        } else {
+            unsigned need_m = own_m;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) { if (ntnv[u] != 0) need_m |= 1u << u; key[u] = 0; }
+            if (__ballot(need_m != 0)) {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    double full = chain_score(cntv[u], ntnv[u], totv[u], (hasw_m >> u) & 1, wv[u], NP,
+                                              ((own_m >> u) & 1) ? stick : 0.0, q.booster_kind, lp_tab, ff_tab);
+                    sc[u] = ((need_m >> u) & 1) ? full : g[u];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) sc[u] = g[u];
+            }
+        }
+        PH(4);
+        // The rule's k picks (plan.go:177-223).  Every anchor's include set is this
+        // region, so the running set is the region minus the anchors' exclude classes;
+        // an empty running set (plan.go:746 would reset it), an anchor without a
+        // proper class, a fallback to candidateNodes[0] or a duplicate pick escape.
+        int ec[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) ec[j] = -2;
+        int covered = 0;
+        unsigned excl_m = 0;
+        int chosen[KM], chosen_l[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) { chosen[j] = -1; chosen_l[j] = -1; }
+        int n_out = 0;
+        int acls = REC(6);                           // exclude class of the current anchor
+        PH(5);
+#pragma unroll
+        for (int slot = 0; slot < KM; slot++) {
+            if (slot < k) {
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
+                if (acls < 0 && !(q.flat && slot == 0)) esc = true;
+                if (!dup && acls >= 0) {
+                    ec[slot] = acls;
+                    covered += cszL[acls];
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
+                }
+                if (covered >= size) esc = true;
+                int best;
+                if (FAST) {
+                    unsigned km = kKeyNone;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) {
+                        const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
+                        km = kv < km ? kv : km;
+                    }
+                    PH(6);
+                    const unsigned kb = wave_min_u32(km);
+                    best = kb == kKeyNone ? INT_MAX : (int)(kb & 0x1fff);
+                } else {
+                    double bs = pos_inf();
+                    int bn = INT_MAX;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) {
+                        const bool ok = ((elig_m & ~excl_m) >> u) & 1;
+                        const bool take = ok && better(sc[u], nid[u], bs, bn);
+                        bs = take ? sc[u] : bs;
+                        bn = take ? nid[u] : bn;
+                    }
+                    PH(6);
+                    best = wave_argmin(bs, bn);
+                }
+                PH(7);
+                if (best == INT_MAX) esc = true;
+                int wcls = -1, wloc = -1;
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    unsigned long long bm = __ballot(nid[u] == best);
+                    if (bm) {
+                        int wl = __ffsll((long long)bm) - 1;
+                        wcls = __builtin_amdgcn_readlane(cls[u], wl);
+                        wloc = wl + 64 * u;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < KM; c++) if (c < slot && chosen[c] == best) esc = true;   // duplicate pick
+                chosen[slot] = best;
+                chosen_l[slot] = wloc;
+                n_out = slot + 1;
+                acls = wcls;
+                PH(8);
+            }
+        }
+        if (__ballot(esc)) { escaped = true; break; }
+
+        // ---- commit: the owner lane of a leaf updates it
+        int dc[NPTC], dt[NPTC];
+#pragma unroll
+        for (int u = 0; u < NPTC; u++) { dc[u] = 0; dt[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < NPTC; u++) {             // old nodes of this state leave it (plan.go:290-293)
+            const int d = ((own_m >> u) & 1) ? w : 0;
+            dc[u] -= d; dt[u] -= d;
+        }
+#pragma unroll
+        for (int c = 0; c < KM; c++) {               // chosen nodes enter it (plan.go:299-301)
+            if (c < k) {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    const bool mine = chosen_l[c] == lane + 64 * u;
+                    dc[u] += mine ? w : 0;
+                    dt[u] += mine ? w : 0;
+                    if (!FAST && NP > 0 && mine) {
+                        if (q.ntn_in_lds) ntn_l[tl * ST + lane + 64 * u] = ntnv[u] + 1;      // plan.go:238-245
+                        else q.ntn[(size_t)(tl < size ? nidL[tl] : NX) * N + nid[u]] = ntnv[u] + 1;
+                    }
+                }
+            }
+        }
+        if (n_low > 0) {                             // a chosen node leaves its lower priority state (plan.go:294-297)
+            for (int e = 0; e < kChainLow; e++) {
+                const int le = REC(kCLow + e), lt = REC(kCLowState + e);
+                if (le < 0) continue;
+#pragma unroll
+                for (int c = 0; c < KM; c++) {
+                    if (c < k && chosen_l[c] == le) {
+#pragma unroll
+                        for (int u = 0; u < NPTC; u++) dt[u] -= le == lane + 64 * u ? w : 0;
+                        if (lane == 0) q.cnt[lt * NX + chosen[c]] -= w;
+                    }
+                }
+            }
+        }
+        PH(9);
+        {
+            unsigned changed_m = 0;
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                cntv[u] += dc[u];
+                totv[u] += dt[u];
+                if (dc[u] | dt[u]) changed_m |= 1u << u;
+                if (FAST && (cntv[u] >= (1 << 15) || cntv[u] <= -(1 << 15))) range_bad = true;
+            }
+            if (__ballot(changed_m != 0)) {
+#pragma unroll
+                for (int u = 0; u < NPTC; u++) {
+                    double gn = FAST ? (double)cntv[u]       // no quotients, no weights: plan.go:664-670 only
+                                     : chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0,
+                                                   q.booster_kind, lp_tab, ff_tab);
+                    g[u] = ((changed_m >> u) & 1) ? gn : g[u];
+                    if ((changed_m >> u) & 1) {
+                        const int i = lane + 64 * u;
+                        gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u];
+                    }
+                }
+            }
+        }
+        PH(10);
+        {
+            // did this step keep its nodes?  then the next ones probably do, too
+            bool same = ((cn >> 24) & 1) && (cn & 0xff) == n_out;
+            if (same) {
+#pragma unroll
+                for (int c = 0; c < KM; c++) if (c < n_out && REC(kCOwn + c) != chosen_l[c]) same = false;
+            }
+            try_spec = same;
+            gmin_dirty = true;
+        }
+        if (lane == 0) {
+            int* o = outbuf + b * q.OW;
+            o[0] = n_out;
+#pragma unroll
+            for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
+        }
+        PH(11);
+#undef REC
+        BLANCE_WAVE_SYNC();
+        b++;
+        if (__ballot(range_bad)) { escaped = true; stop_range = true; break; }
+      }
+      __syncthreads();
+      stop_at = base + b;
+      // flat mode keeps the steps done before a stop; a region chain's pass is redone as a whole
+      const int n_done = (!escaped || q.flat) ? b : 0;
+      for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
+    }
+    PH_DUMP(cend - cbeg);
+    if (lane == 0 && spec_batches) { atomicAdd(&q.flags[2], spec_steps); atomicAdd(&q.flags[3], spec_batches); }
+    if (escaped) {
+        if (lane == 0) { q.flags[1] = 1; q.flags[4] = stop_at; q.flags[5] = stop_range ? 1 : 0; }
+        if (!q.flat) return;
+        // the rest of the pass continues from global memory: hand over the LDS rows
+        if (!FAST && NP > 0 && q.ntn_in_lds) {
+            __syncthreads();
+            for (int i = lane; i < (size + 1) * size; i += 64) {
+                const int row = i / size, col = i - row * size;
+                const int cn = nidL[col];
+                if (cn >= 0 && cn < N) q.ntn[(size_t)(row < size ? nidL[row] : NX) * N + cn] = ntn_l[row * ST + col];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NPTC; u++)
+        if (nid[u] >= 0) q.cnt[s * NX + nid[u]] = cntv[u];
+}
+
+
+}  // namespace blance

@@ -1,0 +1,295 @@
+// k_pass_seq: the exact sequential state pass (always applicable).
+// Part of blance_hip.hip (one translation unit); see DESIGN.md section 4.
+#pragma once
+
+namespace blance {
+
+// ============================================================================
+// The sequential state pass: assignStateToPartitions (plan.go:253-303) with
+// findBestNodes (plan.go:98-248) inlined.  ONE workgroup walks the partitions
+// in pass order; thread t owns nodes t, t+T, ... and keeps their load counts,
+// total counts, weights and partition-independent scores in registers, so a
+// step costs one barrier per argmin and no table traffic.
+// ============================================================================
+template <int T, int NPT>
+__global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
+    BLANCE_DYN_LDS(lds);
+    RedSlot* red = (RedSlot*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k;
+    const int SW = 1 + L;                        // words per state inside a record
+    int round = 0;
+
+    int cntv[NPT], totv[NPT], wv[NPT], lpos[NPT];
+    unsigned alive_m = 0, hasw_m = 0;
+    double g[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        int n = tid + i * T;
+        cntv[i] = 0; totv[i] = 0; wv[i] = 0; lpos[i] = -1; g[i] = 0.0;
+        if (n < NX) {
+            cntv[i] = q.cnt[s * NX + n];
+            int tsum = 0;
+            for (int t = 0; t <= M; t++) tsum += q.cnt[t * NX + n];   // plan.go:118-124
+            totv[i] = tsum;
+            wv[i] = q.node_weight[n];
+            if (q.node_has_weight[n]) hasw_m |= 1u << i;
+            if (n < N && q.alive[n]) alive_m |= 1u << i;
+            lpos[i] = q.node_leaf_pos[n];
+            g[i] = node_score(cntv[i], 0, totv[i], (hasw_m >> i) & 1, wv[i], NP, 0.0, q.booster_kind);
+        }
+    }
+
+    // step record of the current partition: lane j of every wave holds word j
+    int recw = 0, recw_next = 0;
+    if (q.beg < q.end && lane < q.RW) recw_next = q.rec[(size_t)q.beg * q.RW + lane];
+
+    for (int oi = q.beg; oi < q.end; oi++) {
+        recw = recw_next;
+        if (oi + 1 < q.end && lane < q.RW) recw_next = q.rec[(size_t)(oi + 1) * q.RW + lane];
+#define REC(i) __builtin_amdgcn_readlane(recw, (i))
+        const int p = REC(0);
+        const int w = REC(1);
+        const double stick = __hiloint2double(REC(3), REC(2));
+        // topPriorityNode, plan.go:134-138
+        int top = -1;
+        {
+            int hdr = REC(kRecHead + q.top_state * SW);
+            if ((hdr >> 16) != kListAbsent && (hdr & 0xffff) > 0) top = REC(kRecHead + q.top_state * SW + 1);
+        }
+        const int row = top < 0 ? NX : top;
+
+        // nodeToNodeCounts row of the top priority node (only read when NP > 0, plan.go:638)
+        int ntnv[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            int n = tid + i * T;
+            ntnv[i] = (NP > 0 && n < N) ? q.ntn[(size_t)row * N + n] : 0;
+        }
+
+        // membership of my nodes in the higher-priority lists (plan.go:146-154)
+        // and in this state's current list (plan.go:654-662)
+        unsigned inh_m = 0, own_m = 0;
+        int any_higher_key = 0;
+        for (int t = 0; t < M; t++) {
+            int hdr = REC(kRecHead + t * SW);
+            if ((hdr >> 16) == kListAbsent) continue;
+            int len = hdr & 0xffff;
+            bool higher = (q.higher_mask >> t) & 1;
+            if (higher) any_higher_key = 1;
+            if (!higher && t != s) continue;
+            for (int j = 0; j < len; j++) {
+                int x = REC(kRecHead + t * SW + 1 + j);
+#pragma unroll
+                for (int i = 0; i < NPT; i++) {
+                    if (x == tid + i * T) {
+                        if (higher) inh_m |= 1u << i;
+                        if (t == s) own_m |= 1u << i;
+                    }
+                }
+            }
+        }
+        const unsigned elig_m = alive_m & ~inh_m;
+
+        double sc[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            bool own = (own_m >> i) & 1;
+            if (own || ntnv[i] != 0)
+                sc[i] = node_score(cntv[i], ntnv[i], totv[i], (hasw_m >> i) & 1, wv[i], NP,
+                                   own ? stick : 0.0, q.booster_kind);
+            else
+                sc[i] = g[i];
+        }
+
+        int chosen[kMaxK];
+#pragma unroll
+        for (int j = 0; j < kMaxK; j++) chosen[j] = -1;
+        int n_out = 0;
+        unsigned emitted_m = 0;                    // my nodes already in the output list
+
+        if (q.hier) {                              // plan.go:174-226
+            int hn[kMaxAnchors];
+#pragma unroll
+            for (int j = 0; j < kMaxAnchors; j++) hn[j] = -1;
+            int n_hn = 0;
+            int cand0 = -2;                        // candidateNodes[0], computed lazily
+            int err = 0;
+            for (int r = q.rule_begin; r < q.rule_end; r++) {
+                const AnchorSet* tab = q.anchors + (size_t)r * (NX + 1);
+                int h = top < 0 ? q.vertex_empty_anchor : top;
+                if (top < 0 && n_hn > 0) h = hn[0];
+                Fold f;
+                fold_reset(f);
+                {
+                    AnchorSet a = tab[h];
+                    a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
+                    fold_step(f, a, &err);
+                }
+#pragma unroll
+                for (int j = 0; j < kMaxAnchors; j++) {
+                    if (j < n_hn) {
+                        AnchorSet a = tab[hn[j]];
+                        a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
+                        fold_step(f, a, &err);
+                    }
+                }
+                for (int i = 0; i < k; i++) {
+                    // best node of the rule's set ∩ nodesNext − higher priority nodes (plan.go:185-212)
+                    double bs = pos_inf();
+                    int bn = INT_MAX;
+#pragma unroll
+                    for (int u = 0; u < NPT; u++) {
+                        if (((elig_m >> u) & 1) && lpos[u] >= 0 && fold_contains(f, lpos[u]) &&
+                            better(sc[u], tid + u * T, bs, bn)) {
+                            bs = sc[u]; bn = tid + u * T;
+                        }
+                    }
+                    int best = uni(block_argmin<T>(bs, bn, red, round));
+                    int pick = -1;
+                    if (best != INT_MAX) {
+                        pick = best;
+                    } else {                        // plan.go:216-218
+                        if (cand0 == -2) {
+                            double cs = pos_inf();
+                            int cn = INT_MAX;
+#pragma unroll
+                            for (int u = 0; u < NPT; u++) {
+                                if (((elig_m >> u) & 1) && better(sc[u], tid + u * T, cs, cn)) {
+                                    cs = sc[u]; cn = tid + u * T;
+                                }
+                            }
+                            cand0 = uni(block_argmin<T>(cs, cn, red, round));
+                            if (cand0 == INT_MAX) cand0 = -1;
+                        }
+                        pick = cand0;
+                    }
+                    if (pick >= 0) {
+                        if (n_hn >= kMaxAnchors - 1) { err = 1; }
+                        else {
+#pragma unroll
+                            for (int j = 0; j < kMaxAnchors; j++) if (j == n_hn) hn[j] = pick;
+                            n_hn++;
+                            AnchorSet a = tab[pick];
+                            a.alo = uni(a.alo); a.ahi = uni(a.ahi); a.blo = uni(a.blo); a.bhi = uni(a.bhi);
+                            fold_step(f, a, &err);
+                        }
+                    }
+                }
+            }
+            if (err && tid == 0) *q.err = 1;
+            // candidateNodes = dedupe(hierarchyNodes ++ candidateNodes), plan.go:224-225
+#pragma unroll
+            for (int j = 0; j < kMaxAnchors; j++) {
+                if (j < n_hn && n_out < k) {
+                    int x = hn[j];
+                    bool dup = false;
+#pragma unroll
+                    for (int c = 0; c < kMaxK; c++) if (c < n_out && chosen[c] == x) dup = true;
+                    if (!dup) {
+#pragma unroll
+                        for (int c = 0; c < kMaxK; c++) if (c == n_out) chosen[c] = x;
+                        n_out++;
+#pragma unroll
+                        for (int u = 0; u < NPT; u++) if (x == tid + u * T) emitted_m |= 1u << u;
+                    }
+                }
+            }
+        }
+        // the sorted candidate list consumed lazily (plan.go:171-172, :228-235)
+        while (n_out < k) {
+            double bs = pos_inf();
+            int bn = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < NPT; u++) {
+                if (((elig_m & ~emitted_m) >> u) & 1) {
+                    if (better(sc[u], tid + u * T, bs, bn)) { bs = sc[u]; bn = tid + u * T; }
+                }
+            }
+            int best = uni(block_argmin<T>(bs, bn, red, round));
+            if (best == INT_MAX) break;
+#pragma unroll
+            for (int c = 0; c < kMaxK; c++) if (c == n_out) chosen[c] = best;
+            n_out++;
+#pragma unroll
+            for (int u = 0; u < NPT; u++) if (best == tid + u * T) emitted_m |= 1u << u;
+        }
+
+        // ---- commit (plan.go:238-245, :290-301); every thread updates the nodes it owns
+        unsigned changed_m = 0;
+        for (int t = 0; t < M; t++) {
+            int hdr = REC(kRecHead + t * SW);
+            if ((hdr >> 16) == kListAbsent) continue;
+            int len = hdr & 0xffff;
+            for (int j = 0; j < len; j++) {
+                int x = REC(kRecHead + t * SW + 1 + j);
+                bool hit = (t == s);
+                if (!hit) {
+                    // x also held this state (plan.go:290-293) or was chosen now (plan.go:294-297)
+                    int hs = REC(kRecHead + s * SW);
+                    if ((hs >> 16) != kListAbsent) {
+                        int ls = hs & 0xffff;
+                        for (int jj = 0; jj < ls; jj++)
+                            if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
+                    }
+#pragma unroll
+                    for (int c = 0; c < kMaxK; c++) if (c < n_out && chosen[c] == x) hit = true;
+                }
+                if (!hit) continue;
+#pragma unroll
+                for (int u = 0; u < NPT; u++) {
+                    if (x == tid + u * T) {
+                        totv[u] -= w;
+                        if (t == s) cntv[u] -= w;
+                        changed_m |= 1u << u;
+                    }
+                }
+                if (t != s && tid == 0) q.cnt[t * NX + x] -= w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxK; c++) {
+            if (c < n_out) {
+                int x = chosen[c];
+#pragma unroll
+                for (int u = 0; u < NPT; u++) {
+                    if (x == tid + u * T) {
+                        cntv[u] += w;
+                        totv[u] += w;
+                        changed_m |= 1u << u;
+                        if (NP > 0) q.ntn[(size_t)row * N + x] = ntnv[u] + 1;   // plan.go:238-245
+                    }
+                }
+            }
+        }
+        if (changed_m) {
+#pragma unroll
+            for (int u = 0; u < NPT; u++)
+                if ((changed_m >> u) & 1)
+                    g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
+        }
+        if (tid == 0) {
+            int is_nil = (n_out == 0 && q.n_alive == 0 && !any_higher_key && !q.hier);
+            int* o = q.out + (size_t)oi * q.OW;
+            o[0] = n_out | (is_nil << 16);
+#pragma unroll
+            for (int c = 0; c < kMaxK; c++) if (c < k) o[1 + c] = chosen[c];
+            if (n_out < k) {                       // plan.go:230-235
+                int wi = *q.warn_count;
+                q.warn_part[wi] = p;
+                q.warn_state[wi] = s;
+                *q.warn_count = wi + 1;
+            }
+        }
+#undef REC
+    }
+
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        int n = tid + i * T;
+        if (n < NX) q.cnt[s * NX + n] = cntv[i];
+    }
+}
+
+
+}  // namespace blance

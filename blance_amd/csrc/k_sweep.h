@@ -1,0 +1,367 @@
+// Data-parallel kernels of a sweep: live lists, counts, categories, stable partitions, records, convergence.
+// Part of blance_hip.hip (one translation unit); see DESIGN.md section 4.
+#pragma once
+
+namespace blance {
+
+// ============================================================================
+// Data-parallel kernels around the pass
+// ============================================================================
+
+struct DevProblem {   // device pointers + sizes shared by the elementwise kernels
+    int32_t N, NX, M, L, P;
+    int32_t weights_nil;
+    const uint8_t* node_removed;   // view of this sweep (all zero after sweep 1)
+    const uint8_t* node_added;
+    const int32_t* part_weight;
+    const uint8_t* part_has_weight;
+    int32_t* live; int32_t* live_len; uint8_t* live_kind;
+    int32_t* prv;  int32_t* prv_len;  uint8_t* prv_kind;
+    uint8_t* in_prev; uint8_t* never_equal;
+};
+
+// nextPartitions = copy of partitionsToAssign minus nodesToRemove (plan.go:83-88)
+__global__ void k_live_init(DevProblem d, const int32_t* a_off, const int32_t* a_nodes,
+                            const uint8_t* a_kind, const int32_t* p_off, const int32_t* p_nodes,
+                            const uint8_t* p_kind) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    int len = 0;
+    for (int i = a_off[idx]; i < a_off[idx + 1]; i++) {
+        int n = a_nodes[i];
+        if (!d.node_removed[n]) d.live[(size_t)idx * d.L + len++] = n;
+    }
+    d.live_len[idx] = len;
+    d.live_kind[idx] = a_kind[idx] == kListAbsent ? kListAbsent : kListSet;
+    len = 0;
+    for (int i = p_off[idx]; i < p_off[idx + 1]; i++) d.prv[(size_t)idx * d.L + len++] = p_nodes[i];
+    d.prv_len[idx] = len;
+    d.prv_kind[idx] = p_kind[idx];
+}
+
+// sweeps >= 2: every present key is a non-nil slice again (plan.go:418)
+__global__ void k_live_refresh(DevProblem d) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    if (d.live_kind[idx] != kListAbsent) d.live_kind[idx] = kListSet;
+}
+
+// countStateNodes (plan.go:374-399): extra loads ...
+__global__ void k_count_loads(int n_loads, int NX, int later_sweep, const int32_t* st, const int32_t* nd,
+                              const int32_t* wt, const uint8_t* first_only, int32_t* cnt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_loads) return;
+    if (later_sweep && first_only[i]) return;
+    atomicAdd(&cnt[st[i] * NX + nd[i]], wt[i]);
+}
+
+// ... and the prevMap view of the partitions being assigned
+__global__ void k_count_prev(DevProblem d, int32_t* cnt) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    int p = idx / d.M, m = idx % d.M;
+    if (!d.in_prev[p]) return;
+    int w = (!d.weights_nil && d.part_has_weight[p]) ? d.part_weight[p] : 1;
+    for (int i = 0; i < d.prv_len[idx]; i++) atomicAdd(&cnt[m * d.NX + d.prv[(size_t)idx * d.L + i]], w);
+}
+
+// partitionSorter category (plan.go:542-561)
+__global__ void k_category(DevProblem d, int m, int any_removed, int add_nil, uint8_t* cat) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.P) return;
+    int cv = 2;
+    bool is0 = false;
+    if (any_removed && d.in_prev[p]) {
+        int idx = p * d.M + m;
+        if (d.prv_kind[idx] == kListSet)
+            for (int i = 0; i < d.prv_len[idx]; i++)
+                if (d.node_removed[d.prv[(size_t)idx * d.L + i]]) { is0 = true; break; }
+    }
+    if (is0) cv = 0;
+    else if (!add_nil) {
+        bool hit = false;
+        for (int t = 0; t < d.M && !hit; t++) {
+            int idx = p * d.M + t;
+            if (d.live_kind[idx] == kListAbsent) continue;
+            for (int i = 0; i < d.live_len[idx]; i++)
+                if (d.node_added[d.live[(size_t)idx * d.L + i]]) { hit = true; break; }
+        }
+        if (!hit) cv = 1;
+    }
+    cat[p] = (uint8_t)cv;
+}
+
+// Stable partition of a sequence by a small key (the per-pass category of
+// partitionSorter, plan.go:519-562; the region of a step): per-chunk bucket
+// counts -> exclusive scan (bucket major) -> stable scatter.  One wave64 per
+// chunk of kPartChunk elements; ranks inside a round of 64 come from ballots.
+constexpr int kPartChunk = 1024;
+
+__device__ __forceinline__ int part_key(const int32_t* key32, const uint8_t* key8, const int32_t* index, int i) {
+    int j = index ? index[i] : i;
+    return key8 ? (int)key8[j] : key32[j];
+}
+
+__global__ __launch_bounds__(64) void k_part_count(int n, const int32_t* key32, const uint8_t* key8,
+                                                   const int32_t* index, int n_chunks, int B,
+                                                   int32_t* counts /* [B][n_chunks] */) {
+    BLANCE_DYN_LDS(lds);
+    int* hist = (int*)lds;                           // [B]
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    for (int i = lane; i < B; i += 64) hist[i] = 0;
+    __syncthreads();
+    int beg = chunk * kPartChunk, end = beg + kPartChunk < n ? beg + kPartChunk : n;
+    for (int base = beg; base < end; base += 64) {
+        int i = base + lane;
+        if (i < end) atomicAdd(&hist[part_key(key32, key8, index, i)], 1);
+    }
+    __syncthreads();
+    for (int i = lane; i < B; i += 64) counts[(size_t)i * n_chunks + chunk] = hist[i];
+}
+
+__global__ __launch_bounds__(64) void k_part_scatter(int n, const int32_t* key32, const uint8_t* key8,
+                                                     const int32_t* index, const int32_t* values, int n_chunks,
+                                                     int B, int nbits, const int32_t* offsets, int32_t* out) {
+    BLANCE_DYN_LDS(lds);
+    int* pos = (int*)lds;                            // [B] next output slot per bucket
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    for (int i = lane; i < B; i += 64) pos[i] = offsets[(size_t)i * n_chunks + chunk];
+    __syncthreads();
+    int beg = chunk * kPartChunk, end = beg + kPartChunk < n ? beg + kPartChunk : n;
+    for (int base = beg; base < end; base += 64) {
+        int i = base + lane;
+        bool valid = i < end;
+        int key = valid ? part_key(key32, key8, index, i) : 0;
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < nbits; bit++) {
+            unsigned long long m = __ballot((key >> bit) & 1);
+            peers &= ((key >> bit) & 1) ? m : ~m;
+        }
+        unsigned long long lower = peers & ((1ull << lane) - 1);
+        int dst = valid ? pos[key] + __popcll(lower) : 0;
+        __syncthreads();
+        if (valid && lower == 0) pos[key] += __popcll(peers);
+        __syncthreads();
+        if (valid) out[dst] = values[i];
+    }
+}
+
+// Region of every step of the pass, or flags[0] if some step is not region-local:
+// its top priority node and the nodes it currently holds in this state must sit
+// in one region (their counters are then owned by that region's chain).
+__global__ void k_chain_classify(DevProblem d, int m, int top_state, const int32_t* order,
+                                 const int32_t* node_region, int32_t* regid, int32_t* flags) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    int idxT = p * d.M + top_state;
+    int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
+    int rg = top >= 0 ? node_region[top] : -1;
+    if (rg >= 0) {
+        int idx = p * d.M + m;
+        if (d.live_kind[idx] != kListAbsent)
+            for (int i = 0; i < d.live_len[idx]; i++)
+                if (node_region[d.live[(size_t)idx * d.L + i]] != rg) rg = -1;
+    }
+    if (rg < 0) { flags[0] = 1; rg = 0; }
+    regid[oi] = rg;
+}
+
+// Compact chain records (layout: blance_kernels.h): the step's nodes as leaf
+// indices local to its region.  Steps the chain kernel cannot represent raise flags[0].
+__global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
+                               const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
+                               const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
+                               const int32_t* leaf_cls, int flat, int32_t* crec, int32_t* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.P) return;
+    int p = chain_order[i];
+    int32_t* r = crec + (size_t)i * kCW;
+    for (int j = 0; j < kCW; j++) r[j] = -1;
+    int w = 1;
+    double stick = 1.5;
+    if (!d.weights_nil) {
+        if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
+        else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
+    }
+    r[0] = p; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    int idxT = p * d.M + top_state;
+    int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
+    int rg = flat ? 0 : (top >= 0 ? node_region[top] : -1);
+    if (rg < 0) { flags[0] = 1; r[4] = 0; r[5] = 0; r[6] = -1; return; }
+    const int lo = reg_lo[rg];
+    if (flat) {
+        r[4] = top >= 0 ? top : d.NX;              // the "" row when there is no top priority node
+        r[6] = -1;                                 // no anchor: nothing is excluded in the first slot
+    } else {
+        r[4] = node_leaf_pos[top] - lo;
+        r[6] = leaf_cls[node_leaf_pos[top]];
+    }
+    bool bad = false;
+    int own_nodes[kChainOwn];
+    int n_own = 0, n_h = 0, n_low = 0, present = 0;
+    int idx = p * d.M + m;
+    if (d.live_kind[idx] != kListAbsent) {
+        present = 1;
+        for (int j = 0; j < d.live_len[idx]; j++) {
+            int x = d.live[(size_t)idx * d.L + j];
+            if (n_own >= kChainOwn || node_region[x] != rg) { bad = true; break; }
+            own_nodes[n_own] = x;
+            r[kCOwn + n_own++] = node_leaf_pos[x] - lo;
+        }
+    }
+    for (int t = 0; t < d.M && !bad; t++) {
+        if (t == m) continue;
+        int ix = p * d.M + t;
+        if (d.live_kind[ix] == kListAbsent) continue;
+        const bool higher = (higher_mask >> t) & 1;
+        for (int j = 0; j < d.live_len[ix]; j++) {
+            int x = d.live[(size_t)ix * d.L + j];
+            for (int e = 0; e < n_own; e++) if (own_nodes[e] == x) bad = true;   // a node held in two states
+            if (node_region[x] != rg) continue;      // never a candidate of this region's chain
+            int loc = node_leaf_pos[x] - lo;
+            if (higher) {
+                // the top priority node's exclude class is excluded in every slot anyway
+                if (r[6] >= 0 && leaf_cls[node_leaf_pos[x]] == r[6]) continue;
+                if (n_h >= kChainHigh) { bad = true; break; }
+                r[kCHigh + n_h++] = loc;
+            } else {
+                if (n_low >= kChainLow) { bad = true; break; }
+                r[kCLow + n_low] = loc;
+                r[kCLowState + n_low++] = t;
+            }
+        }
+    }
+    r[5] = n_own | (n_h << 8) | (n_low << 16) | (present << 24);
+    if (bad) flags[0] = 1;
+}
+
+// exclusive scan of n ints by one workgroup of 1024 threads: tiles of 8192
+// elements, 8 contiguous per thread (coalesced), carry across tiles
+__global__ __launch_bounds__(1024) void k_scan_excl(int n, int32_t* data) {
+    BLANCE_DYN_LDS(lds);
+    int* wsum = (int*)lds;                       // [16] wave totals, [16] carry
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 8192) {
+        int v[8];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int i = base + tid * 8 + j;
+            v[j] = i < n ? data[i] : 0;
+            sum += v[j];
+        }
+        int incl = sum;                          // inclusive scan of the thread sums inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { int x = wsum[w]; if (w < wave) wbase += x; total += x; }
+        int acc = carry + wbase + incl - sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int i = base + tid * 8 + j;
+            if (i < n) data[i] = acc;
+            acc += v[j];
+        }
+        carry += total;
+        __syncthreads();
+    }
+}
+
+__global__ void k_region_offsets(int B, int n_chunks, int P, const int32_t* offsets, int32_t* reg_off) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    reg_off[b] = b == B ? P : offsets[(size_t)b * n_chunks];
+}
+
+// Step records in pass order: what findBestNodes needs to know about its partition.
+__global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
+                         const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
+                         int32_t* rec) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    int32_t* r = rec + (size_t)oi * RW;
+    int w = 1;                                         // plan.go:269-275
+    double stick = 1.5;                                // plan.go:104-115
+    if (!d.weights_nil) {
+        if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
+        else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
+    }
+    r[0] = p; r[1] = w;
+    r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    for (int t = 0; t < d.M; t++) {
+        int idx = p * d.M + t;
+        int32_t* rs = r + kRecHead + t * (1 + d.L);
+        int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
+        rs[0] = len | ((int)d.live_kind[idx] << 16);
+        for (int i = 0; i < d.L; i++) rs[1 + i] = i < len ? d.live[(size_t)idx * d.L + i] : -1;
+    }
+}
+
+// Apply the pass's choices to the live lists (plan.go:290-299); list edits only
+// touch the step's own partition, so this runs in parallel after the pass.
+__global__ void k_scatter(DevProblem d, int m, int RW, int OW, const int32_t* order, const int32_t* rec,
+                          const int32_t* out) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    const int32_t* r = rec + (size_t)oi * RW;
+    const int32_t* o = out + (size_t)oi * OW;
+    int n_out = o[0] & 0xffff, is_nil = o[0] >> 16;
+    const int32_t* old_s = r + kRecHead + m * (1 + d.L);
+    int n_old = (old_s[0] >> 16) == kListAbsent ? 0 : (old_s[0] & 0xffff);
+    for (int t = 0; t < d.M; t++) {
+        int idx = p * d.M + t;
+        if (t == m) continue;
+        if (d.live_kind[idx] == kListAbsent) continue;
+        int len = d.live_len[idx], w = 0;
+        int32_t* lst = d.live + (size_t)idx * d.L;
+        for (int i = 0; i < len; i++) {
+            int x = lst[i];
+            bool rm = false;
+            for (int j = 0; j < n_old; j++) rm |= old_s[1 + j] == x;
+            for (int j = 0; j < n_out; j++) rm |= o[1 + j] == x;
+            if (!rm) lst[w++] = x;
+        }
+        d.live_len[idx] = w;
+        d.live_kind[idx] = kListSet;
+    }
+    int idx = p * d.M + m;
+    for (int j = 0; j < n_out; j++) d.live[(size_t)idx * d.L + j] = o[1 + j];
+    d.live_len[idx] = n_out;
+    d.live_kind[idx] = is_nil ? kListNil : kListSet;
+}
+
+// Convergence test (plan.go:36-45) fused with the write-back prevMap[name] =
+// partitionsToAssign[name] = nextMap[name] (plan.go:49-52).
+__global__ void k_converge(DevProblem d, int32_t* not_match) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.P) return;
+    bool diff = !d.in_prev[p] || d.never_equal[p];
+    for (int m = 0; m < d.M; m++) {
+        int idx = p * d.M + m;
+        int len = d.live_len[idx];
+        if (d.live_kind[idx] != d.prv_kind[idx] || len != d.prv_len[idx]) diff = true;
+        for (int i = 0; i < len; i++) {
+            int x = d.live[(size_t)idx * d.L + i];
+            if (!diff && d.prv[(size_t)idx * d.L + i] != x) diff = true;
+            d.prv[(size_t)idx * d.L + i] = x;
+        }
+        d.prv_len[idx] = len;
+        d.prv_kind[idx] = d.live_kind[idx];
+    }
+    d.in_prev[p] = 1;
+    d.never_equal[p] = 0;
+    if (diff) atomicOr(not_match, 1);
+}
+
+
+}  // namespace blance
