@@ -841,8 +841,34 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 cq.cnt = c->cnt.as<int32_t>(); cq.ntn = c->ntn.as<int32_t>();
                 cq.crec = c->crec.as<int32_t>(); cq.out = c->out.as<int32_t>();
                 cq.flags = scal + 4;
+                cq.cnt_out = cq.cnt;
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
-                bool launched = dispatch_chain(c, cq, rr.max_size);
+                // a fresh plan's first sweep: every step blank -> the lean kernel; it either
+                // does the whole pass or changes nothing that is not restored below
+                bool lean = false;
+                if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4) {
+                    const int nptc = cdiv(rr.max_size, 64);
+                    const size_t lds = sizeof(int32_t) * ((size_t)rr.max_size + 64 * (size_t)(kCW + OW)) + 64;
+                    if (k <= 2) {
+                        if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 2>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
+                        else { auto kern = k_pass_chain_blank<4, 2>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
+                    } else {
+                        if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 4>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
+                        else { auto kern = k_pass_chain_blank<4, 4>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
+                    }
+                    int32_t fl[2] = {0, 0};
+                    HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
+                    HIPTRY(hipStreamSynchronize(sm));
+                    launches++;
+                    if (!fl[0] && !fl[1]) {
+                        lean = true;
+                    } else if (!fl[0]) {                            // not all blank: the full kernel, from the same state
+                        HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
+                                              hipMemcpyDeviceToDevice, sm));
+                        HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
+                    }
+                }
+                bool launched = lean || dispatch_chain(c, cq, rr.max_size);
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
                 launches += 8;
                 if (launched) {

@@ -81,6 +81,7 @@ struct ChainParams {
     const int32_t* node_weight;
     const uint8_t* node_has_weight;
     int32_t* cnt;
+    int32_t* cnt_out;              // k_pass_chain_blank: where the new counters go (committed by the host)
     int32_t* ntn;
     const int32_t* crec;           // [P * kCW] compact step records in chain order
     int32_t* out;                  // [P * OW]

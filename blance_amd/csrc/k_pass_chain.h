@@ -106,6 +106,20 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return r2 < r0 ? r2 : r0;
 }
 
+// the same with the cross-row part done by row broadcasts: one v_readlane at the end
+__device__ __forceinline__ unsigned wave_min_u32_bcast(unsigned v) {
+    unsigned t;
+    t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x141>((int)v); v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x140>((int)v); v = t < v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v = t < v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    v = t < v ? t : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // FAST = the pass has NP == 0 and no node weights: nodeSorter.Score is then
 // double(count) - currentFactor with currentFactor in {1.5, integers}, so
 // 2 * score is an exact small integer and (score, position) packs into one
@@ -113,6 +127,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 // whose counters leave the representable range make the chain escape.
 constexpr int kKeyBias = 1 << 17;
 constexpr unsigned kKeyNone = 0xffffffffu;
+constexpr int kCompactMax = 8000;    // |count| bound of the compact keys of the blank-run loop
 
 template <int NPTC, int KM, bool FAST>
 __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
@@ -179,6 +194,23 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             flgL[i] = ((alive_m >> u) & 1) | (((hasw_m >> u) & 1) << 1);
             clsL[i] = cls[u];
         }
+    }
+    // compact-key loop preconditions: node ids rise with the leaf index, and k exclude
+    // classes can never cover the region (then "empty set -> reset", plan.go:746, cannot occur)
+    bool compact_ok = false;
+    if (FAST) {
+        __syncthreads();
+        int prev = -1, mx = 0;
+        bool mono = true;
+        if (lane == 0) {
+            for (int i = 0; i < size; i++) {
+                const int n = nidL[i];
+                if (n >= 0) { if (n <= prev) mono = false; prev = n; }
+                if (cszL[i] > mx) mx = cszL[i];
+            }
+        }
+        const int mono_u = __builtin_amdgcn_readlane(mono ? 1 : 0, 0), mx_u = __builtin_amdgcn_readlane(mx, 0);
+        compact_ok = mono_u && (long long)mx_u * (k + 1) < (long long)size && size <= 256;
     }
     bool escaped = __ballot(range_bad) != 0;
     int stop_at = cbeg;                            // flat mode: first step this launch did not do
@@ -315,19 +347,21 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             if (b >= nb) break;
             if (nok == 64) continue;
         }
-        // ---- FAST mode, runs of blank steps (a partition that holds no node in any
-        // state, apart from higher priority nodes already inside the top node's exclude
-        // class): nothing to match, demote or un-count, so a step is k masked minima over
-        // the packed keys plus two counter bumps.  Lane a pre-scans step b + a; the run
-        // is walked with everything in registers.
-        if (FAST) {
+        // ---- FAST mode, runs of blank steps (a partition that holds no node of this or
+        // a lower priority state; its higher priority nodes are simply masked): nothing
+        // to match, demote or un-count, so a step is k masked minima plus k counter
+        // bumps.  Lane a pre-scans step b + a; the run is walked with everything in
+        // registers, on compact keys [ 2*count + 2^14 : 15 | leaf : 8 | exclude class : 9 ]
+        // that also carry what the next slot needs to know about the winner.  Needs node
+        // ids rising with the leaf index (ties go to the lower node id, plan.go:617-628),
+        // exclude classes too small to ever empty the candidate set, small counters;
+        // otherwise the general step below does the work.
+        if (FAST && compact_ok) {
             const int sb = b + lane;
             const bool active = sb < nb;
             const int* rp = recbuf + (active ? sb : b) * kCW;
             const int w0 = recbuf[b * kCW + 1];
             const int tcv = rp[6];
-            const int tcsz = cszL[tcv < 0 ? 0 : tcv];       // leaves covered by the top node's exclude class
-            // no own node, no lower priority node; higher priority nodes are just masked out
             const bool blank = active && (rp[5] & 0xff00ff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
             int hv[kChainHigh];
 #pragma unroll
@@ -336,97 +370,78 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const unsigned long long nm = __ballot(!blank);
             int run = nm ? __ffsll((long long)nm) - 1 : 64;
             if (run > nb - b) run = nb - b;
-            if (run > 0 && w0 > 0 && w0 < (1 << 14)) {
+            bool small = true;                     // counters inside the compact key's range?
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) if (cntv[u] <= -kCompactMax || cntv[u] >= kCompactMax) small = false;
+            if (run > 0 && w0 > 0 && w0 < 64 && !__ballot(!small)) {
                 unsigned key[NPTC];
-                int mycsz[NPTC];
 #pragma unroll
                 for (int u = 0; u < NPTC; u++) {
-                    key[u] = ((alive_m >> u) & 1) ? (((unsigned)(2 * cntv[u] + kKeyBias) << 13) | (unsigned)nid[u]) : kKeyNone;
-                    mycsz[u] = cszL[cls[u] < 0 ? 0 : cls[u]];
+                    const unsigned c9 = cls[u] < 0 ? 511u : (unsigned)cls[u];
+                    key[u] = ((alive_m >> u) & 1)
+                                 ? (((unsigned)(2 * cntv[u] + (1 << 14)) << 17) | ((unsigned)(lane + 64 * u) << 9) | c9)
+                                 : kKeyNone;
                 }
-                const unsigned bump = (unsigned)(2 * w0) << 13;
+                const unsigned bump = (unsigned)(2 * w0) << 17;
                 bool esc = false;
                 int r = 0;
                 // two instances of the loop: the common one carries no code for higher priority nodes
                 auto walk = [&](auto with_high) {
-                for (; r < run; r++) {
-                    int acls = __builtin_amdgcn_readlane(tcv, r), acsz = __builtin_amdgcn_readlane(tcsz, r);
-                    int ec[KM];
+                    for (; r < run; r++) {
+                        int acls = __builtin_amdgcn_readlane(tcv, r);
+                        unsigned excl_m = 0;
+                        if (decltype(with_high)::value) {   // plan.go:146-154
 #pragma unroll
-                    for (int j = 0; j < KM; j++) ec[j] = -2;
-                    int covered = 0;
-                    unsigned excl_m = 0;
-                    if (decltype(with_high)::value) {   // plan.go:146-154
+                            for (int j = 0; j < kChainHigh; j++) {
+                                const int hj = __builtin_amdgcn_readlane(hv[j], r);
 #pragma unroll
-                        for (int j = 0; j < kChainHigh; j++) {
-                            const int hj = __builtin_amdgcn_readlane(hv[j], r);
-#pragma unroll
-                            for (int u = 0; u < NPTC; u++) excl_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+                                for (int u = 0; u < NPTC; u++) excl_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+                            }
                         }
-                    }
-                    int chosen[KM];
+                        int chosen_l[KM];
 #pragma unroll
-                    for (int j = 0; j < KM; j++) chosen[j] = -1;
-                    unsigned picked_m = 0;
+                        for (int j = 0; j < KM; j++) chosen_l[j] = 0;
+                        unsigned picked_m = 0;
 #pragma unroll
-                    for (int slot = 0; slot < KM; slot++) {
-                        if (slot < k) {
-                            bool dup = false;
+                        for (int slot = 0; slot < KM; slot++) {
+                            if (slot < k) {
+                                if (acls < 0 && !(q.flat && slot == 0)) esc = true;   // anchor without an exclude class
 #pragma unroll
-                            for (int j = 0; j < KM; j++) if (j < slot && ec[j] == acls) dup = true;
-                            if (acls < 0 && !(q.flat && slot == 0)) esc = true;
-                            if (!dup && acls >= 0) {
-                                ec[slot] = acls;
-                                covered += acsz;
+                                for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls && acls >= 0 ? 1u : 0u) << u;
+                                unsigned km = kKeyNone;
 #pragma unroll
-                                for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
-                            }
-                            if (covered >= size) esc = true;
-                            unsigned km = kKeyNone;
-#pragma unroll
-                            for (int u = 0; u < NPTC; u++) {
-                                const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
-                                km = kv < km ? kv : km;
-                            }
-                            const unsigned kb = wave_min_u32(km);
-                            if (kb == kKeyNone) esc = true;
-                            int wcls = -1, wcsz = 0;
-#pragma unroll
-                            for (int u = 0; u < NPTC; u++) {
-                                const bool mine = key[u] == kb && kb != kKeyNone;
-                                unsigned long long bm = __ballot(mine);
-                                if (bm) {
-                                    const int wl = __ffsll((long long)bm) - 1;
-                                    wcls = __builtin_amdgcn_readlane(cls[u], wl);
-                                    wcsz = __builtin_amdgcn_readlane(mycsz[u], wl);
+                                for (int u = 0; u < NPTC; u++) {
+                                    const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
+                                    km = kv < km ? kv : km;
                                 }
-                                picked_m |= (mine ? 1u : 0u) << u;
+                                const unsigned kb = wave_min_u32_bcast(km);
+                                if (kb == kKeyNone) esc = true;          // would fall back to candidateNodes[0]
+#pragma unroll
+                                for (int u = 0; u < NPTC; u++) picked_m |= (key[u] == kb && kb != kKeyNone ? 1u : 0u) << u;
+                                chosen_l[slot] = (int)((kb >> 9) & 0xff);
+                                const int wc = (int)(kb & 0x1ff);
+                                acls = wc == 511 ? -1 : wc;              // the winner's class is excluded next
                             }
-                            // a duplicate pick is impossible: the winner's own class is excluded next,
-                            // unless it has none (wcls < 0 -> escape)
-                            chosen[slot] = (int)(kb & 0x1fff);
-                            acls = wcls;
-                            acsz = wcsz;
                         }
-                    }
-                    if (__ballot(esc)) break;
+                        if (__ballot(esc)) break;
+                        bool big = false;
 #pragma unroll
-                    for (int u = 0; u < NPTC; u++) {
-                        if ((picked_m >> u) & 1) {
-                            key[u] += bump;
-                            cntv[u] += w0;
-                            totv[u] += w0;
-                            if (cntv[u] >= (1 << 15)) range_bad = true;
+                        for (int u = 0; u < NPTC; u++) {
+                            if ((picked_m >> u) & 1) {
+                                key[u] += bump;
+                                cntv[u] += w0;
+                                totv[u] += w0;
+                                if (cntv[u] >= kCompactMax) big = true;
+                            }
                         }
-                    }
-                    if (lane == 0) {
-                        int* o = outbuf + (b + r) * q.OW;
-                        o[0] = k;
+                        if (lane == 0) {
+                            int* o = outbuf + (b + r) * q.OW;
+                            o[0] = k;
 #pragma unroll
-                        for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
+                            for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = nidL[chosen_l[c]];
+                        }
+                        if (__ballot(big)) { r++; break; }               // leave the compact range: general step next
                     }
-                    if (__ballot(range_bad)) { r++; break; }
-                }
                 };
                 if (any_high) walk(std::true_type{}); else walk(std::false_type{});
                 // refresh the mirrors and the partition-independent scores of my leaves
@@ -436,6 +451,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     if (i < size) {
                         g[u] = (double)cntv[u];
                         gL[i] = g[u]; cntL[i] = cntv[u]; totL[i] = totv[u];
+                        if (cntv[u] >= (1 << 15)) range_bad = true;
                     }
                 }
                 BLANCE_WAVE_SYNC();
@@ -704,5 +720,150 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         if (nid[u] >= 0) q.cnt[s * NX + nid[u]] = cntv[u];
 }
 
+
+// ---------------------------------------------------------------------------
+// k_pass_chain_blank: the chain kernel reduced to the compact-key loop, for passes
+// in which EVERY step is blank (the replica pass of a fresh plan's first sweep:
+// NumPartitions == 0, no node weights, partitions that hold no node of this or a
+// lower priority state).  Few live values, no spills: one dependent step costs k
+// wave minima and little else.  Anything outside its envelope sets flags[1] and
+// changes nothing; the host then runs k_pass_chain from the same state.
+// ---------------------------------------------------------------------------
+template <int NPTC, int KM>
+__global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
+    BLANCE_DYN_LDS(lds);
+    const int lane = threadIdx.x;
+    const int rg = blockIdx.x;
+    const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
+    const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
+    if (cbeg >= cend) return;
+    const int k = q.k;
+    int* nidL = (int*)lds;                           // [size]
+    int* recbuf = nidL + size;                       // [64][kCW]
+    int* outbuf = recbuf + 64 * kCW;                 // [64][OW] leaf indices, turned into node ids at the flush
+    int nid[NPTC], cntv[NPTC], cls[NPTC];
+    unsigned alive_m = 0;
+    bool bad = size > 256 || q.NP != 0;
+    int mx = 0;
+#pragma unroll
+    for (int u = 0; u < NPTC; u++) {
+        const int pos = lo + lane + 64 * u;
+        nid[u] = -2; cntv[u] = 0; cls[u] = -1;
+        if (pos < hi) {
+            const int n = q.leaf_node[pos];
+            if (n >= 0) {
+                nid[u] = n;
+                cntv[u] = q.cnt[q.s * q.NX + n];
+                if (q.node_has_weight[n]) bad = true;
+                if (n < q.N && q.alive[n]) alive_m |= 1u << u;
+                cls[u] = q.leaf_cls[pos];
+                if (cntv[u] <= -kCompactMax || cntv[u] >= kCompactMax) bad = true;
+            }
+            const int cs = q.cls_size[pos];          // sizes are stored per class index at reg_lo + c
+            if (cs > mx) mx = cs;
+            nidL[lane + 64 * u] = nid[u];
+        }
+    }
+    __syncthreads();
+    {   // node ids must rise with the leaf index; k classes must never cover the region
+        int prev = -1;
+        bool mono = true;
+        if (lane == 0)
+            for (int i = 0; i < size; i++) { const int n = nidL[i]; if (n >= 0) { if (n <= prev) mono = false; prev = n; } }
+        if (!__builtin_amdgcn_readlane(mono ? 1 : 0, 0)) bad = true;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { int t = __shfl_xor(mx, off, 64); mx = t > mx ? t : mx; }
+        if ((long long)mx * (k + 1) >= (long long)size) bad = true;
+    }
+    unsigned key[NPTC];
+#pragma unroll
+    for (int u = 0; u < NPTC; u++) {
+        const unsigned c9 = cls[u] < 0 ? 511u : (unsigned)cls[u];
+        key[u] = ((alive_m >> u) & 1) ? (((unsigned)(2 * cntv[u] + (1 << 14)) << 17) | ((unsigned)(lane + 64 * u) << 9) | c9)
+                                      : kKeyNone;
+    }
+    bool failed = __ballot(bad) != 0;
+    for (int base = cbeg; base < cend && !failed; base += 64) {
+        const int nb = cend - base < 64 ? cend - base : 64;
+        for (int i = lane; i < nb * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
+        __syncthreads();
+        const bool active = lane < nb;
+        const int* rp = recbuf + (active ? lane : 0) * kCW;
+        const int w0 = recbuf[1];
+        const int tcv = rp[6];
+        int hv[kChainHigh];
+#pragma unroll
+        for (int j = 0; j < kChainHigh; j++) hv[j] = rp[kCHigh + j];
+        const bool blank = (rp[5] & 0xff00ff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
+        if (__ballot(active && !blank) || w0 <= 0 || w0 >= 64) { failed = true; break; }
+        const bool any_high = __ballot(active && (rp[5] & 0xff00) != 0) != 0;
+        const unsigned bump = (unsigned)(2 * w0) << 17;
+        bool esc = false;
+        for (int r = 0; r < nb; r++) {
+            int acls = __builtin_amdgcn_readlane(tcv, r);
+            unsigned excl_m = 0;
+            if (any_high) {                          // plan.go:146-154
+#pragma unroll
+                for (int j = 0; j < kChainHigh; j++) {
+                    const int hj = __builtin_amdgcn_readlane(hv[j], r);
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) excl_m |= (hj == lane + 64 * u ? 1u : 0u) << u;
+                }
+            }
+            unsigned picked_m = 0;
+            int wl[KM];
+#pragma unroll
+            for (int slot = 0; slot < KM; slot++) {
+                wl[slot] = 0;
+                if (slot < k) {
+                    if (acls < 0 && !(q.flat && slot == 0)) esc = true;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls && acls >= 0 ? 1u : 0u) << u;
+                    unsigned km = kKeyNone;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) {
+                        const unsigned kv = ((excl_m >> u) & 1) ? kKeyNone : key[u];
+                        km = kv < km ? kv : km;
+                    }
+                    const unsigned kb = wave_min_u32_bcast(km);
+                    if (kb == kKeyNone) esc = true;
+#pragma unroll
+                    for (int u = 0; u < NPTC; u++) picked_m |= (key[u] == kb && kb != kKeyNone ? 1u : 0u) << u;
+                    wl[slot] = (int)((kb >> 9) & 0xff);
+                    const int wc = (int)(kb & 0x1ff);
+                    acls = wc == 511 ? -1 : wc;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NPTC; u++) {
+                if ((picked_m >> u) & 1) {
+                    key[u] += bump;
+                    cntv[u] += w0;
+                    if (cntv[u] >= kCompactMax) esc = true;
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < KM; c++) if (c < k) outbuf[r * q.OW + 1 + c] = wl[c];
+            }
+        }
+        if (__ballot(esc)) { failed = true; break; }
+        __syncthreads();
+        for (int i = lane; i < nb * q.OW; i += 64) {
+            const int c = i % q.OW;
+            q.out[(size_t)base * q.OW + i] = c == 0 ? k : nidL[outbuf[i]];
+        }
+        __syncthreads();
+    }
+    if (failed) {
+        if (lane == 0) q.flags[1] = 1;
+        return;
+    }
+    // every region must succeed before any of them may publish its counters: publish to
+    // the scratch copy; the host commits it when no chain failed
+#pragma unroll
+    for (int u = 0; u < NPTC; u++)
+        if (nid[u] >= 0) q.cnt_out[q.s * q.NX + nid[u]] = cntv[u];
+}
 
 }  // namespace blance

@@ -200,13 +200,17 @@ inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)emu::wave_ex
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)emu::wave_exchange((uint32_t)v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 // DPP lane selects used by wave_argmin: quad_perm (ctrl < 0x100), row_half_mirror, row_mirror
-inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool) {
     int l = threadIdx.x & 63, from;
+    bool write = (row_mask >> (l >> 4)) & 1;          // rows not in row_mask keep `old`
     if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
     else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
     else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else if (ctrl == 0x142) { from = (l & ~15) - 1; if (from < 0) { from = l; write = false; } }   // row_bcast:15
+    else if (ctrl == 0x143) { from = 31; if (l < 32) write = false; }                             // row_bcast:31
     else { fprintf(stderr, "emu: dpp ctrl %x not modelled\n", ctrl); abort(); }
-    return (int)(uint32_t)emu::wave_exchange((uint32_t)src, from);
+    int got = (int)(uint32_t)emu::wave_exchange((uint32_t)src, from);
+    return write ? got : old;
 }
 inline unsigned long long __ballot(int pred) {
     if (!emu::t_block) return pred ? 1ull : 0ull;
