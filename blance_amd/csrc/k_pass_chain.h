@@ -106,8 +106,27 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return r2 < r0 ? r2 : r0;
 }
 
-// the same with the cross-row part done by row broadcasts: one v_readlane at the end
+// the same with the cross-row part done by row broadcasts and the minimum taken by the
+// DPP instruction itself: six v_min_u32_dpp and one v_readlane
 __device__ __forceinline__ unsigned wave_min_u32_bcast(unsigned v) {
+#ifndef BLANCE_SIMT_EMU
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#else
     unsigned t;
     t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
     t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
@@ -118,6 +137,7 @@ __device__ __forceinline__ unsigned wave_min_u32_bcast(unsigned v) {
     t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     v = t < v ? t : v;
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#endif
 }
 
 // FAST = the pass has NP == 0 and no node weights: nodeSorter.Score is then
