@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
                 if (q.node_has_weight[n]) bad = true;
                 if (n < q.N && q.alive[n]) alive_m |= 1u << u;
                 cls[u] = q.leaf_cls[pos];
-                if (cntv[u] <= -kCompactMax || cntv[u] >= kCompactMax) bad = true;
+                if (cntv[u] <= -kCompactMax / 2 || cntv[u] >= kCompactMax / 2) bad = true;
             }
             const int cs = q.cls_size[pos];          // sizes are stored per class index at reg_lo + c
             if (cs > mx) mx = cs;
@@ -818,7 +818,13 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
         if (__ballot(active && !blank) || w0 <= 0 || w0 >= 64) { failed = true; break; }
         const bool any_high = __ballot(active && (rp[5] & 0xff00) != 0) != 0;
         const unsigned bump = (unsigned)(2 * w0) << 17;
-        bool esc = false;
+        // failure conditions are accumulated and tested once per batch: a bad step only
+        // produces garbage that is thrown away with the whole launch
+        unsigned none_acc = kKeyNone;                // becomes 0 if some minimum found no candidate
+        int anchor_acc = 0;                          // sign bit set if some anchor had no exclude class
+        int my_w[KM];                                // lane r keeps the picks of step r
+#pragma unroll
+        for (int c = 0; c < KM; c++) my_w[c] = 0;
         for (int r = 0; r < nb; r++) {
             int acls = __builtin_amdgcn_readlane(tcv, r);
             unsigned excl_m = 0;
@@ -836,9 +842,9 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
             for (int slot = 0; slot < KM; slot++) {
                 wl[slot] = 0;
                 if (slot < k) {
-                    if (acls < 0 && !(q.flat && slot == 0)) esc = true;
+                    if (!(q.flat && slot == 0)) anchor_acc |= acls;
 #pragma unroll
-                    for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls && acls >= 0 ? 1u : 0u) << u;
+                    for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;    // (leaves without a class are no candidates)
                     unsigned km = kKeyNone;
 #pragma unroll
                     for (int u = 0; u < NPTC; u++) {
@@ -846,9 +852,9 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
                         km = kv < km ? kv : km;
                     }
                     const unsigned kb = wave_min_u32_bcast(km);
-                    if (kb == kKeyNone) esc = true;
+                    none_acc = ~kb < none_acc ? ~kb : none_acc;
 #pragma unroll
-                    for (int u = 0; u < NPTC; u++) picked_m |= (key[u] == kb && kb != kKeyNone ? 1u : 0u) << u;
+                    for (int u = 0; u < NPTC; u++) picked_m |= (key[u] == kb ? 1u : 0u) << u;
                     wl[slot] = (int)((kb >> 9) & 0xff);
                     const int wc = (int)(kb & 0x1ff);
                     acls = wc == 511 ? -1 : wc;
@@ -856,18 +862,21 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
             }
 #pragma unroll
             for (int u = 0; u < NPTC; u++) {
-                if ((picked_m >> u) & 1) {
-                    key[u] += bump;
-                    cntv[u] += w0;
-                    if (cntv[u] >= kCompactMax) esc = true;
-                }
+                const bool p = (picked_m >> u) & 1;
+                key[u] += p ? bump : 0u;
+                cntv[u] += p ? w0 : 0;
             }
-            if (lane == 0) {
 #pragma unroll
-                for (int c = 0; c < KM; c++) if (c < k) outbuf[r * q.OW + 1 + c] = wl[c];
-            }
+            for (int c = 0; c < KM; c++) my_w[c] = lane == r ? wl[c] : my_w[c];
         }
+        bool esc = none_acc == 0 || anchor_acc < 0;
+#pragma unroll
+        for (int u = 0; u < NPTC; u++) if (cntv[u] >= kCompactMax / 2) esc = true;   // a batch adds at most 64 * 63
         if (__ballot(esc)) { failed = true; break; }
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < KM; c++) if (c < k) outbuf[lane * q.OW + 1 + c] = my_w[c];
+        }
         __syncthreads();
         for (int i = lane; i < nb * q.OW; i += 64) {
             const int c = i % q.OW;
