@@ -821,7 +821,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
                                      c->chain_order.as<int32_t>(), c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
-                                     rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(), 0,
+                                     rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
+                                     rr.cls_size.as<int32_t>(), 0,
                                      c->crec.as<int32_t>(), scal + 4);
                 HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                       hipMemcpyDeviceToDevice, sm));
@@ -933,7 +934,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
                                      c->order.as<int32_t>(), c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
-                                     c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(), 1,
+                                     c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
+                                     c->fl_one.as<int32_t>(), 1,
                                      c->crec.as<int32_t>(), scal + 4);
                 int32_t bad = 0;
                 HIPTRY(hipMemcpyAsync(&bad, scal + 4, sizeof bad, hipMemcpyDeviceToHost, sm));

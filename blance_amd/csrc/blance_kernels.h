@@ -59,6 +59,7 @@ struct PassParams {
 //   7..10  leaves of the nodes the partition holds in this state (-1 padded)
 //   11..14 leaves of its higher priority nodes inside the region (never candidates)
 //   15..18 leaves of its lower priority nodes inside the region, 19..22 their states
+//   23 leaves covered by the top priority node's exclude class
 constexpr int kChainOwn = 4, kChainHigh = 4, kChainLow = 4;
 constexpr int kCW = 24;
 constexpr int kCOwn = 7, kCHigh = 11, kCLow = 15, kCLowState = 19;

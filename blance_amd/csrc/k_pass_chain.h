@@ -92,6 +92,8 @@ __device__ __forceinline__ double chain_score(int cnt, int ntn, int tot, int has
     return r;
 }
 
+constexpr unsigned kKeyNoneV = 0xffffffffu;
+
 // 32-bit minimum over one wave64 (wave-uniform result)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     unsigned t;
@@ -140,6 +142,22 @@ __device__ __forceinline__ unsigned wave_min_u32_bcast(unsigned v) {
 #endif
 }
 
+// (score, position) argmin of eligible lanes over one wave64 through three 32-bit
+// minima: the high and the low word of the order-preserving integer image of the
+// double, then the position.  Same total order as better() for non-NaN scores.
+__device__ __forceinline__ int wave_argmin3(double s, int n, bool ok) {
+    if (s == 0.0) s = 0.0;                                   // -0.0 == +0.0
+    unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    const unsigned hi = (unsigned)(b >> 32), lo = (unsigned)b;
+    const unsigned mh = wave_min_u32_bcast(ok ? hi : kKeyNoneV);
+    const bool ok2 = ok && hi == mh;
+    const unsigned ml = wave_min_u32_bcast(ok2 ? lo : kKeyNoneV);
+    const bool ok3 = ok2 && lo == ml;
+    const unsigned mn = wave_min_u32_bcast(ok3 ? (unsigned)n : kKeyNoneV);
+    return __ballot(ok) ? (int)mn : INT_MAX;
+}
+
 // FAST = the pass has NP == 0 and no node weights: nodeSorter.Score is then
 // double(count) - currentFactor with currentFactor in {1.5, integers}, so
 // 2 * score is an exact small integer and (score, position) packs into one
@@ -186,10 +204,12 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     __syncthreads();
 
     // lane l owns leaves lo + l + 64 u
-    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], cls[NPTC];
+    int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], cls[NPTC], mycsz[NPTC];
     unsigned alive_m = 0, hasw_m = 0;
     double g[NPTC];
     bool range_bad = false;
+#pragma unroll
+    for (int u = 0; u < NPTC; u++) mycsz[u] = 0;
 #pragma unroll
     for (int u = 0; u < NPTC; u++) {
         const int pos = lo + lane + 64 * u;
@@ -207,6 +227,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 if (n < N && q.alive[n]) alive_m |= 1u << u;
                 g[u] = chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind, lp_tab, ff_tab);
                 cls[u] = q.leaf_cls[pos];
+                mycsz[u] = cls[u] >= 0 ? q.cls_size[lo + cls[u]] : 0;
                 if (FAST && (cntv[u] >= (1 << 15) || cntv[u] <= -(1 << 15))) range_bad = true;
             }
             const int i = lane + 64 * u;
@@ -566,7 +587,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
 #pragma unroll
         for (int j = 0; j < KM; j++) { chosen[j] = -1; chosen_l[j] = -1; }
         int n_out = 0;
-        int acls = REC(6);                           // exclude class of the current anchor
+        int acls = REC(6);                           // exclude class of the current anchor ...
+        int acsz = REC(23);                          // ... and the leaves it covers
         PH(5);
 #pragma unroll
         for (int slot = 0; slot < KM; slot++) {
@@ -577,7 +599,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 if (acls < 0 && !(q.flat && slot == 0)) esc = true;
                 if (!dup && acls >= 0) {
                     ec[slot] = acls;
-                    covered += cszL[acls];
+                    covered += acsz;
 #pragma unroll
                     for (int u = 0; u < NPTC; u++) excl_m |= (cls[u] == acls ? 1u : 0u) << u;
                 }
@@ -596,25 +618,28 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 } else {
                     double bs = pos_inf();
                     int bn = INT_MAX;
+                    bool any = false;
 #pragma unroll
                     for (int u = 0; u < NPTC; u++) {
                         const bool ok = ((elig_m & ~excl_m) >> u) & 1;
-                        const bool take = ok && better(sc[u], nid[u], bs, bn);
+                        const bool take = ok && (!any || better(sc[u], nid[u], bs, bn));
                         bs = take ? sc[u] : bs;
                         bn = take ? nid[u] : bn;
+                        any = any || ok;
                     }
                     PH(6);
-                    best = wave_argmin(bs, bn);
+                    best = wave_argmin3(bs, bn, any);
                 }
                 PH(7);
                 if (best == INT_MAX) esc = true;
-                int wcls = -1, wloc = -1;
+                int wcls = -1, wloc = -1, wcsz = 0;
 #pragma unroll
                 for (int u = 0; u < NPTC; u++) {
                     unsigned long long bm = __ballot(nid[u] == best);
                     if (bm) {
                         int wl = __ffsll((long long)bm) - 1;
                         wcls = __builtin_amdgcn_readlane(cls[u], wl);
+                        wcsz = __builtin_amdgcn_readlane(mycsz[u], wl);
                         wloc = wl + 64 * u;
                     }
                 }
@@ -624,6 +649,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                 chosen_l[slot] = wloc;
                 n_out = slot + 1;
                 acls = wcls;
+                acsz = wcsz;
                 PH(8);
             }
         }

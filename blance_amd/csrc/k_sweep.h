@@ -172,7 +172,8 @@ __global__ void k_chain_classify(DevProblem d, int m, int top_state, const int32
 __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
                                const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
                                const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
-                               const int32_t* leaf_cls, int flat, int32_t* crec, int32_t* flags) {
+                               const int32_t* leaf_cls, const int32_t* cls_size, int flat, int32_t* crec,
+                               int32_t* flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.P) return;
     int p = chain_order[i];
@@ -193,9 +194,11 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
     if (flat) {
         r[4] = top >= 0 ? top : d.NX;              // the "" row when there is no top priority node
         r[6] = -1;                                 // no anchor: nothing is excluded in the first slot
+        r[23] = 0;
     } else {
         r[4] = node_leaf_pos[top] - lo;
         r[6] = leaf_cls[node_leaf_pos[top]];
+        r[23] = r[6] >= 0 ? cls_size[lo + r[6]] : 0;
     }
     bool bad = false;
     int own_nodes[kChainOwn];
