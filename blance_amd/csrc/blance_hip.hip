@@ -101,6 +101,7 @@ struct blance_ctx {
     std::vector<RuleRegions> rule_regions;
     DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save, crec;
     DevBuf fl_iota, fl_zero, fl_one, fl_reglo, fl_reghi;   // the whole cluster as one region (flat single chain)
+    DevBuf n_ev, chain_oi, ev_key, ev_oi, ev_leaf, ev_w, ev_perm, ev_off, ev_counts;   // chain events
     bool flat_chain_ok = false;
     DevBuf f_tot, f_g, f_top_g, f_top_n, f_row_count, f_m, f_moff, f_keys_a, f_keys_b, f_vals_a, f_vals_b, f_hist;
     int64_t steps_batched = 0;
@@ -137,7 +138,8 @@ struct blance_ctx {
         for (DevBuf* b : all) b->release();
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
         rule_regions.clear();
-        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &fl_iota, &fl_zero,
+        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &n_ev, &chain_oi,
+                          &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
                           &fl_one, &fl_reglo, &fl_reghi, &f_tot, &f_g,
                           &f_top_g, &f_top_n, &f_row_count, &f_m, &f_moff, &f_keys_a, &f_keys_b, &f_vals_a,
                           &f_vals_b, &f_hist};
@@ -469,6 +471,18 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
         RESERVE(bucket_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv(P, kPartChunk) + 1) + 1));
         RESERVE(reg_off, sizeof(int32_t) * ((size_t)maxB + 2));
         RESERVE(cnt_save, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1));
+        if (maxB > 1) {
+            const size_t emax = (size_t)P * L + 1;
+            RESERVE(n_ev, sizeof(int32_t) * ((size_t)P + 2));
+            RESERVE(chain_oi, sizeof(int32_t) * ((size_t)P + 1));
+            RESERVE(ev_key, sizeof(int32_t) * emax);
+            RESERVE(ev_oi, sizeof(int32_t) * emax);
+            RESERVE(ev_leaf, sizeof(int32_t) * emax);
+            RESERVE(ev_w, sizeof(int32_t) * emax);
+            RESERVE(ev_perm, sizeof(int32_t) * emax);
+            RESERVE(ev_off, sizeof(int32_t) * ((size_t)maxB + 2));
+            RESERVE(ev_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv((int64_t)emax, kPartChunk) + 1) + 1));
+        }
         c->flat_chain_ok = NX >= 1 && NX <= 256 && L <= kChainOwn;
         if (maxB > 1 || c->flat_chain_ok) RESERVE(crec, sizeof(int32_t) * ((size_t)P * kCW + 64));
         if (c->flat_chain_ok) {
@@ -715,6 +729,25 @@ static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
     return true;
 }
 
+// developer aid: BLANCE_DUMP_SWEEP=<i> prints every step's choice of sweep i (pass order)
+static int dump_pass(blance_ctx* c, int sweep, int state, int P, int OW, const int32_t* idx_dev /* or null */) {
+    const char* e = getenv("BLANCE_DUMP_SWEEP");
+    if (!e || atoi(e) != sweep) return 0;
+    std::vector<int32_t> out((size_t)P * OW), idx((size_t)P);
+    HIPTRY(hipMemcpyAsync(out.data(), c->out.p, sizeof(int32_t) * out.size(), hipMemcpyDeviceToHost, c->stream));
+    if (idx_dev) HIPTRY(hipMemcpyAsync(idx.data(), idx_dev, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
+    HIPTRY(hipStreamSynchronize(c->stream));
+    std::vector<int> at((size_t)P);
+    for (int i = 0; i < P; i++) at[idx_dev ? idx[i] : i] = i;
+    for (int oi = 0; oi < P; oi++) {
+        const int32_t* o = &out[(size_t)at[oi] * OW];
+        fprintf(stderr, "[dump] sweep %d state %d step %d:", sweep, state, oi);
+        for (int j = 0; j < OW; j++) fprintf(stderr, " %d", o[j]);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}
+
 static int plan_locked(blance_ctx* c, blance_result* res) {
     if (!c->uploaded) return fail(BLANCE_ERR_BAD_ARG, "no problem uploaded");
     HIPTRY(hipSetDevice(c->device));
@@ -726,7 +759,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int32_t* scal = c->scalars.as<int32_t>();
     int64_t launches = 0, steps = 0, batched = 0;
     int n_pass = 0;
-    unsigned chain_gave_up = 0;     // states whose chain pass had to be redone sequentially
+    unsigned chain_gave_up = 0;     // states whose chain pass had to be redone sequentially (this sweep)
 
     DevProblem d;
     d.N = N; d.NX = NX; d.M = M; d.L = L; d.P = P;
@@ -746,6 +779,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int iterations = 0, converged = 0;
     for (int it = 0; it < h.max_iterations; it++) {                 // plan.go:32
         const bool first = it == 0;
+        chain_gave_up = 0;
         d.node_removed = first ? c->node_removed.as<uint8_t>() : c->zeros_nx.as<uint8_t>();   // plan.go:53-55
         d.node_added = first ? c->node_added.as<uint8_t>() : c->zeros_nx.as<uint8_t>();
         const int add_nil = first ? h.nodes_to_add_nil : 0;
@@ -783,7 +817,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, 3 * n_chunks, c->chunk_counts.as<int32_t>());
             BLANCE_LAUNCH(k_part_scatter, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
                           c->part_order.as<int32_t>(), c->part_order.as<int32_t>(), n_chunks, 3, 2,
-                          c->chunk_counts.as<int32_t>(), c->order.as<int32_t>());
+                          c->chunk_counts.as<int32_t>(), c->order.as<int32_t>(), (int32_t*)nullptr);
             if (NP > 0)                                             // nodeToNodeCounts := fresh, plan.go:266
                 HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
             const int OW = 1 + k;
@@ -803,9 +837,10 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4 && !((chain_gave_up >> m) & 1)) {
                 blance_ctx::RuleRegions& rr = c->rule_regions[r0];
                 const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
-                HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
-                BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
-                                     rr.node_region.as<int32_t>(), c->regid.as<int32_t>(), scal + 4);
+                HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+                BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P + 1, 256), 256, 0, sm, d, m, h.top_state,
+                                     c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
+                                     c->n_ev.as<int32_t>(), scal + 4);
                 int nbits = 1;
                 while ((1 << nbits) < B) nbits++;
                 BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
@@ -815,11 +850,39 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                                      c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
                 BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
                               (const uint8_t*)nullptr, (const int32_t*)nullptr, c->order.as<int32_t>(), nbc, B, nbits,
-                              c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>());
+                              c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>());
+                // events: how many?  (also: is every step region-local at all, are there orphan nodes)
+                int32_t n_events = 0, cfl[8] = {0};
+                HIPTRY(hipMemcpyAsync(cfl, scal + 4, sizeof cfl, hipMemcpyDeviceToHost, sm));
+                HIPTRY(hipStreamSynchronize(sm));
+                if (!cfl[0] && cfl[7]) {                            // rare: nodes outside their partition's region
+                    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, P + 1, c->n_ev.as<int32_t>());   // -> event slots
+                    HIPTRY(hipMemcpyAsync(&n_events, c->n_ev.as<int32_t>() + P, sizeof n_events, hipMemcpyDeviceToHost, sm));
+                    HIPTRY(hipStreamSynchronize(sm));
+                }
+                if (getenv("BLANCE_TRACE"))
+                    fprintf(stderr, "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
+                HIPTRY(hipMemsetAsync(c->ev_off.p, 0, sizeof(int32_t) * ((size_t)B + 1), sm));
+                if (!cfl[0] && n_events > 0) {
+                    const int nec = cdiv(n_events, kPartChunk);
+                    BLANCE_LAUNCH_NOSYNC(k_chain_ev_fill, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+                                         rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), c->node_leaf_pos.as<int32_t>(),
+                                         c->regid.as<int32_t>(), c->n_ev.as<int32_t>(), c->ev_key.as<int32_t>(),
+                                         c->ev_oi.as<int32_t>(), c->ev_leaf.as<int32_t>(), c->ev_w.as<int32_t>());
+                    BLANCE_LAUNCH(k_part_count, nec, 64, sizeof(int32_t) * B + 64, sm, n_events, c->ev_key.as<int32_t>(),
+                                  (const uint8_t*)nullptr, (const int32_t*)nullptr, nec, B, c->ev_counts.as<int32_t>());
+                    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, B * nec, c->ev_counts.as<int32_t>());
+                    BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nec, n_events,
+                                         c->ev_counts.as<int32_t>(), c->ev_off.as<int32_t>());
+                    BLANCE_LAUNCH(k_part_scatter, nec, 64, sizeof(int32_t) * B + 64, sm, n_events, c->ev_key.as<int32_t>(),
+                                  (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, nec, B, nbits,
+                                  c->ev_counts.as<int32_t>(), c->ev_perm.as<int32_t>(), (int32_t*)nullptr);
+                    launches += 5;
+                }
                 BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->chain_order.as<int32_t>(),
                                      c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
                 BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
-                                     c->chain_order.as<int32_t>(), c->state_stick.as<int32_t>(),
+                                     c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>(), c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
                                      rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
                                      rr.cls_size.as<int32_t>(), 0,
@@ -842,6 +905,11 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 cq.cnt = c->cnt.as<int32_t>(); cq.ntn = c->ntn.as<int32_t>();
                 cq.crec = c->crec.as<int32_t>(); cq.out = c->out.as<int32_t>();
                 cq.flags = scal + 4;
+                cq.ev_off = c->ev_off.as<int32_t>(); cq.ev_perm = c->ev_perm.as<int32_t>();
+                cq.ev_oi = c->ev_oi.as<int32_t>(); cq.ev_leaf = c->ev_leaf.as<int32_t>(); cq.ev_w = c->ev_w.as<int32_t>();
+                if (cfl[6])                                        // nodes of this state that lie in no region
+                    BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+                                         rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
                 cq.cnt_out = cq.cnt;
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
                 // a fresh plan's first sweep: every step blank -> the lean kernel; it either
@@ -866,6 +934,9 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                     } else if (!fl[0]) {                            // not all blank: the full kernel, from the same state
                         HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
                                               hipMemcpyDeviceToDevice, sm));
+                        if (cfl[6])
+                            BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state,
+                                                 c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
                         HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
                     }
                 }
@@ -883,6 +954,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                         fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
                                 m, fl[2], P, fl[3]);
                     if (!fl[0] && !fl[1]) {
+                        if (dump_pass(c, it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
                         BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, OW, c->chain_order.as<int32_t>(),
                                              c->rec.as<int32_t>(), c->out.as<int32_t>());
                         launches++;
@@ -932,7 +1004,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             if (flat_chain) {
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
                 BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
-                                     c->order.as<int32_t>(), c->state_stick.as<int32_t>(),
+                                     c->order.as<int32_t>(), (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_one.as<int32_t>(), 1,
@@ -962,6 +1034,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             if (e) return e;
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
             n_pass++;
+            if (dump_pass(c, it, m, P, q.OW, nullptr)) return BLANCE_ERR_DEVICE;
             BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, q.OW, c->order.as<int32_t>(),
                                  c->rec.as<int32_t>(), c->out.as<int32_t>());
             }

@@ -53,8 +53,10 @@ struct PassParams {
 //
 // Compact chain step record (k_gather_chain), kCW words, everything already
 // translated to leaf indices local to the region:
-//   0 partition   1 weight   2,3 stickiness (fp64)   4 top priority node's leaf
-//   5 counts: own | higher << 8 | lower << 16 | (state list present) << 24
+//   1 weight   2,3 stickiness (fp64)   4 top priority node's leaf
+//   0 index of the step in pass order
+//   5 counts: own (inside the region) | higher << 8 | lower << 16 | (state list present) << 24
+//     | (holds nodes of this state outside the region) << 25
 //   6 exclude class of the top priority node
 //   7..10  leaves of the nodes the partition holds in this state (-1 padded)
 //   11..14 leaves of its higher priority nodes inside the region (never candidates)
@@ -84,6 +86,14 @@ struct ChainParams {
     int32_t* cnt;
     int32_t* cnt_out;              // k_pass_chain_blank: where the new counters go (committed by the host)
     int32_t* ntn;
+    // A node the partition holds in this state OUTSIDE its region leaves it (plan.go:290-293)
+    // whatever the step decides: a static event for the chain that owns the node, applied
+    // before that chain's first step that comes later in pass order.
+    const int32_t* ev_off;         // [n_regions + 1] events of the region: ev_perm[ev_off[r] .. ev_off[r + 1])
+    const int32_t* ev_perm;        // event ids grouped by region, pass order inside a region
+    const int32_t* ev_oi;          // [E] pass index of the step that causes the event
+    const int32_t* ev_leaf;        // [E] leaf (local to the owning region) whose counters drop
+    const int32_t* ev_w;           // [E] by this much
     const int32_t* crec;           // [P * kCW] compact step records in chain order
     int32_t* out;                  // [P * OW]
     int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape,

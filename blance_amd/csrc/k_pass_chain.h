@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     const int rg = blockIdx.x;
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
-    if (cbeg >= cend) return;
+    if (cbeg >= cend && !(q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1])) return;   // no step, no event
     const int N = q.N, NX = q.NX, M = q.M, NP = q.NP, s = q.s, k = q.k;
     // LDS: quotient tables, mirrors of the per-leaf registers (read by the stay
     // validators), a 64-step staging area for records and outputs (no global memory
@@ -262,6 +262,29 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     double gmin_s = 0.0;
     int gmin_n = INT_MAX;
     int spec_steps = 0, spec_batches = 0;          // statistics (lane 0)
+    // events: nodes of other regions' partitions that leave this region's counters (see ChainParams)
+    int ev_cur = q.ev_off ? q.ev_off[rg] : 0;
+    const int ev_end = q.ev_off ? q.ev_off[rg + 1] : 0;
+    int next_ev_oi = ev_cur < ev_end ? q.ev_oi[q.ev_perm[ev_cur]] : INT_MAX;
+    auto apply_event = [&]() {
+        const int e = q.ev_perm[ev_cur];
+        const int el = q.ev_leaf[e], ew = q.ev_w[e];
+#pragma unroll
+        for (int u = 0; u < NPTC; u++) {
+            if (el == lane + 64 * u) {
+                cntv[u] -= ew;
+                totv[u] -= ew;
+                g[u] = FAST ? (double)cntv[u]
+                            : chain_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind, lp_tab, ff_tab);
+                gL[el] = g[u]; cntL[el] = cntv[u]; totL[el] = totv[u];
+                if (FAST && cntv[u] <= -(1 << 15)) range_bad = true;
+            }
+        }
+        BLANCE_WAVE_SYNC();
+        gmin_dirty = true;
+        ev_cur++;
+        next_ev_oi = ev_cur < ev_end ? q.ev_oi[q.ev_perm[ev_cur]] : INT_MAX;
+    };
     PH_DECL;
 
     for (int base = cbeg; base < cend && !escaped; base += 64) {
@@ -271,6 +294,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
       __syncthreads();
       int b = 0;
       while (b < nb) {
+        while (next_ev_oi < recbuf[b * kCW]) apply_event();      // due before this step (pass order)
         // ---- Speculate that the next (up to 64) steps keep their nodes.  A stay
         // changes no counter, so under that hypothesis every step sees the state as
         // it is now and lane a can check step b + a on its own: the partition's
@@ -311,7 +335,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const double vstick = __hiloint2double(rp[3], rp[2]);
             const int vtl = rp[4];
             const int cn = rp[5];
-            if (!((cn >> 24) & 1) || (cn & 0xff) != k) fail = true;      // must hold exactly k nodes
+            if (!((cn >> 24) & 1) || (cn & 0xff) != k || ((cn >> 25) & 1)) fail = true;   // exactly k nodes, all here
+            if (rp[0] > next_ev_oi) fail = true;                      // an event comes first
             int oi[KM], oc[KM + 1];
             int on[KM];
             double so[KM];
@@ -387,6 +412,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             b += nok;
             if (b >= nb) break;
             if (nok == 64) continue;
+            if (next_ev_oi < recbuf[b * kCW]) continue;          // an event is due before the step that failed
         }
         // ---- FAST mode, runs of blank steps (a partition that holds no node of this or
         // a lower priority state; its higher priority nodes are simply masked): nothing
@@ -403,7 +429,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const int* rp = recbuf + (active ? sb : b) * kCW;
             const int w0 = recbuf[b * kCW + 1];
             const int tcv = rp[6];
-            const bool blank = active && (rp[5] & 0xff00ff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat);
+            const bool blank = active && (rp[5] & 0xff00ff) == 0 && rp[1] == w0 && (tcv >= 0 || q.flat) &&
+                               rp[0] < next_ev_oi;
             int hv[kChainHigh];
 #pragma unroll
             for (int j = 0; j < kChainHigh; j++) hv[j] = rp[kCHigh + j];
@@ -720,7 +747,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         PH(10);
         {
             // did this step keep its nodes?  then the next ones probably do, too
-            bool same = ((cn >> 24) & 1) && (cn & 0xff) == n_out;
+            bool same = ((cn >> 24) & 1) && !((cn >> 25) & 1) && (cn & 0xff) == n_out;
             if (same) {
 #pragma unroll
                 for (int c = 0; c < KM; c++) if (c < n_out && REC(kCOwn + c) != chosen_l[c]) same = false;
@@ -746,6 +773,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
       const int n_done = (!escaped || q.flat) ? b : 0;
       for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
     }
+    if (!escaped) while (ev_cur < ev_end) apply_event();      // nodes that leave after this region's last step
+    if (__ballot(range_bad)) { escaped = true; stop_range = true; }
     PH_DUMP(cend - cbeg);
     if (lane == 0 && spec_batches) { atomicAdd(&q.flags[2], spec_steps); atomicAdd(&q.flags[3], spec_batches); }
     if (escaped) {
@@ -789,7 +818,7 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
     int* outbuf = recbuf + 64 * kCW;                 // [64][OW] leaf indices, turned into node ids at the flush
     int nid[NPTC], cntv[NPTC], cls[NPTC];
     unsigned alive_m = 0;
-    bool bad = size > 256 || q.NP != 0;
+    bool bad = size > 256 || q.NP != 0 || (q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1]);
     int mx = 0;
 #pragma unroll
     for (int u = 0; u < NPTC; u++) {

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64) void k_part_count(int n, const int32_t* key32, 
 
 __global__ __launch_bounds__(64) void k_part_scatter(int n, const int32_t* key32, const uint8_t* key8,
                                                      const int32_t* index, const int32_t* values, int n_chunks,
-                                                     int B, int nbits, const int32_t* offsets, int32_t* out) {
+                                                     int B, int nbits, const int32_t* offsets, int32_t* out,
+                                                     int32_t* out_index) {
     BLANCE_DYN_LDS(lds);
     int* pos = (int*)lds;                            // [B] next output slot per bucket
     const int lane = threadIdx.x, chunk = blockIdx.x;
@@ -142,34 +143,82 @@ __global__ __launch_bounds__(64) void k_part_scatter(int n, const int32_t* key32
         __syncthreads();
         if (valid && lower == 0) pos[key] += __popcll(peers);
         __syncthreads();
-        if (valid) out[dst] = values[i];
+        if (valid) {
+            out[dst] = values ? values[i] : i;
+            if (out_index) out_index[dst] = i;
+        }
     }
 }
 
-// Region of every step of the pass, or flags[0] if some step is not region-local:
-// its top priority node and the nodes it currently holds in this state must sit
-// in one region (their counters are then owned by that region's chain).
+// Region of every step of the pass (the region of its top priority node), or
+// flags[0] if a step has none.  Nodes the partition holds in this state outside
+// that region leave the state whatever the step decides (plan.go:290-293): they
+// become events for the chains that own them (n_ev counts them per step; flags[7]
+// says there are any; flags[6] is raised if some lie in no region at all --
+// k_chain_orphans un-counts those).
 __global__ void k_chain_classify(DevProblem d, int m, int top_state, const int32_t* order,
-                                 const int32_t* node_region, int32_t* regid, int32_t* flags) {
+                                 const int32_t* node_region, int32_t* regid, int32_t* n_ev, int32_t* flags) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (oi >= d.P) return;
+    if (oi > d.P) return;
+    if (oi == d.P) { n_ev[oi] = 0; return; }
     int p = order[oi];
     int idxT = p * d.M + top_state;
     int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
     int rg = top >= 0 ? node_region[top] : -1;
+    int ne = 0;
     if (rg >= 0) {
         int idx = p * d.M + m;
         if (d.live_kind[idx] != kListAbsent)
-            for (int i = 0; i < d.live_len[idx]; i++)
-                if (node_region[d.live[(size_t)idx * d.L + i]] != rg) rg = -1;
+            for (int i = 0; i < d.live_len[idx]; i++) {
+                int r2 = node_region[d.live[(size_t)idx * d.L + i]];
+                if (r2 == rg) continue;
+                if (r2 >= 0) ne++; else flags[6] = 1;
+                flags[7] = 1;                      // the pass has nodes outside their partition's region
+            }
     }
     if (rg < 0) { flags[0] = 1; rg = 0; }
     regid[oi] = rg;
+    n_ev[oi] = ne;
+}
+
+// the events of every step, in pass order, at the slots an exclusive scan of n_ev gave
+__global__ void k_chain_ev_fill(DevProblem d, int m, int top_state, const int32_t* order, const int32_t* node_region,
+                                const int32_t* reg_lo, const int32_t* node_leaf_pos, const int32_t* regid,
+                                const int32_t* ev_pos, int32_t* ev_key, int32_t* ev_oi, int32_t* ev_leaf, int32_t* ev_w) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    if (ev_pos[oi + 1] == ev_pos[oi]) return;
+    int p = order[oi];
+    int w = (!d.weights_nil && d.part_has_weight[p]) ? d.part_weight[p] : 1;
+    int idx = p * d.M + m, rg = regid[oi], e = ev_pos[oi];
+    for (int i = 0; i < d.live_len[idx]; i++) {
+        int x = d.live[(size_t)idx * d.L + i];
+        int r2 = node_region[x];
+        if (r2 == rg || r2 < 0) continue;
+        ev_key[e] = r2; ev_oi[e] = oi; ev_leaf[e] = node_leaf_pos[x] - reg_lo[r2]; ev_w[e] = w;
+        e++;
+    }
+}
+
+// nodes of this state that lie in no region: nobody reads their counters during the pass
+__global__ void k_chain_orphans(DevProblem d, int m, int top_state, const int32_t* order, const int32_t* node_region,
+                                int32_t* cnt) {
+    int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= d.P) return;
+    int p = order[oi];
+    int w = (!d.weights_nil && d.part_has_weight[p]) ? d.part_weight[p] : 1;
+    int idx = p * d.M + m;
+    if (d.live_kind[idx] == kListAbsent) return;
+    for (int i = 0; i < d.live_len[idx]; i++) {
+        int x = d.live[(size_t)idx * d.L + i];
+        if (node_region[x] < 0) atomicAdd(&cnt[m * d.NX + x], -w);
+    }
 }
 
 // Compact chain records (layout: blance_kernels.h): the step's nodes as leaf
 // indices local to its region.  Steps the chain kernel cannot represent raise flags[0].
 __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
+                               const int32_t* chain_oi,
                                const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
                                const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
                                const int32_t* leaf_cls, const int32_t* cls_size, int flat, int32_t* crec,
@@ -185,7 +234,7 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
         if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
         else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
     }
-    r[0] = p; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    r[0] = chain_oi ? chain_oi[i] : i; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
     int idxT = p * d.M + top_state;
     int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
     int rg = flat ? 0 : (top >= 0 ? node_region[top] : -1);
@@ -202,14 +251,15 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
     }
     bool bad = false;
     int own_nodes[kChainOwn];
-    int n_own = 0, n_h = 0, n_low = 0, present = 0;
+    int n_own = 0, n_all = 0, n_h = 0, n_low = 0, present = 0, remote = 0;
     int idx = p * d.M + m;
     if (d.live_kind[idx] != kListAbsent) {
         present = 1;
         for (int j = 0; j < d.live_len[idx]; j++) {
             int x = d.live[(size_t)idx * d.L + j];
-            if (n_own >= kChainOwn || node_region[x] != rg) { bad = true; break; }
-            own_nodes[n_own] = x;
+            if (n_all >= kChainOwn) { bad = true; break; }
+            own_nodes[n_all++] = x;
+            if (node_region[x] != rg) { remote = 1; continue; }     // leaves by an event (or as an orphan)
             r[kCOwn + n_own++] = node_leaf_pos[x] - lo;
         }
     }
@@ -220,7 +270,7 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
         const bool higher = (higher_mask >> t) & 1;
         for (int j = 0; j < d.live_len[ix]; j++) {
             int x = d.live[(size_t)ix * d.L + j];
-            for (int e = 0; e < n_own; e++) if (own_nodes[e] == x) bad = true;   // a node held in two states
+            for (int e = 0; e < n_all; e++) if (own_nodes[e] == x) bad = true;   // a node held in two states
             if (node_region[x] != rg) continue;      // never a candidate of this region's chain
             int loc = node_leaf_pos[x] - lo;
             if (higher) {
@@ -235,7 +285,7 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
             }
         }
     }
-    r[5] = n_own | (n_h << 8) | (n_low << 16) | (present << 24);
+    r[5] = n_own | (n_h << 8) | (n_low << 16) | (present << 24) | (remote << 25);
     if (bad) flags[0] = 1;
 }
 
