@@ -527,6 +527,7 @@ static void launch_pass(blance_ctx* c, const PassParams& q) {
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     // T threads own NPT nodes each (register resident); one workgroup runs the pass.
     const int NX = q.NX > 0 ? q.NX : 1;
+    // measured: N = 1024: 3.1 us/step with 256 threads vs 4.0 with 1024; N = 4096: 5.9 (256 x 16) vs 4.8 (1024 x 4)
     int T = c->force_threads;
     if (T != 64 && T != 256 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 256 : 1024);
     if (T == 64 && NX > 256) T = 256;
