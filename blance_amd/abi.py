@@ -63,6 +63,20 @@ class Result(C.Structure):
     ]
 
 
+OP_ADD, OP_DEL, OP_PROMOTE, OP_DEMOTE = 0, 1, 2, 3
+OP_NAMES = ["add", "del", "promote", "demote"]          # NodeStateOp.Op, moves.go:17-21
+
+
+class MovesProblem(C.Structure):
+    _fields_ = [("n_parts", C.c_int32), ("n_states", C.c_int32), ("favor_min_nodes", C.c_int32),
+                ("beg_off", _i32p), ("beg_nodes", _i32p), ("end_off", _i32p), ("end_nodes", _i32p)]
+
+
+class MovesResult(C.Structure):
+    _fields_ = [("op_off", _i32p), ("op_node", _i32p), ("op_state", _i32p), ("op_kind", _i32p),
+                ("capacity", C.c_int64), ("device_ms", C.c_double)]
+
+
 class Options(C.Structure):
     _fields_ = [("engine", C.c_int32), ("device_id", C.c_int32), ("reserved", C.c_int32 * 6)]
 

@@ -1154,6 +1154,69 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     return BLANCE_OK;
 }
 
+extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, blance_moves_result* res) {
+    if (!c || !pb || !res) return fail(BLANCE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    const int P = pb->n_parts, M = pb->n_states;
+    if (P < 0 || M < 0 || !pb->beg_off || !pb->end_off || !pb->beg_nodes || !pb->end_nodes || !res->op_off ||
+        !res->op_node || !res->op_state || !res->op_kind)
+        return fail(BLANCE_ERR_BAD_ARG, "null array pointer or negative size");
+    const size_t PS = (size_t)P * (M + 1);
+    if (pb->beg_off[0] != 0 || pb->end_off[0] != 0) return fail(BLANCE_ERR_BAD_ARG, "CSR offsets must start at 0");
+    for (size_t i = 0; i < PS; i++)
+        if (pb->beg_off[i + 1] < pb->beg_off[i] || pb->end_off[i + 1] < pb->end_off[i])
+            return fail(BLANCE_ERR_BAD_ARG, "CSR offsets not monotone");
+    const int64_t nb = pb->beg_off[PS], ne = pb->end_off[PS], cap = nb + ne;
+    if (cap > res->capacity) return fail(BLANCE_ERR_CAPACITY, "moves capacity too small");
+    if (cap > (int64_t)INT32_MAX) return fail(BLANCE_ERR_UNSUPPORTED, "more than 2^31 list entries");
+    HIPTRY(hipSetDevice(c->device));
+    DevBuf boff, bnod, eoff, enod, onode, ostate, okind, nmov;
+    struct Free { DevBuf* b[8]; ~Free() { for (DevBuf* x : b) x->release(); } } fr{{&boff, &bnod, &eoff, &enod, &onode, &ostate, &okind, &nmov}};
+    auto up = [&](DevBuf& b, const int32_t* src, size_t n) -> int {
+        if (b.reserve(sizeof(int32_t) * (n + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+        if (n) HIPTRY(hipMemcpyAsync(b.p, src, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    };
+    int e;
+    if ((e = up(boff, pb->beg_off, PS + 1)) || (e = up(bnod, pb->beg_nodes, (size_t)nb)) ||
+        (e = up(eoff, pb->end_off, PS + 1)) || (e = up(enod, pb->end_nodes, (size_t)ne)))
+        return e;
+    if (onode.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || ostate.reserve(sizeof(int32_t) * ((size_t)cap + 1)) ||
+        okind.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || nmov.reserve(sizeof(int32_t) * ((size_t)P + 1)))
+        return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    MovesParams q;
+    q.P = P; q.M = M; q.favor_min_nodes = pb->favor_min_nodes;
+    q.beg_off = boff.as<int32_t>(); q.beg_nodes = bnod.as<int32_t>();
+    q.end_off = eoff.as<int32_t>(); q.end_nodes = enod.as<int32_t>();
+    q.op_node = onode.as<int32_t>(); q.op_state = ostate.as<int32_t>(); q.op_kind = okind.as<int32_t>();
+    q.n_moves = nmov.as<int32_t>();
+    HIPTRY(hipEventRecord(c->ev0, c->stream));
+    if (P > 0) BLANCE_LAUNCH_NOSYNC(k_calc_moves, cdiv(P, 256), 256, 0, c->stream, q);
+    HIPTRY(hipEventRecord(c->ev1, c->stream));
+    std::vector<int32_t> hn((size_t)P + 1), hnode((size_t)cap + 1), hstate((size_t)cap + 1), hkind((size_t)cap + 1);
+    if (P > 0) HIPTRY(hipMemcpyAsync(hn.data(), nmov.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
+    if (cap > 0) {
+        HIPTRY(hipMemcpyAsync(hnode.data(), onode.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipMemcpyAsync(hstate.data(), ostate.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipMemcpyAsync(hkind.data(), okind.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPTRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    res->device_ms = ms;
+    int64_t off = 0;
+    for (int p = 0; p < P; p++) {                       // compact the per-partition slices
+        res->op_off[p] = (int32_t)off;
+        const int64_t src = (int64_t)pb->beg_off[(size_t)p * (M + 1)] + pb->end_off[(size_t)p * (M + 1)];
+        for (int i = 0; i < hn[p]; i++) {
+            res->op_node[off] = hnode[src + i]; res->op_state[off] = hstate[src + i]; res->op_kind[off] = hkind[src + i];
+            off++;
+        }
+    }
+    res->op_off[P] = (int32_t)off;
+    return BLANCE_OK;
+}
+
 extern "C" int blance_upload(blance_ctx* c, const blance_problem* pb) {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);

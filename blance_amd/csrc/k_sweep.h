@@ -417,4 +417,76 @@ __global__ void k_converge(DevProblem d, int32_t* not_match) {
 }
 
 
+// ---------------------------------------------------------------------------
+// CalcPartitionMoves (moves.go:41-136) for every partition: one thread per
+// partition, lists are a handful of node ids.  Moves are written to the
+// partition's slice of the output (capacity = its list entries), n_moves[p] says
+// how many; the host compacts.
+// ---------------------------------------------------------------------------
+struct MovesParams {
+    int32_t P, M, favor_min_nodes;
+    const int32_t* beg_off; const int32_t* beg_nodes;
+    const int32_t* end_off; const int32_t* end_nodes;
+    int32_t* op_node; int32_t* op_state; int32_t* op_kind; int32_t* n_moves;
+};
+
+__device__ __forceinline__ bool moves_in(const int32_t* off, const int32_t* nodes, int idx, int x) {
+    for (int i = off[idx]; i < off[idx + 1]; i++) if (nodes[i] == x) return true;
+    return false;
+}
+
+__global__ void k_calc_moves(MovesParams q) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= q.P) return;
+    const int M = q.M, S = M + 1, base = p * S;
+    const int out0 = q.beg_off[base] + q.end_off[base];
+    int n = 0;
+    auto add_move = [&](int node, int state, int kind) {         // addMoves + seen, moves.go:49-58
+        for (int i = 0; i < n; i++) if (q.op_node[out0 + i] == node) return;
+        q.op_node[out0 + n] = node; q.op_state[out0 + n] = state; q.op_kind[out0 + n] = kind;
+        n++;
+    };
+    auto in_any = [&](const int32_t* off, const int32_t* nodes, int x) {   // x in flattenNodesByState(...)
+        for (int t = 0; t < S; t++) if (moves_in(off, nodes, base + t, x)) return true;
+        return false;
+    };
+    auto state_changes = [&](int si, int lo, int hi, int kind) {           // findStateChanges, moves.go:121-136
+        for (int e = q.end_off[base + si]; e < q.end_off[base + si + 1]; e++) {
+            int node = q.end_nodes[e];
+            for (int i = lo; i < hi; i++)
+                if (moves_in(q.beg_off, q.beg_nodes, base + i, node)) add_move(node, si, kind);
+        }
+    };
+    auto clean_adds = [&](int si) {                                       // moves.go:77-82
+        for (int e = q.end_off[base + si]; e < q.end_off[base + si + 1]; e++) {
+            int x = q.end_nodes[e];
+            if (!moves_in(q.beg_off, q.beg_nodes, base + si, x) && !in_any(q.beg_off, q.beg_nodes, x))
+                add_move(x, si, BLANCE_OP_ADD);
+        }
+    };
+    auto clean_dels = [&](int si) {                                       // moves.go:84-89
+        for (int e = q.beg_off[base + si]; e < q.beg_off[base + si + 1]; e++) {
+            int x = q.beg_nodes[e];
+            if (!moves_in(q.end_off, q.end_nodes, base + si, x) && !in_any(q.end_off, q.end_nodes, x))
+                add_move(x, -1, BLANCE_OP_DEL);
+        }
+    };
+    if (!q.favor_min_nodes) {
+        for (int si = 0; si < M; si++) {
+            state_changes(si, si + 1, M, BLANCE_OP_PROMOTE);
+            state_changes(si, 0, si, BLANCE_OP_DEMOTE);
+            clean_adds(si);
+            clean_dels(si);
+        }
+    } else {
+        for (int si = M - 1; si >= 0; si--) {
+            clean_dels(si);
+            state_changes(si, 0, si, BLANCE_OP_DEMOTE);
+            state_changes(si, si + 1, M, BLANCE_OP_PROMOTE);
+            clean_adds(si);
+        }
+    }
+    q.n_moves[p] = n;
+}
+
 }  // namespace blance

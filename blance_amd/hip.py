@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libblance_hip.so")
 
 EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", "blance_validate",
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
-           "blance_plan_resident", "blance_download"]
+           "blance_plan_resident", "blance_download", "blance_calc_moves"]
 
 _libs = {}
 
@@ -55,6 +55,8 @@ def load_library(path=None):
     lib.blance_plan_resident.argtypes = [C.c_void_p, C.POINTER(abi.Result)]
     lib.blance_download.restype = C.c_int
     lib.blance_download.argtypes = [C.c_void_p, C.POINTER(abi.Result)]
+    lib.blance_calc_moves.restype = C.c_int
+    lib.blance_calc_moves.argtypes = [C.c_void_p, C.POINTER(abi.MovesProblem), C.POINTER(abi.MovesResult)]
     if lib.blance_abi_version() != abi.ABI_VERSION:
         raise ImportError("ABI version mismatch")
     _libs[path] = lib
@@ -99,6 +101,24 @@ class Planner:
         res = abi.FlatResult(fp)
         self._check(self.lib.blance_plan(self._h, C.byref(fp.as_struct()), C.byref(res.struct)))
         return res
+
+    def calc_moves(self, n_states, favor_min_nodes, beg_off, beg_nodes, end_off, end_nodes):
+        """blance_calc_moves(): CalcPartitionMoves for every partition (CSR over
+        p * (n_states + 1) + state).  Returns (op_off, op_node, op_state, op_kind, device_ms)."""
+        import numpy as np
+        arr = [np.ascontiguousarray(a, dtype=np.int32) for a in (beg_off, beg_nodes, end_off, end_nodes)]
+        keep = [a if a.size else np.zeros(1, dtype=np.int32) for a in arr]
+        P = (arr[0].size - 1) // (n_states + 1)
+        pb = abi.MovesProblem()
+        pb.n_parts, pb.n_states, pb.favor_min_nodes = P, n_states, int(bool(favor_min_nodes))
+        pb.beg_off, pb.beg_nodes, pb.end_off, pb.end_nodes = [a.ctypes.data_as(C.POINTER(C.c_int32)) for a in keep]
+        cap = int(arr[0][-1]) + int(arr[2][-1])
+        out = [np.zeros(P + 1, dtype=np.int32)] + [np.zeros(max(cap, 1), dtype=np.int32) for _ in range(3)]
+        res = abi.MovesResult()
+        res.op_off, res.op_node, res.op_state, res.op_kind = [a.ctypes.data_as(C.POINTER(C.c_int32)) for a in out]
+        res.capacity = cap
+        self._check(self.lib.blance_calc_moves(self._h, C.byref(pb), C.byref(res)))
+        return out[0], out[1], out[2], out[3], float(res.device_ms)
 
     def upload(self, fp):
         self._fp = fp

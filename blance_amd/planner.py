@@ -100,6 +100,76 @@ def PlanNextMap(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd
                                             nodeHierarchy, hierarchyRules), planner=planner)
 
 
+class NodeStateOp:
+    """moves.go:17-21"""
+    __slots__ = ("Node", "State", "Op")
+
+    def __init__(self, Node, State, Op):
+        self.Node, self.State, self.Op = Node, State, Op
+
+    def __eq__(self, other):
+        return (self.Node, self.State, self.Op) == (other.Node, other.State, other.Op)
+
+    def __repr__(self):
+        return "NodeStateOp(%r, %r, %r)" % (self.Node, self.State, self.Op)
+
+
+def CalcPartitionMovesBatch(states, begMap, endMap, favorMinNodes, planner=None):
+    """CalcPartitionMoves (moves.go:41-119) for every partition of begMap / endMap at
+    once -- what OrchestrateMoves does in a loop (orchestrate.go:273-287).  Maps are
+    {name: nodesByState} or {name: Partition}; returns {name: [NodeStateOp]}."""
+    import numpy as np
+    from . import abi
+    names = list(endMap.keys()) if endMap is not None else []
+    for n in (begMap or {}):
+        if n not in (endMap or {}):
+            names.append(n)
+    ids, node_names = {}, []
+
+    def nid(x):
+        i = ids.get(x)
+        if i is None:
+            i = ids[x] = len(node_names)
+            node_names.append(x)
+        return i
+
+    def nbs_of(m, name):
+        p = (m or {}).get(name)
+        if p is None:
+            return {}
+        return (p.NodesByState if hasattr(p, "NodesByState") else p) or {}
+
+    M = len(states)
+    known = set(states)
+
+    def csr(m):
+        off, nodes = [0], []
+        for name in names:
+            nbs = nbs_of(m, name)
+            for s in states:
+                nodes.extend(nid(x) for x in (nbs.get(s) or []))
+                off.append(len(nodes))
+            for s, lst in nbs.items():               # keys outside `states` only feed flattenNodesByState
+                if s not in known:
+                    nodes.extend(nid(x) for x in (lst or []))
+            off.append(len(nodes))
+        return np.asarray(off, dtype=np.int32), np.asarray(nodes, dtype=np.int32)
+
+    boff, bnod = csr(begMap)
+    eoff, enod = csr(endMap)
+    op_off, op_node, op_state, op_kind, _ = (planner or default_planner()).calc_moves(M, favorMinNodes, boff, bnod, eoff, enod)
+    out = {}
+    for i, name in enumerate(names):
+        out[name] = [NodeStateOp(node_names[op_node[j]], "" if op_state[j] < 0 else states[op_state[j]],
+                                 abi.OP_NAMES[op_kind[j]]) for j in range(op_off[i], op_off[i + 1])]
+    return out
+
+
+def CalcPartitionMoves(states, begNodesByState, endNodesByState, favorMinNodes, planner=None):
+    """moves.go:41-119 for one partition."""
+    return CalcPartitionMovesBatch(states, {"p": begNodesByState}, {"p": endNodesByState}, favorMinNodes, planner)["p"]
+
+
 # misc.go:13-51, exported helpers callers may use
 def StringsToMap(strs):
     return None if strs is None else {s: True for s in strs}

@@ -206,6 +206,38 @@ int blance_upload(blance_ctx* ctx, const blance_problem* pb);
 int blance_plan_resident(blance_ctx* ctx, blance_result* res /* timings+stats only */);
 int blance_download(blance_ctx* ctx, blance_result* res);
 
+/* ---- CalcPartitionMoves for every partition at once (moves.go:41-136) ---------
+ * The planner's consumer (orchestrate.go:273-287 calls it per partition): the
+ * ordered node-by-node state transitions from begMap[p] to endMap[p].  Per
+ * partition independent.  State ids 0..n_states-1 follow the `states` argument
+ * (superior first); pseudo state n_states collects the nodes of map keys that
+ * are not in `states` (they only feed flattenNodesByState, plan.go:425-431). */
+#define BLANCE_OP_ADD      0
+#define BLANCE_OP_DEL      1
+#define BLANCE_OP_PROMOTE  2
+#define BLANCE_OP_DEMOTE   3
+
+typedef struct blance_moves_problem {
+    int32_t n_parts;
+    int32_t n_states;             /* M = len(states)                                      */
+    int32_t favor_min_nodes;      /* favorMinNodes                                        */
+    const int32_t* beg_off;       /* [P*(M+1) + 1] CSR of begNodesByState over p*(M+1)+s  */
+    const int32_t* beg_nodes;     /* node ids (any non-negative numbering)                */
+    const int32_t* end_off;       /* [P*(M+1) + 1] the same for endNodesByState           */
+    const int32_t* end_nodes;
+} blance_moves_problem;
+
+typedef struct blance_moves_result {
+    int32_t* op_off;              /* [P + 1] moves of partition p: op_off[p]..op_off[p+1] */
+    int32_t* op_node;             /* [capacity] NodeStateOp.Node                          */
+    int32_t* op_state;            /* [capacity] NodeStateOp.State as a state id, -1 = ""  */
+    int32_t* op_kind;             /* [capacity] BLANCE_OP_*                               */
+    int64_t  capacity;            /* in: >= beg_off[last] + end_off[last] always suffices */
+    double   device_ms;           /* out                                                  */
+} blance_moves_result;
+
+int blance_calc_moves(blance_ctx* ctx, const blance_moves_problem* pb, blance_moves_result* res);
+
 /* Validate a problem without touching a device (sizes, id ranges, supported
  * envelope).  Same status codes as blance_plan. */
 int blance_validate(const blance_problem* pb);
