@@ -93,6 +93,7 @@ struct blance_ctx {
     int chain_min_parts = 2048;
     int any_node_weight = 0;
     bool no_fast_keys = false;      // a chain left the packed keys' range during this pass
+    bool no_seq_spec = false;       // test knob (options.reserved[2] & 1): k_pass_seq without stay speculation
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -254,6 +255,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->engine = opt ? opt->engine : BLANCE_ENGINE_AUTO;
     c->force_threads = opt ? opt->reserved[0] : 0;
     if (opt && opt->reserved[1] > 0) c->chain_min_parts = opt->reserved[1];
+    c->no_seq_spec = opt && (opt->reserved[2] & 1);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -402,7 +404,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
                     node_region[a] = (int)j - 1;
                 }
             }
-            if (max_size > 256) ok = false;
+            if (max_size > kChainMaxLeaves) ok = false;
             // Exclude classes: inside a region the anchors' exclude intervals must be
             // pairwise disjoint (racks inside a zone), so "leaf is excluded by anchor a"
             // is "leaf has a's class".  Intervals that cover the region get class -1.
@@ -483,7 +485,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
             RESERVE(ev_off, sizeof(int32_t) * ((size_t)maxB + 2));
             RESERVE(ev_counts, sizeof(int32_t) * ((size_t)maxB * (cdiv((int64_t)emax, kPartChunk) + 1) + 1));
         }
-        c->flat_chain_ok = NX >= 1 && NX <= 256 && L <= kChainOwn;
+        c->flat_chain_ok = NX >= 1 && NX <= 256 && L <= kChainOwn;   // wider: k_pass_seq is faster (measured)
         if (maxB > 1 || c->flat_chain_ok) RESERVE(crec, sizeof(int32_t) * ((size_t)P * kCW + 64));
         if (c->flat_chain_ok) {
             std::vector<int32_t> iota((size_t)NX + 1), zero((size_t)NX + 1, 0), one((size_t)NX + 1, 1);
@@ -518,8 +520,13 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
 }
 
 template <int T, int NPT>
-static void launch_pass(blance_ctx* c, const PassParams& q) {
+static void launch_pass(blance_ctx* c, PassParams q) {
     size_t lds = sizeof(RedSlot) * 2 * (T / 64) + 64;
+    // flat passes: LDS mirrors for the verified-stay speculation (k_pass_seq.h)
+    const size_t mirrors = sizeof(int32_t) * (3 * (size_t)q.NX + 4) + 32;
+    q.spec = (q.rule_begin == q.rule_end && !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL &&
+              lds + mirrors <= 150 * 1024) ? 1 : 0;
+    if (q.spec) lds += mirrors;
     auto kern = k_pass_seq<T, NPT>;
     BLANCE_LAUNCH(kern, 1, T, lds, c->stream, q);
 }
@@ -719,10 +726,12 @@ static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
     if (q.k <= 2) {
         if (nptc <= 2) launch_chain_mode<2, 2>(c, q, lds, fast);
         else if (nptc <= 4) launch_chain_mode<4, 2>(c, q, lds, fast);
+        else if (nptc <= 8) launch_chain_mode<8, 2>(c, q, lds, fast);
         else return false;
     } else if (q.k <= 4) {
         if (nptc <= 2) launch_chain_mode<2, 4>(c, q, lds, fast);
         else if (nptc <= 4) launch_chain_mode<4, 4>(c, q, lds, fast);
+        else if (nptc <= 8) launch_chain_mode<8, 4>(c, q, lds, fast);
         else return false;
     } else {
         return false;
@@ -996,6 +1005,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             q.warn_state = c->warn_state.as<int32_t>();
             q.warn_count = scal + 0;
             q.err = scal + 2;
+            q.spec_count = (long long*)(scal + 12);
             q.beg = 0; q.end = P;
             // a flat pass (no rule for the state) of a small cluster can run on one wave64
             const bool flat_state = h.hierarchy_rules_nil || r1 == r0;
@@ -1057,7 +1067,15 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         if (!hs[1]) { converged = 1; break; }
     }
     HIPTRY(hipEventRecord(c->ev1, sm));
-    HIPTRY(hipEventSynchronize(c->ev1));
+    {                                              // steps k_pass_seq committed as verified stays
+        long long spec = 0;
+        HIPTRY(hipMemcpyAsync(&spec, scal + 12, sizeof spec, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipEventSynchronize(c->ev1));
+        HIPTRY(hipStreamSynchronize(sm));
+        batched += spec;
+        if (batched > steps) batched = steps;     // the flat chain counts its whole pass already
+        if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] sequential passes: %lld verified stays\n", spec);
+    }
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double pass_ms = 0.0, flat_ms = 0.0;

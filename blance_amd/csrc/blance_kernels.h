@@ -46,6 +46,8 @@ struct PassParams {
     int32_t* warn_state;
     int32_t* warn_count;
     int32_t* err;                  // device error word (interval overflow ...)
+    int32_t spec;                  // try verified-stay speculation (flat passes; LDS mirrors sized by the host)
+    long long* spec_count;         // steps committed as verified stays (statistics, may be null)
 };
 
 // Parameters of a state pass run as independent per-region chains (DESIGN.md
@@ -63,6 +65,7 @@ struct PassParams {
 //   15..18 leaves of its lower priority nodes inside the region, 19..22 their states
 //   23 leaves covered by the top priority node's exclude class
 constexpr int kChainOwn = 4, kChainHigh = 4, kChainLow = 4;
+constexpr int kChainMaxLeaves = 512;             // leaves of one region (one wave64, 8 leaves per lane)
 constexpr int kCW = 24;
 constexpr int kCOwn = 7, kCHigh = 11, kCLow = 15, kCLowState = 19;
 

@@ -40,13 +40,125 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         }
     }
 
+    // ---- verified-stay speculation (flat passes; DESIGN.md "Verified stays"): mirrors of the
+    // per-node counters that any thread may read, a first-use table of top priority nodes
+    const bool spec_ok = q.spec && q.rule_begin == q.rule_end && k >= 1 && k <= kMaxK;
+    int* cntL = (int*)(red + 2 * (T / 64));        // [NX]
+    int* totL = cntL + NX;                         // [NX]
+    int* markL = totL + NX;                        // [NX + 1] lowest lane of the batch that uses the row
+    int* shI = markL + NX + 1;                     // [0] first failing lane
+    double* shD = (double*)(shI + 2);              // [0] score of the bound node
+    if (spec_ok) {
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            int n = tid + i * T;
+            if (n < NX) { cntL[n] = cntv[i]; totL[n] = totv[i]; markL[n] = INT_MAX; }
+        }
+        if (tid == 0) markL[NX] = INT_MAX;
+        __syncthreads();
+    }
+    bool try_spec = spec_ok;
+    long long spec_steps = 0;
+
     // step record of the current partition: lane j of every wave holds word j
     int recw = 0, recw_next = 0;
-    if (q.beg < q.end && lane < q.RW) recw_next = q.rec[(size_t)q.beg * q.RW + lane];
+    bool have_next = false;                        // recw_next holds the record of step oi
+    // nodeToNodeCounts row of the NEXT step, fetched one step ahead (NP > 0)
+    int ntn_pre[NPT];
+    int pre_row = -1;
+#pragma unroll
+    for (int i = 0; i < NPT; i++) ntn_pre[i] = 0;
 
-    for (int oi = q.beg; oi < q.end; oi++) {
-        recw = recw_next;
-        if (oi + 1 < q.end && lane < q.RW) recw_next = q.rec[(size_t)(oi + 1) * q.RW + lane];
+    int oi = q.beg;
+    while (oi < q.end) {
+        // ---- Speculate that the next steps keep their nodes: a stay changes no counter, so
+        // thread a can check step oi + a against the state as it is now.  The partition's own
+        // nodes, scored exactly, must come out in list order below the smallest
+        // partition-independent score of the cluster (a lower bound of every other
+        // candidate: the omitted terms are >= 0 and IEEE add / divide / subtract are
+        // monotone).  The verified prefix is committed; the first other step runs below.
+        if (spec_ok && try_spec) {
+            double ms = pos_inf();
+            int mn = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < NPT; u++) {
+                if (((alive_m >> u) & 1) && better(g[u], tid + u * T, ms, mn)) { ms = g[u]; mn = tid + u * T; }
+            }
+            const int gmin_n = uni(block_argmin<T>(ms, mn, red, round));
+#pragma unroll
+            for (int u = 0; u < NPT; u++) if (tid + u * T == gmin_n) shD[0] = g[u];
+            __syncthreads();
+            const double gmin_s = gmin_n == INT_MAX ? pos_inf() : shD[0];
+            for (;;) {
+                const int B = q.end - oi < T ? q.end - oi : T;
+                const bool active = tid < B;
+                bool fail = false;
+                int own[kMaxK];
+#pragma unroll
+                for (int j = 0; j < kMaxK; j++) own[j] = 0;
+                int vrow = NX;
+                if (active) {
+                    const int32_t* r = q.rec + (size_t)(oi + tid) * q.RW;
+                    const double vstick = __hiloint2double(r[3], r[2]);
+                    const int hT = r[kRecHead + q.top_state * SW];
+                    if ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) vrow = r[kRecHead + q.top_state * SW + 1];
+                    const int hs = r[kRecHead + s * SW];
+                    if ((hs >> 16) == kListAbsent || (hs & 0xffff) != k) fail = true;
+                    if (!fail) {
+                        double prev_s = 0.0;
+                        int prev_n = -1;
+                        for (int j = 0; j < k; j++) {
+                            const int o = r[kRecHead + s * SW + 1 + j];
+                            own[j] = o;
+                            if (o >= N || !q.alive[o]) { fail = true; break; }
+                            // held in another state as well: excluded (higher) or demoted (lower)
+                            for (int t = 0; t < M; t++) {
+                                if (t == s) continue;
+                                const int h = r[kRecHead + t * SW];
+                                if ((h >> 16) == kListAbsent) continue;
+                                for (int jj = 0; jj < (h & 0xffff); jj++)
+                                    if (r[kRecHead + t * SW + 1 + jj] == o) fail = true;
+                            }
+                            const int nt = NP > 0 ? q.ntn[(size_t)vrow * N + o] : 0;
+                            const double so = node_score(cntL[o], nt, totL[o], q.node_has_weight[o], q.node_weight[o],
+                                                         NP, vstick, q.booster_kind);
+                            if (j > 0 && !better(prev_s, prev_n, so, o)) fail = true;
+                            if (!better(so, o, gmin_s, gmin_n)) fail = true;
+                            prev_s = so; prev_n = o;
+                        }
+                    }
+                }
+                if (tid == 0) shI[0] = B;
+                // an earlier step of the batch with the same top priority node bumps my row
+                if (NP > 0 && active) atomicMin(&markL[vrow], tid);
+                __syncthreads();
+                if (NP > 0 && active && markL[vrow] < tid) fail = true;
+                if (active && fail) atomicMin(&shI[0], tid);
+                __syncthreads();
+                const int nok = shI[0];
+                if (NP > 0 && active) markL[vrow] = INT_MAX;
+                if (tid < nok) {
+                    int* o = q.out + (size_t)(oi + tid) * q.OW;
+                    o[0] = k;
+                    for (int j = 0; j < k; j++) {
+                        o[1 + j] = own[j];
+                        if (NP > 0) q.ntn[(size_t)vrow * N + own[j]] += 1;        // plan.go:238-245
+                    }
+                }
+                __syncthreads();
+                oi += nok;
+                spec_steps += nok;
+                if (nok < B || oi >= q.end) break;
+            }
+            if (oi >= q.end) break;
+            have_next = false;
+            pre_row = -1;
+        }
+
+        if (have_next) recw = recw_next;
+        else recw = lane < q.RW ? q.rec[(size_t)oi * q.RW + lane] : 0;
+        have_next = oi + 1 < q.end;
+        if (have_next && lane < q.RW) recw_next = q.rec[(size_t)(oi + 1) * q.RW + lane];
 #define REC(i) __builtin_amdgcn_readlane(recw, (i))
         const int p = REC(0);
         const int w = REC(1);
@@ -61,11 +173,30 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
 
         // nodeToNodeCounts row of the top priority node (only read when NP > 0, plan.go:638)
         int ntnv[NPT];
+        if (NP > 0 && pre_row == row) {
 #pragma unroll
-        for (int i = 0; i < NPT; i++) {
-            int n = tid + i * T;
-            ntnv[i] = (NP > 0 && n < N) ? q.ntn[(size_t)row * N + n] : 0;
+            for (int i = 0; i < NPT; i++) ntnv[i] = ntn_pre[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPT; i++) {
+                int n = tid + i * T;
+                ntnv[i] = (NP > 0 && n < N) ? q.ntn[(size_t)row * N + n] : 0;
+            }
         }
+        // the next step's row, in flight during this step; entries this step bumps are patched at commit
+        int next_row = -1;
+        if (NP > 0 && have_next) {
+            int hdr = __builtin_amdgcn_readlane(recw_next, kRecHead + q.top_state * SW);
+            next_row = NX;
+            if ((hdr >> 16) != kListAbsent && (hdr & 0xffff) > 0)
+                next_row = __builtin_amdgcn_readlane(recw_next, kRecHead + q.top_state * SW + 1);
+#pragma unroll
+            for (int i = 0; i < NPT; i++) {
+                int n = tid + i * T;
+                ntn_pre[i] = n < N ? q.ntn[(size_t)next_row * N + n] : 0;
+            }
+        }
+        pre_row = next_row;
 
         // membership of my nodes in the higher-priority lists (plan.go:146-154)
         // and in this state's current list (plan.go:654-662)
@@ -257,7 +388,10 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                         cntv[u] += w;
                         totv[u] += w;
                         changed_m |= 1u << u;
-                        if (NP > 0) q.ntn[(size_t)row * N + x] = ntnv[u] + 1;   // plan.go:238-245
+                        if (NP > 0) {                                           // plan.go:238-245
+                            q.ntn[(size_t)row * N + x] = ntnv[u] + 1;
+                            if (next_row == row) ntn_pre[u] = ntnv[u] + 1;
+                        }
                     }
                 }
             }
@@ -265,8 +399,18 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         if (changed_m) {
 #pragma unroll
             for (int u = 0; u < NPT; u++)
-                if ((changed_m >> u) & 1)
+                if ((changed_m >> u) & 1) {
                     g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
+                    if (spec_ok) { cntL[tid + u * T] = cntv[u]; totL[tid + u * T] = totv[u]; }
+                }
+        }
+        if (spec_ok) {                             // speculate again after a step that kept its nodes
+            int hs = REC(kRecHead + s * SW);
+            bool stay = (hs >> 16) != kListAbsent && (hs & 0xffff) == k && n_out == k;
+#pragma unroll
+            for (int c = 0; c < kMaxK; c++)
+                if (stay && c < k && chosen[c] != REC(kRecHead + s * SW + 1 + c)) stay = false;
+            try_spec = stay;
         }
         if (tid == 0) {
             int is_nil = (n_out == 0 && q.n_alive == 0 && !any_higher_key && !q.hier);
@@ -282,7 +426,9 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             }
         }
 #undef REC
+        oi++;
     }
+    if (spec_ok && tid == 0 && q.spec_count) *q.spec_count += spec_steps;
 
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
