@@ -521,7 +521,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
 
 template <int T, int NPT>
 static void launch_pass(blance_ctx* c, PassParams q) {
-    size_t lds = sizeof(RedSlot) * 2 * (T / 64) + 64;
+    size_t lds = sizeof(RedSlot) * 2 * (T / 64) + sizeof(double) * kLpTab + 64;
     // flat passes: LDS mirrors for the verified-stay speculation (k_pass_seq.h)
     const size_t mirrors = sizeof(int32_t) * (3 * (size_t)q.NX + 4) + 32;
     q.spec = (q.rule_begin == q.rule_end && !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL &&
@@ -538,14 +538,16 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     int T = c->force_threads;
     if (T != 64 && T != 256 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 256 : 1024);
     if (T == 64 && NX > 256) T = 256;
-    if (T == 256 && NX > 1024) T = 1024;
+    if (T == 256 && NX > 4096) T = 1024;
     const int npt = cdiv(NX, T);
     if (T == 64) {
         if (npt <= 1) launch_pass<64, 1>(c, q);
         else launch_pass<64, 4>(c, q);
     } else if (T == 256) {
         if (npt <= 1) launch_pass<256, 1>(c, q);
-        else launch_pass<256, 4>(c, q);
+        else if (npt <= 4) launch_pass<256, 4>(c, q);
+        else if (npt <= 8) launch_pass<256, 8>(c, q);
+        else launch_pass<256, 16>(c, q);
     } else {
         if (npt <= 2) launch_pass<1024, 2>(c, q);
         else if (npt <= 4) launch_pass<1024, 4>(c, q);

@@ -40,36 +40,136 @@ __device__ __forceinline__ bool better(double s1, int n1, double s2, int n2) {
 
 __device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
-struct RedSlot { double s; int n; int pad; };
+struct RedSlot { unsigned hi, lo; int n; int pad; };
 
-// Lexicographic (score, position) argmin over a workgroup of T threads.
-// One barrier per call; slots are double-buffered by call parity.
+#ifdef BLANCE_PHASE_PROF     // developer build only: per-phase shader-clock totals of chain 0
+#define PH_DECL unsigned long long ph_acc[12] = {0}, ph_t0 = clock64(), ph_t1
+#define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
+#define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
+    printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
+#elif defined(BLANCE_ASM_MARKS)   // developer build only: phase markers as comments in the ISA
+#define PH_DECL
+#define PH(i) asm volatile("; PHASE_MARK " #i)
+#define PH_DUMP(steps)
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_DUMP(steps)
+#endif
+
+constexpr unsigned kKeyNoneV = 0xffffffffu;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+
+// 32-bit minimum over one wave64 (wave-uniform result): the cross-row part by row broadcasts, the
+// minimum taken by the DPP instruction itself -- six v_min_u32_dpp and one v_readlane
+__device__ __forceinline__ unsigned wave_min_u32_bcast(unsigned v) {
+#ifndef BLANCE_SIMT_EMU
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#else
+    unsigned t;
+    t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x141>((int)v); v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x140>((int)v); v = t < v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v = t < v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    v = t < v ? t : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+
+// 32-bit minimum over aligned groups of G = 4 or 16 lanes (every lane gets its group's minimum)
+template <int G>
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
+    static_assert(G == 4 || G == 16, "group of 4 or 16 lanes");
+#ifndef BLANCE_SIMT_EMU
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    if (G == 16)
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0"
+            : "+v"(v));
+#else
+    unsigned t;
+    t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
+    t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
+    if (G == 16) {
+        t = (unsigned)dpp_mov<0x141>((int)v); v = t < v ? t : v;
+        t = (unsigned)dpp_mov<0x140>((int)v); v = t < v ? t : v;
+    }
+#endif
+    return v;
+}
+
+// order-preserving integer image of a non-NaN double (-0.0 == +0.0)
+__device__ __forceinline__ unsigned long long sortable_bits(double s) {
+    if (s == 0.0) s = 0.0;
+    unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Lexicographic (score, position) argmin over a workgroup of T threads; callers pass
+// (+inf, INT_MAX) for "no candidate".  Per wave: three 32-bit DPP minima (high word,
+// low word of the score's integer image, position) -- the same total order as
+// better().  One barrier per call; slots are double-buffered by call parity.
 template <int T>
 __device__ __forceinline__ int block_argmin(double s, int n, RedSlot* red, int& round) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double s2 = __shfl_xor(s, off, 64);
-        int n2 = __shfl_xor(n, off, 64);
-        if (better(s2, n2, s, n)) { s = s2; n = n2; }
-    }
+    const unsigned long long b = sortable_bits(s);
+    const unsigned hi = (unsigned)(b >> 32), lo = (unsigned)b;
+    const unsigned mh = wave_min_u32_bcast(hi);
+    const bool ok2 = hi == mh;
+    const unsigned ml = wave_min_u32_bcast(ok2 ? lo : kKeyNoneV);
+    const bool ok3 = ok2 && lo == ml;
+    const unsigned mn = wave_min_u32_bcast(ok3 ? (unsigned)n : kKeyNoneV);
     constexpr int W = T / 64;
-    if (W == 1) return n;
+    if constexpr (W == 1) {
+        return (int)mn;
+    } else {
     RedSlot* slot = red + (round & 1) * W;
     round++;
     if ((threadIdx.x & 63) == 0) {
-        slot[threadIdx.x >> 6].s = s;
-        slot[threadIdx.x >> 6].n = n;
+        slot[threadIdx.x >> 6].hi = mh;
+        slot[threadIdx.x >> 6].lo = ml;
+        slot[threadIdx.x >> 6].n = (int)mn;
     }
     __syncthreads();
-    double bs = slot[0].s;
-    int bn = slot[0].n;
-#pragma unroll
-    for (int j = 1; j < W; j++) {
-        double s2 = slot[j].s;
-        int n2 = slot[j].n;
-        if (better(s2, n2, bs, bn)) { bs = s2; bn = n2; }
+    // second stage: lane l takes wave (l mod W)'s slot; W <= 16 slots sit in one DPP row
+    const RedSlot mine = slot[threadIdx.x & (W - 1)];
+    const unsigned bh = row_min_u32<W>(mine.hi);
+    const bool k2 = mine.hi == bh;
+    const unsigned bl = row_min_u32<W>(k2 ? mine.lo : kKeyNoneV);
+    const bool k3 = k2 && mine.lo == bl;
+    return (int)row_min_u32<W>(k3 ? (unsigned)mine.n : kKeyNoneV);
     }
-    return bn;
 }
 
 // Running value of includeExcludeNodesIntersect (plan.go:738-753) as leaf-interval

@@ -17,11 +17,6 @@ namespace blance {
 // host redoes the whole pass with k_pass_seq.
 // ============================================================================
 template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-}
-
-template <int CTRL>
 __device__ __forceinline__ void argmin_stage(double& s, int& n) {
     int lo2 = dpp_mov<CTRL>(__double2loint(s));
     int hi2 = dpp_mov<CTRL>(__double2hiint(s));
@@ -48,21 +43,6 @@ __device__ __forceinline__ int wave_argmin(double s, int n) {
     }
     return bn;
 }
-
-#ifdef BLANCE_PHASE_PROF     // developer build only: per-phase shader-clock totals of chain 0
-#define PH_DECL unsigned long long ph_acc[12] = {0}, ph_t0 = clock64(), ph_t1
-#define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
-#define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
-    printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
-#elif defined(BLANCE_ASM_MARKS)   // developer build only: phase markers as comments in the ISA
-#define PH_DECL
-#define PH(i) asm volatile("; PHASE_MARK " #i)
-#define PH_DUMP(steps)
-#else
-#define PH_DECL
-#define PH(i)
-#define PH_DUMP(steps)
-#endif
 
 // nodeSorter.Score with the two quotients that do not depend on the node taken
 // from LDS tables filled by the same expressions (bit-identical by construction).
@@ -92,8 +72,6 @@ __device__ __forceinline__ double chain_score(int cnt, int ntn, int tot, int has
     return r;
 }
 
-constexpr unsigned kKeyNoneV = 0xffffffffu;
-
 // 32-bit minimum over one wave64 (wave-uniform result)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     unsigned t;
@@ -106,40 +84,6 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     r0 = r1 < r0 ? r1 : r0;
     r2 = r3 < r2 ? r3 : r2;
     return r2 < r0 ? r2 : r0;
-}
-
-// the same with the cross-row part done by row broadcasts and the minimum taken by the
-// DPP instruction itself: six v_min_u32_dpp and one v_readlane
-__device__ __forceinline__ unsigned wave_min_u32_bcast(unsigned v) {
-#ifndef BLANCE_SIMT_EMU
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 0"
-        : "+v"(v));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-#else
-    unsigned t;
-    t = (unsigned)dpp_mov<0xB1>((int)v);  v = t < v ? t : v;
-    t = (unsigned)dpp_mov<0x4E>((int)v);  v = t < v ? t : v;
-    t = (unsigned)dpp_mov<0x141>((int)v); v = t < v ? t : v;
-    t = (unsigned)dpp_mov<0x140>((int)v); v = t < v ? t : v;
-    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    v = t < v ? t : v;
-    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    v = t < v ? t : v;
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-#endif
 }
 
 // (score, position) argmin of eligible lanes over one wave64 through three 32-bit

@@ -11,6 +11,29 @@ namespace blance {
 // total counts, weights and partition-independent scores in registers, so a
 // step costs one barrier per argmin and no table traffic.
 // ============================================================================
+// nodeSorter.Score (plan.go:632-688) with its two NP quotients precomputed: the
+// nodeToNodeCounts one from an LDS table, the fill-factor one cached per node.
+// Same operations in the same order as node_score().
+__device__ __forceinline__ double seq_score(int cnt, int ntn, double ff, int hasw, int w, int NP, double cf,
+                                            int booster, const double* lpT) {
+    double lp = 0.0;
+    if (NP > 0) lp = (unsigned)ntn < (unsigned)kLpTab ? lpT[ntn] : (double)ntn / (double)NP;
+    double r = (double)cnt;
+    r = r + lp;
+    r = r + ff;
+    if (hasw) {
+        if (w > 0) {
+            r = r / (double)w;
+        } else if (w < 0 && booster == BLANCE_BOOSTER_CBGT) {
+            double b = (double)(-w);
+            if (b < cf) b = cf;
+            r = r + b;
+        }
+    }
+    r = r - cf;
+    return r;
+}
+
 template <int T, int NPT>
 __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
     BLANCE_DYN_LDS(lds);
@@ -22,11 +45,11 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
 
     int cntv[NPT], totv[NPT], wv[NPT], lpos[NPT];
     unsigned alive_m = 0, hasw_m = 0;
-    double g[NPT];
+    double g[NPT], ffv[NPT];                     // ffv: the fill-factor term (0.001 * total) / NP, plan.go:647-652
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         int n = tid + i * T;
-        cntv[i] = 0; totv[i] = 0; wv[i] = 0; lpos[i] = -1; g[i] = 0.0;
+        cntv[i] = 0; totv[i] = 0; wv[i] = 0; lpos[i] = -1; g[i] = 0.0; ffv[i] = 0.0;
         if (n < NX) {
             cntv[i] = q.cnt[s * NX + n];
             int tsum = 0;
@@ -37,13 +60,20 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             if (n < N && q.alive[n]) alive_m |= 1u << i;
             lpos[i] = q.node_leaf_pos[n];
             g[i] = node_score(cntv[i], 0, totv[i], (hasw_m >> i) & 1, wv[i], NP, 0.0, q.booster_kind);
+            if (NP > 0) ffv[i] = (0.001 * (double)totv[i]) / (double)NP;
         }
+    }
+    // quotient table of the nodeToNodeCounts term (plan.go:638-644), filled by the same expression
+    double* lpT = (double*)(red + 2 * (T / 64));   // [kLpTab]
+    if (NP > 0) {
+        for (int i = tid; i < kLpTab; i += T) lpT[i] = (double)i / (double)NP;
+        __syncthreads();
     }
 
     // ---- verified-stay speculation (flat passes; DESIGN.md "Verified stays"): mirrors of the
     // per-node counters that any thread may read, a first-use table of top priority nodes
     const bool spec_ok = q.spec && q.rule_begin == q.rule_end && k >= 1 && k <= kMaxK;
-    int* cntL = (int*)(red + 2 * (T / 64));        // [NX]
+    int* cntL = (int*)(lpT + kLpTab);              // [NX]
     int* totL = cntL + NX;                         // [NX]
     int* markL = totL + NX;                        // [NX + 1] lowest lane of the batch that uses the row
     int* shI = markL + NX + 1;                     // [0] first failing lane
@@ -69,8 +99,10 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
 #pragma unroll
     for (int i = 0; i < NPT; i++) ntn_pre[i] = 0;
 
+    PH_DECL;
     int oi = q.beg;
     while (oi < q.end) {
+        PH(0);
         // ---- Speculate that the next steps keep their nodes: a stay changes no counter, so
         // thread a can check step oi + a against the state as it is now.  The partition's own
         // nodes, scored exactly, must come out in list order below the smallest
@@ -155,6 +187,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             pre_row = -1;
         }
 
+        PH(1);
         if (have_next) recw = recw_next;
         else recw = lane < q.RW ? q.rec[(size_t)oi * q.RW + lane] : 0;
         have_next = oi + 1 < q.end;
@@ -198,6 +231,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         }
         pre_row = next_row;
 
+        PH(2);
         // membership of my nodes in the higher-priority lists (plan.go:146-154)
         // and in this state's current list (plan.go:654-662)
         unsigned inh_m = 0, own_m = 0;
@@ -222,17 +256,19 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         }
         const unsigned elig_m = alive_m & ~inh_m;
 
+        PH(3);
         double sc[NPT];
 #pragma unroll
         for (int i = 0; i < NPT; i++) {
             bool own = (own_m >> i) & 1;
             if (own || ntnv[i] != 0)
-                sc[i] = node_score(cntv[i], ntnv[i], totv[i], (hasw_m >> i) & 1, wv[i], NP,
-                                   own ? stick : 0.0, q.booster_kind);
+                sc[i] = seq_score(cntv[i], ntnv[i], ffv[i], (hasw_m >> i) & 1, wv[i], NP,
+                                  own ? stick : 0.0, q.booster_kind, lpT);
             else
                 sc[i] = g[i];
         }
 
+        PH(4);
         int chosen[kMaxK];
 #pragma unroll
         for (int j = 0; j < kMaxK; j++) chosen[j] = -1;
@@ -346,6 +382,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             for (int u = 0; u < NPT; u++) if (best == tid + u * T) emitted_m |= 1u << u;
         }
 
+        PH(5);
         // ---- commit (plan.go:238-245, :290-301); every thread updates the nodes it owns
         unsigned changed_m = 0;
         for (int t = 0; t < M; t++) {
@@ -396,11 +433,13 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                 }
             }
         }
+        PH(6);
         if (changed_m) {
 #pragma unroll
             for (int u = 0; u < NPT; u++)
                 if ((changed_m >> u) & 1) {
                     g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
+                    if (NP > 0) ffv[u] = (0.001 * (double)totv[u]) / (double)NP;
                     if (spec_ok) { cntL[tid + u * T] = cntv[u]; totL[tid + u * T] = totv[u]; }
                 }
         }
@@ -412,6 +451,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                 if (stay && c < k && chosen[c] != REC(kRecHead + s * SW + 1 + c)) stay = false;
             try_spec = stay;
         }
+        PH(7);
         if (tid == 0) {
             int is_nil = (n_out == 0 && q.n_alive == 0 && !any_higher_key && !q.hier);
             int* o = q.out + (size_t)oi * q.OW;
@@ -427,7 +467,9 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         }
 #undef REC
         oi++;
+        PH(8);
     }
+    PH_DUMP(q.end - q.beg);
     if (spec_ok && tid == 0 && q.spec_count) *q.spec_count += spec_steps;
 
 #pragma unroll

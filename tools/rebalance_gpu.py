@@ -21,7 +21,7 @@ def main():
     fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
     opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
                 node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
-    pl = hip.Planner()
+    pl = hip.Planner(lib_path=os.environ.get("BLANCE_DEV_LIB"), force_threads=int(os.environ.get("BLANCE_FORCE_T", "0")))   # developer builds (phase profile)
     fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
     r1 = pl.plan(fp1)
     r1 = pl.plan(fp1)
