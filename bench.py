@@ -140,7 +140,7 @@ def main():
                        "headline": bool(args.config == 3 and not args.parts and not args.nodes)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_pass_chain (state-pass kernel)", "launches": pass_launches,
+                         "kernel": "k_pass_chain / k_pass_chain_blank (state-pass kernel, one launch per replica pass)", "launches": pass_launches,
                          "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_per_launch,
                          "whole_call_algorithmic_GBps": whole,
                          "note": "algorithmic bytes are what the reference's dense per-step scan reads "

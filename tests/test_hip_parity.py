@@ -194,6 +194,28 @@ def test_config5_miniature_hierarchy(planner):
     _rebalance(planner, P=6000, N=256, hierarchy=True)
 
 
+@pytest.mark.parametrize("N", [600, 1500])
+def test_config5_wide_flat_cluster(planner, N):
+    """Flat clusters beyond one wave64's reach: the workgroup pass (k_pass_seq) with
+    verified-stay speculation, weights and stickiness; same answer with it switched off."""
+    r1, r2 = _rebalance(planner, P=5000, N=N, hierarchy=False)
+    assert r2.struct.steps_batched > 0
+    plain = hip.Planner(device_id=0, seq_speculation=False)
+    p1, p2 = _rebalance(plain, P=5000, N=N, hierarchy=False)
+    plain.close()
+    assert (p1.digest(), p2.digest()) == (r1.digest(), r2.digest())
+
+
+def test_wide_hierarchy_regions(planner):
+    """Zones of 320 nodes: 5 leaves per lane of the region's wave64."""
+    c = synth.config_case(3, P=6000, N=1300)
+    c["nodeHierarchy"] = synth.hierarchy_names(1300, rack=16, racks_per_zone=20, zones_per_dc=2)
+    fp = synth.case_to_flat(c)
+    got = planner.plan(fp)
+    _same(got, _oracle(fp), "zones of 320")
+    assert got.struct.steps_batched > 0
+
+
 def test_resident_replan_is_deterministic(planner):
     fp = synth.config_flat(3, P=8192, N=512)
     planner.upload(fp)

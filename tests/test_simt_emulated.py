@@ -162,6 +162,41 @@ def test_rebalance_miniature(emu_lib):
     pl.close()
 
 
+def test_sequential_pass_speculation(emu_lib):
+    """k_pass_seq on a flat cluster too wide for one wave64 (300 nodes): verified stays are
+    committed in batches, the other steps one by one; bit-exact with and without."""
+    c = synth.rebalance_case(P=300, N=300, hierarchy=False)
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=None, hierarchy_rules=None)
+    fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
+    digests = []
+    for spec in (True, False):
+        pl = hip.Planner(lib_path=emu_lib, seq_speculation=spec)
+        r1 = pl.plan(fp1)
+        assert r1.digest() == _oracle(fp1).digest()
+        plan1, _ = problem.decode_result(fp1, r1)
+        fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+        r2 = pl.plan(fp2)
+        assert r2.digest() == _oracle(fp2).digest()
+        assert (r2.struct.steps_batched > 300) == spec       # beyond the primary pass's bulk stays
+        digests.append(r2.digest())
+        pl.close()
+    assert digests[0] == digests[1]
+
+
+def test_wide_hierarchy_regions(emu_lib):
+    """Regions of 320 leaves: 5 leaves per lane of the region's wave64."""
+    c = synth.config_case(3, P=300, N=700)
+    c["nodeHierarchy"] = synth.hierarchy_names(700, rack=16, racks_per_zone=20, zones_per_dc=2)
+    fp = synth.case_to_flat(c)
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=8)
+    got = pl.plan(fp)
+    assert got.digest() == _oracle(fp).digest()
+    assert got.struct.steps_batched > 0
+    pl.close()
+
+
 def test_several_nodes_per_thread(emu_lib):
     """NX > T exercises the NPT > 1 register tiles."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64)
