@@ -125,6 +125,13 @@ def main():
             with open(prof) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         whole = synth.algorithmic_bytes_per_sweep(fp) * iterations * args.steps / (device_ms * 1e-3) / 1e9
+        # what actually bounds the kernel: the dependent chain of one region
+        critical = None
+        if args.config == 3 and pass_launches:
+            regions = -(-N // 128)                                # zones of 8 racks x 16 nodes
+            chain_steps = -(-P // regions)
+            critical = {"regions": regions, "dependent_steps_per_launch": chain_steps,
+                        "avg_ns_per_dependent_step": avg_launch_ms * 1e6 / chain_steps}
         out = {
             "metric": "partition-state assignments/sec at 1M partitions x 4,096 nodes",
             "value": value, "unit": "assignments/s", "n_gpus": world, "steps": args.steps,
@@ -142,7 +149,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_pass_chain / k_pass_chain_blank (state-pass kernel, one launch per replica pass)", "launches": pass_launches,
                          "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_per_launch,
-                         "whole_call_algorithmic_GBps": whole,
+                         "whole_call_algorithmic_GBps": whole, "critical_path": critical,
                          "note": "algorithmic bytes are what the reference's dense per-step scan reads "
                                  "(SURVEY.md 8d); the kernel keeps tables in registers/LDS and resolves "
                                  "verified stays in bulk, so measured HBM traffic is far below them"},
