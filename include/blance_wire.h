@@ -19,8 +19,9 @@
  *     UTF-8 become U+FFFD;
  *   - a value of the wrong JSON type, or malformed JSON, is an error (no partial result).
  * Encoding follows encoding/json.Marshal (Go >= 1.22): map keys sorted bytewise, struct
- * fields in declaration order, compact, HTML-safe escapes (< > &),
- *    , control characters as \b \f \n \r \t or \u00XX, invalid UTF-8 -> �.
+ * fields in declaration order, compact, HTML-safe escapes (< > & as \u003c \u003e \u0026),
+ * U+2028 / U+2029 as \u2028 / \u2029, control characters as \b \f \n \r \t or \u00XX,
+ * invalid UTF-8 bytes as \ufffd.
  *
  * All arrays returned by the accessors are owned by the blance_wire_map and live until
  * blance_wire_free().  Lists are kept per (partition, state entry) in document order.
