@@ -519,35 +519,46 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     return BLANCE_OK;
 }
 
+template <int T, int NPT, bool HIER, int KM>
+static void launch_pass_v(blance_ctx* c, const PassParams& q, size_t lds) {
+    auto kern = k_pass_seq<T, NPT, HIER, KM>;
+    BLANCE_LAUNCH(kern, 1, T, lds, c->stream, q);
+}
+
 template <int T, int NPT>
 static void launch_pass(blance_ctx* c, PassParams q) {
     size_t lds = sizeof(RedSlot) * 2 * (T / 64) + sizeof(double) * kLpTab + 64;
     // flat passes: LDS mirrors for the verified-stay speculation (k_pass_seq.h)
     const size_t mirrors = sizeof(int32_t) * (3 * (size_t)q.NX + 4) + 32;
-    q.spec = (q.rule_begin == q.rule_end && !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL &&
+    const bool rules = q.rule_begin < q.rule_end;
+    q.spec = (!rules && !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL &&
               lds + mirrors <= 150 * 1024) ? 1 : 0;
     if (q.spec) lds += mirrors;
-    auto kern = k_pass_seq<T, NPT>;
-    BLANCE_LAUNCH(kern, 1, T, lds, c->stream, q);
+    if (rules) {
+        if (q.k <= 2) launch_pass_v<T, NPT, true, 2>(c, q, lds);
+        else launch_pass_v<T, NPT, true, kMaxK>(c, q, lds);
+    } else {
+        if (q.k <= 2) launch_pass_v<T, NPT, false, 2>(c, q, lds);
+        else launch_pass_v<T, NPT, false, kMaxK>(c, q, lds);
+    }
 }
 
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
-    // T threads own NPT nodes each (register resident); one workgroup runs the pass.
+    // T threads own NPT nodes each (register resident); one workgroup runs the pass.  A step is a
+    // chain of dependent instructions in every wave (about 11 cycles each, measured), so the
+    // width costs little: 2.7 us / step at 256 and 1,024 nodes, 3.7 at 4,096.
     const int NX = q.NX > 0 ? q.NX : 1;
-    // measured: N = 1024: 3.1 us/step with 256 threads vs 4.0 with 1024; N = 4096: 5.9 (256 x 16) vs 4.8 (1024 x 4)
     int T = c->force_threads;
     if (T != 64 && T != 256 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 256 : 1024);
     if (T == 64 && NX > 256) T = 256;
-    if (T == 256 && NX > 4096) T = 1024;
+    if (T == 256 && NX > 1024) T = 1024;
     const int npt = cdiv(NX, T);
     if (T == 64) {
         if (npt <= 1) launch_pass<64, 1>(c, q);
         else launch_pass<64, 4>(c, q);
     } else if (T == 256) {
         if (npt <= 1) launch_pass<256, 1>(c, q);
-        else if (npt <= 4) launch_pass<256, 4>(c, q);
-        else if (npt <= 8) launch_pass<256, 8>(c, q);
-        else launch_pass<256, 16>(c, q);
+        else launch_pass<256, 4>(c, q);
     } else {
         if (npt <= 2) launch_pass<1024, 2>(c, q);
         else if (npt <= 4) launch_pass<1024, 4>(c, q);

@@ -137,6 +137,17 @@ __device__ __forceinline__ unsigned long long sortable_bits(double s) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store of the wave (vmcnt(0)) -- that would put the latency of
+// the record / row prefetches, issued precisely to overlap with the step, on every argmin.
+__device__ __forceinline__ void lds_barrier() {
+#ifndef BLANCE_SIMT_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // Lexicographic (score, position) argmin over a workgroup of T threads; callers pass
 // (+inf, INT_MAX) for "no candidate".  Per wave: three 32-bit DPP minima (high word,
 // low word of the score's integer image, position) -- the same total order as
@@ -161,7 +172,7 @@ __device__ __forceinline__ int block_argmin(double s, int n, RedSlot* red, int& 
         slot[threadIdx.x >> 6].lo = ml;
         slot[threadIdx.x >> 6].n = (int)mn;
     }
-    __syncthreads();
+    lds_barrier();
     // second stage: lane l takes wave (l mod W)'s slot; W <= 16 slots sit in one DPP row
     const RedSlot mine = slot[threadIdx.x & (W - 1)];
     const unsigned bh = row_min_u32<W>(mine.hi);

@@ -34,7 +34,10 @@ __device__ __forceinline__ double seq_score(int cnt, int ntn, double ff, int has
     return r;
 }
 
-template <int T, int NPT>
+// HIER: the state has hierarchy rules (plan.go:174-226); the variant without carries none of that
+// code or its uniform state (it more than halves the kernel's scalar-register spills).
+// KM: capacity of the step's output list (k <= KM); the k <= 2 variant keeps the bookkeeping short.
+template <int T, int NPT, bool HIER, int KM>
 __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
     BLANCE_DYN_LDS(lds);
     RedSlot* red = (RedSlot*)lds;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
 
     // ---- verified-stay speculation (flat passes; DESIGN.md "Verified stays"): mirrors of the
     // per-node counters that any thread may read, a first-use table of top priority nodes
-    const bool spec_ok = q.spec && q.rule_begin == q.rule_end && k >= 1 && k <= kMaxK;
+    const bool spec_ok = q.spec && q.rule_begin == q.rule_end && k >= 1 && k <= KM;
     int* cntL = (int*)(lpT + kLpTab);              // [NX]
     int* totL = cntL + NX;                         // [NX]
     int* markL = totL + NX;                        // [NX + 1] lowest lane of the batch that uses the row
@@ -125,9 +128,9 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                 const int B = q.end - oi < T ? q.end - oi : T;
                 const bool active = tid < B;
                 bool fail = false;
-                int own[kMaxK];
+                int own[KM];
 #pragma unroll
-                for (int j = 0; j < kMaxK; j++) own[j] = 0;
+                for (int j = 0; j < KM; j++) own[j] = 0;
                 int vrow = NX;
                 if (active) {
                     const int32_t* r = q.rec + (size_t)(oi + tid) * q.RW;
@@ -139,7 +142,9 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                     if (!fail) {
                         double prev_s = 0.0;
                         int prev_n = -1;
-                        for (int j = 0; j < k; j++) {
+#pragma unroll
+                        for (int j = 0; j < KM; j++) {
+                            if (j >= k || fail) break;
                             const int o = r[kRecHead + s * SW + 1 + j];
                             own[j] = o;
                             if (o >= N || !q.alive[o]) { fail = true; break; }
@@ -172,9 +177,12 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                 if (tid < nok) {
                     int* o = q.out + (size_t)(oi + tid) * q.OW;
                     o[0] = k;
-                    for (int j = 0; j < k; j++) {
-                        o[1 + j] = own[j];
-                        if (NP > 0) q.ntn[(size_t)vrow * N + own[j]] += 1;        // plan.go:238-245
+#pragma unroll
+                    for (int j = 0; j < KM; j++) {
+                        if (j < k) {
+                            o[1 + j] = own[j];
+                            if (NP > 0) q.ntn[(size_t)vrow * N + own[j]] += 1;    // plan.go:238-245
+                        }
                     }
                 }
                 __syncthreads();
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         PH(2);
         // membership of my nodes in the higher-priority lists (plan.go:146-154)
         // and in this state's current list (plan.go:654-662)
-        unsigned inh_m = 0, own_m = 0;
+        unsigned inh_m = 0, own_m = 0, oth_m = 0;    // oth_m: held in another state of this partition
         int any_higher_key = 0;
         for (int t = 0; t < M; t++) {
             int hdr = REC(kRecHead + t * SW);
@@ -242,15 +250,14 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             int len = hdr & 0xffff;
             bool higher = (q.higher_mask >> t) & 1;
             if (higher) any_higher_key = 1;
-            if (!higher && t != s) continue;
             for (int j = 0; j < len; j++) {
                 int x = REC(kRecHead + t * SW + 1 + j);
 #pragma unroll
                 for (int i = 0; i < NPT; i++) {
-                    if (x == tid + i * T) {
-                        if (higher) inh_m |= 1u << i;
-                        if (t == s) own_m |= 1u << i;
-                    }
+                    const unsigned hit = (x == tid + i * T ? 1u : 0u) << i;
+                    inh_m |= higher ? hit : 0u;
+                    own_m |= t == s ? hit : 0u;
+                    oth_m |= t != s ? hit : 0u;
                 }
             }
         }
@@ -269,13 +276,13 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
         }
 
         PH(4);
-        int chosen[kMaxK];
+        int chosen[KM];
 #pragma unroll
-        for (int j = 0; j < kMaxK; j++) chosen[j] = -1;
+        for (int j = 0; j < KM; j++) chosen[j] = -1;
         int n_out = 0;
         unsigned emitted_m = 0;                    // my nodes already in the output list
 
-        if (q.hier) {                              // plan.go:174-226
+        if (HIER && q.hier) {                      // plan.go:174-226
             int hn[kMaxAnchors];
 #pragma unroll
             for (int j = 0; j < kMaxAnchors; j++) hn[j] = -1;
@@ -352,10 +359,10 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
                     int x = hn[j];
                     bool dup = false;
 #pragma unroll
-                    for (int c = 0; c < kMaxK; c++) if (c < n_out && chosen[c] == x) dup = true;
+                    for (int c = 0; c < KM; c++) if (c < n_out && chosen[c] == x) dup = true;
                     if (!dup) {
 #pragma unroll
-                        for (int c = 0; c < kMaxK; c++) if (c == n_out) chosen[c] = x;
+                        for (int c = 0; c < KM; c++) if (c == n_out) chosen[c] = x;
                         n_out++;
 #pragma unroll
                         for (int u = 0; u < NPT; u++) if (x == tid + u * T) emitted_m |= 1u << u;
@@ -376,62 +383,50 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             int best = uni(block_argmin<T>(bs, bn, red, round));
             if (best == INT_MAX) break;
 #pragma unroll
-            for (int c = 0; c < kMaxK; c++) if (c == n_out) chosen[c] = best;
+            for (int c = 0; c < KM; c++) if (c == n_out) chosen[c] = best;
             n_out++;
 #pragma unroll
             for (int u = 0; u < NPT; u++) if (best == tid + u * T) emitted_m |= 1u << u;
         }
 
         PH(5);
-        // ---- commit (plan.go:238-245, :290-301); every thread updates the nodes it owns
+        // ---- commit (plan.go:238-245, :290-301); every thread updates the nodes it owns:
+        // a node of this state's old list leaves it (:290-293), a chosen node enters it (:299-301),
+        // and a node that is either of those also leaves every OTHER state list of the partition
+        // that holds it (:290-297 -- the reference walks all states' lists)
         unsigned changed_m = 0;
-        for (int t = 0; t < M; t++) {
-            int hdr = REC(kRecHead + t * SW);
-            if ((hdr >> 16) == kListAbsent) continue;
-            int len = hdr & 0xffff;
-            for (int j = 0; j < len; j++) {
-                int x = REC(kRecHead + t * SW + 1 + j);
-                bool hit = (t == s);
-                if (!hit) {
-                    // x also held this state (plan.go:290-293) or was chosen now (plan.go:294-297)
-                    int hs = REC(kRecHead + s * SW);
-                    if ((hs >> 16) != kListAbsent) {
-                        int ls = hs & 0xffff;
-                        for (int jj = 0; jj < ls; jj++)
-                            if (REC(kRecHead + s * SW + 1 + jj) == x) hit = true;
-                    }
+        {
+            const unsigned moved_m = (own_m | emitted_m) & oth_m;      // rare: promotions / demotions
+            if (__ballot(moved_m != 0)) {
+                for (int t = 0; t < M; t++) {
+                    if (t == s) continue;
+                    int hdr = REC(kRecHead + t * SW);
+                    if ((hdr >> 16) == kListAbsent) continue;
+                    int len = hdr & 0xffff;
+                    for (int j = 0; j < len; j++) {
+                        int x = REC(kRecHead + t * SW + 1 + j);
 #pragma unroll
-                    for (int c = 0; c < kMaxK; c++) if (c < n_out && chosen[c] == x) hit = true;
-                }
-                if (!hit) continue;
-#pragma unroll
-                for (int u = 0; u < NPT; u++) {
-                    if (x == tid + u * T) {
-                        totv[u] -= w;
-                        if (t == s) cntv[u] -= w;
-                        changed_m |= 1u << u;
-                    }
-                }
-                if (t != s && tid == 0) q.cnt[t * NX + x] -= w;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < kMaxK; c++) {
-            if (c < n_out) {
-                int x = chosen[c];
-#pragma unroll
-                for (int u = 0; u < NPT; u++) {
-                    if (x == tid + u * T) {
-                        cntv[u] += w;
-                        totv[u] += w;
-                        changed_m |= 1u << u;
-                        if (NP > 0) {                                           // plan.go:238-245
-                            q.ntn[(size_t)row * N + x] = ntnv[u] + 1;
-                            if (next_row == row) ntn_pre[u] = ntnv[u] + 1;
+                        for (int u = 0; u < NPT; u++) {
+                            if (((moved_m >> u) & 1) && x == tid + u * T) {
+                                totv[u] -= w;
+                                q.cnt[t * NX + x] -= w;             // only this thread touches the node's counters
+                                changed_m |= 1u << u;
+                            }
                         }
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < NPT; u++) {
+                const int leave = ((own_m >> u) & 1) ? w : 0, enter = ((emitted_m >> u) & 1) ? w : 0;
+                cntv[u] += enter - leave;
+                totv[u] += enter - leave;
+                if (NP > 0 && ((emitted_m >> u) & 1)) {                   // plan.go:238-245
+                    q.ntn[(size_t)row * N + tid + u * T] = ntnv[u] + 1;
+                    if (next_row == row) ntn_pre[u] = ntnv[u] + 1;
+                }
+            }
+            changed_m |= own_m | emitted_m;
         }
         PH(6);
         if (changed_m) {
@@ -447,7 +442,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             int hs = REC(kRecHead + s * SW);
             bool stay = (hs >> 16) != kListAbsent && (hs & 0xffff) == k && n_out == k;
 #pragma unroll
-            for (int c = 0; c < kMaxK; c++)
+            for (int c = 0; c < KM; c++)
                 if (stay && c < k && chosen[c] != REC(kRecHead + s * SW + 1 + c)) stay = false;
             try_spec = stay;
         }
@@ -457,7 +452,7 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
             int* o = q.out + (size_t)oi * q.OW;
             o[0] = n_out | (is_nil << 16);
 #pragma unroll
-            for (int c = 0; c < kMaxK; c++) if (c < k) o[1 + c] = chosen[c];
+            for (int c = 0; c < KM; c++) if (c < k) o[1 + c] = chosen[c];
             if (n_out < k) {                       // plan.go:230-235
                 int wi = *q.warn_count;
                 q.warn_part[wi] = p;

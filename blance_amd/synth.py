@@ -236,3 +236,25 @@ def rebalance_case(P=4096, N=128, seed=5, remove_frac=0.1, add_frac=0.1, hierarc
         case["nodeHierarchy"] = hierarchy_names(N)
         case["hierarchyRules"] = {"replica": [{"includeLevel": 2, "excludeLevel": 1}]}
     return case
+
+
+def _config5_opts(c):
+    return dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
+
+
+def config5_initial(P=1048576, N=4096, hierarchy=False):
+    """BASELINE.json config 5, first half: the plan over the old nodes that the rebalance
+    starts from (fresh partitions, weights, stickiness).  Goes through the interning layer."""
+    c = rebalance_case(P=P, N=N, hierarchy=hierarchy)
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    return problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **_config5_opts(c))
+
+
+def config5_rebalance(fp1, res1, P=1048576, N=4096, hierarchy=False):
+    """Config 5 proper: prevMap = partitionsToAssign = the plan `res1` of config5_initial's
+    problem `fp1`; a tenth of the nodes removed, a tenth added."""
+    c = rebalance_case(P=P, N=N, hierarchy=hierarchy)
+    plan1, _ = problem.decode_result(fp1, res1)
+    return problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"],
+                                 **_config5_opts(c))
