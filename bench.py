@@ -33,6 +33,22 @@ def cpu_baseline(parts, nodes, cfg):
     cost is O(nodes), so assignments/s carries over to the full size."""
     from blance_amd import synth
     from oracle import loader
+    if cfg == 5:
+        # config 5 (weighted rebalance, 10 sweeps): 1/32 of the partitions; the plan it starts
+        # from is made on the GPU (untimed), the oracle is timed on the rebalance only
+        from blance_amd import hip
+        sample_parts = max(1024, parts // 32)
+        fp1 = synth.config5_initial(sample_parts, nodes)
+        pl = hip.Planner()
+        fp = synth.config5_rebalance(fp1, pl.plan(fp1), sample_parts, nodes)
+        pl.close()
+        t0 = time.perf_counter()
+        res = loader.plan(fp)
+        dt = time.perf_counter() - t0
+        return {"value": synth.assignments(fp) / dt, "unit": "assignments/s", "cores": 1, "kind": "port",
+                "sample": "oracle/blance_oracle.c, the rebalance PlanNextMap (%d sweeps) on %d partitions x %d nodes "
+                          "(1/32 of the partitions, same generator), %.1f s" % (res.iterations, sample_parts, nodes, dt),
+                "host_cpus": os.cpu_count()}
     sample_parts = max(1024, parts // 4)
     fp = synth.config_flat(cfg, P=sample_parts, N=nodes)
     t0 = time.perf_counter()
@@ -50,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config (2 or 3)")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config: 3 (headline), 2, or 5 (weighted rebalance; ~40 s per step)")
     ap.add_argument("--parts", type=int, default=0, help="override partition count (not the headline)")
     ap.add_argument("--nodes", type=int, default=0, help="override node count (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -68,9 +84,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from blance_amd import dist_util, hip, synth
-    fp = synth.config_flat(args.config, P=args.parts or None, N=args.nodes or None)
-    P, N = fp.n_parts, fp.n_nodes
     pl = hip.Planner(device_id=local_rank)          # raises without the HIP library / a device
+    if args.config == 5:                            # the rebalance starts from a plan over the old nodes (setup, untimed)
+        fp1 = synth.config5_initial(args.parts or 1 << 20, args.nodes or 4096)
+        fp = synth.config5_rebalance(fp1, pl.plan(fp1), args.parts or 1 << 20, args.nodes or 4096)
+        del fp1
+    else:
+        fp = synth.config_flat(args.config, P=args.parts or None, N=args.nodes or None)
+    P, N = fp.n_parts, fp.n_nodes
     t0 = time.perf_counter()
     pl.upload(fp)
     upload_s = time.perf_counter() - t0
@@ -139,8 +160,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json config %d: %d partitions x %d nodes, %s"
                                    % (args.config, P, N,
-                                      "primary+2 replicas, 3-level rack/zone/DC hierarchy, rule replica{include 2, exclude 1}"
-                                      if args.config == 3 else "primary+1 replica, flat"),
+                                      {3: "primary+2 replicas, 3-level rack/zone/DC hierarchy, rule replica{include 2, exclude 1}",
+                                       5: "primary+2 replicas, flat, Zipf partition weights, node weights, stickiness; rebalance "
+                                          "after removing and adding a tenth of the nodes, prevMap = the plan over the old nodes"}
+                                      .get(args.config, "primary+1 replica, flat")),
                        "partitions": P, "nodes": N, "assignments_per_call": assignments,
                        "sweeps_per_call": iterations, "parallelism": "replicas x%d" % world,
                        "steps_bulk": int(batched), "steps_one_by_one": int(sequential),
@@ -164,12 +187,12 @@ def main():
             with open(ref) as f:
                 want = json.load(f).get("config%d" % args.config)
             if want:
-                out["matches_oracle_digest"] = want["digest"] == digest
+                out["matches_oracle_digest"] = (want["rebalance"] if args.config == 5 else want)["digest"] == digest
         if args.verify:
             from oracle import loader
             out["matches_oracle"] = loader.plan(fp).digest() == digest
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, N, args.config)
+            out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config)
         print(json.dumps(out), flush=True)
     pl.close()
     if dist is not None:

@@ -433,8 +433,8 @@ __global__ __launch_bounds__(T) void k_pass_seq(PassParams q) {
 #pragma unroll
             for (int u = 0; u < NPT; u++)
                 if ((changed_m >> u) & 1) {
-                    g[u] = node_score(cntv[u], 0, totv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind);
                     if (NP > 0) ffv[u] = (0.001 * (double)totv[u]) / (double)NP;
+                    g[u] = seq_score(cntv[u], 0, ffv[u], (hasw_m >> u) & 1, wv[u], NP, 0.0, q.booster_kind, lpT);
                     if (spec_ok) { cntL[tid + u * T] = cntv[u]; totL[tid + u * T] = totv[u]; }
                 }
         }

@@ -216,6 +216,36 @@ def test_wide_hierarchy_regions(planner):
     assert got.struct.steps_batched > 0
 
 
+def _golden_digests():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")) as f:
+        return json.load(f)
+
+
+def test_config3_full_size_digest(planner):
+    """BASELINE.json's headline configuration at its full size (1,048,576 x 4,096): the result's
+    SHA-256 equals the CPU oracle's (tools/make_config_digests.py, 141 s on one core)."""
+    want = _golden_digests()["config3"]
+    got = planner.plan(synth.config_flat(3))
+    assert (got.iterations, got.n_warnings) == (want["iterations"], want["warnings"])
+    assert got.digest() == want["digest"]
+
+
+def test_config5_full_size_digest(planner):
+    """Config 5 at its full size: weighted plan over the old nodes, then the rebalance from it
+    (10 sweeps each, about 70 s of device time); digests from tools/make_config5_digest.py
+    (the CPU oracle needs 8 minutes for each)."""
+    want = _golden_digests()["config5"]
+    P, N = want["partitions"], want["nodes"]
+    fp1 = synth.config5_initial(P, N)
+    r1 = planner.plan(fp1)
+    assert (r1.iterations, r1.digest()) == (want["initial"]["iterations"], want["initial"]["digest"])
+    fp2 = synth.config5_rebalance(fp1, r1, P, N)
+    r2 = planner.plan(fp2)
+    assert (r2.iterations, r2.digest()) == (want["rebalance"]["iterations"], want["rebalance"]["digest"])
+
+
 def test_resident_replan_is_deterministic(planner):
     fp = synth.config_flat(3, P=8192, N=512)
     planner.upload(fp)

@@ -91,7 +91,7 @@ def test_region_chains(emu_lib):
     verified-stay speculation) and its escape to the sequential pass."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     chains = 0
-    for seed in range(0, 300):
+    for seed in range(0, 130):               # the GPU suite walks 800 of these (tests/test_hip_parity.py)
         try:
             fp = build_from_case(random_regular_case(seed))
         except problem.Unsupported:
@@ -99,7 +99,7 @@ def test_region_chains(emu_lib):
         got = pl.plan(fp)
         assert got.digest() == _oracle(fp).digest(), seed
         chains += got.struct.steps_batched > 0
-    assert chains >= 150
+    assert chains >= 60
     fp = synth.config_flat(3, P=160, N=200)
     got = pl.plan(fp)
     assert got.digest() == _oracle(fp).digest() and got.struct.steps_batched > 0
@@ -109,7 +109,7 @@ def test_region_chains(emu_lib):
 def test_random_instances_bulk_engines(emu_lib):
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     n = bulk = 0
-    for seed in range(600, 1200):
+    for seed in range(600, 860):             # the GPU suite walks 1,000 of these
         try:
             fp = build_from_case(random_case(seed))
         except problem.Unsupported:
@@ -118,7 +118,7 @@ def test_random_instances_bulk_engines(emu_lib):
         assert got.digest() == _oracle(fp).digest(), seed
         n += 1
         bulk += got.struct.steps_batched > 0
-    assert n > 400 and bulk > 100
+    assert n > 170 and bulk > 40
     pl.close()
 
 
