@@ -194,7 +194,7 @@ def test_config5_miniature_hierarchy(planner):
     _rebalance(planner, P=6000, N=256, hierarchy=True)
 
 
-@pytest.mark.parametrize("N", [600, 1500])
+@pytest.mark.parametrize("N", [600, 1500, 5000])
 def test_config5_wide_flat_cluster(planner, N):
     """Flat clusters beyond one wave64's reach: the workgroup pass (k_pass_seq) with
     verified-stay speculation, weights and stickiness; same answer with it switched off."""
