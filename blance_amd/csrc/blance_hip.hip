@@ -575,7 +575,17 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
     unsigned long long* kb = c->f_keys_b.as<unsigned long long>();
     int32_t* va = c->f_vals_a.as<int32_t>();
     int32_t* vb = c->f_vals_b.as<int32_t>();
+    // byte positions equal in every key need no pass (scores of one pass share most of their bits)
+    unsigned long long* vbits = (unsigned long long*)(c->scalars.as<int32_t>() + 14);
+    unsigned long long varying = 0;
+    HIPTRY(hipMemsetAsync(vbits, 0, sizeof varying, c->stream));
+    BLANCE_LAUNCH(k_sort_varbits, cdiv(n, 256), 256, 0, c->stream, n, ka, vbits);
+    HIPTRY(hipMemcpyAsync(&varying, vbits, sizeof varying, hipMemcpyDeviceToHost, c->stream));
+    HIPTRY(hipStreamSynchronize(c->stream));
+    *launches += 1;
+    int done = 0;
     for (int shift = 0; shift < 64; shift += 8) {
+        if (((varying >> shift) & 0xff) == 0) continue;
         BLANCE_LAUNCH(k_sort_hist, n_tiles, 64, 1024 + 64, c->stream, n, shift, ka, n_tiles, c->f_hist.as<int32_t>());
         BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, 256 * n_tiles, c->f_hist.as<int32_t>());
         BLANCE_LAUNCH(k_sort_scatter, n_tiles, 64, 1024 + 64, c->stream, n, shift, ka, va, kb, vb, n_tiles,
@@ -583,8 +593,13 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
         std::swap(ka, kb);
         std::swap(va, vb);
         *launches += 3;
+        done++;
     }
-    return 0;                                       // 8 passes: the data is back in the *_a buffers
+    if (done & 1) {                                  // callers read the *_a buffers
+        HIPTRY(hipMemcpyAsync(kb, ka, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        HIPTRY(hipMemcpyAsync(vb, va, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
 }
 
 static int dispatch_pass(blance_ctx* c, const PassParams& q);
@@ -668,7 +683,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
         }
         int32_t init[2] = {INT_MAX, INT_MAX};
         HIPTRY(hipMemcpyAsync(scal + 8, init, sizeof init, hipMemcpyHostToDevice, sm));
-        BLANCE_LAUNCH_NOSYNC(k_flat_scan, cdiv(P - pos, 256), 256, 0, sm, fq, pos, P);
+        BLANCE_LAUNCH(k_flat_scan, cdiv(P - pos, 256), 256, 0, sm, fq, pos, P);
         int32_t got[2] = {0, 0};
         HIPTRY(hipMemcpyAsync(got, scal + 8, sizeof got, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipStreamSynchronize(sm));

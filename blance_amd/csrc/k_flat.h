@@ -81,9 +81,16 @@ __global__ void k_flat_row_count(FlatParams q, int32_t* row_count) {
 
 // Classify the steps [beg, end): record the first one that is not a certain
 // stay and the first one that is not "fresh identical" to step beg.
+// first lane of the wave for which `flag` holds publishes its step index (pass order rises with the lane)
+__device__ __forceinline__ void scan_note_first(bool flag, int oi, int* slot) {
+    const unsigned long long m = __ballot(flag);
+    if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1 && oi < *(volatile int*)slot) atomicMin(slot, oi);
+}
+
 __global__ void k_flat_scan(FlatParams q, int beg, int end) {
     int oi = beg + blockIdx.x * blockDim.x + threadIdx.x;
-    if (oi >= end) return;
+    const bool in_range = oi < end;
+    if (!in_range) oi = end - 1;                     // keep the wave whole for the ballots below
     const int SW = 1 + q.L;
     const int32_t* r = q.rec + (size_t)oi * q.RW;
     const int w = r[1];
@@ -102,7 +109,7 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
         const int32_t* r0 = q.rec + (size_t)beg * q.RW;
         // no node anywhere: nothing to exclude, demote or promote (plan.go:290-297)
         bool fresh = q.k == 1 && all_len == 0 && w > 0 && w == r0[1] && top < 0;
-        if (!fresh) atomicMin(&q.scan[1], oi);
+        scan_note_first(in_range && !fresh, oi, &q.scan[1]);
     }
     // ---- certain stay?
     bool stay = false;
@@ -136,7 +143,7 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
             }
         }
     }
-    if (!stay) atomicMin(&q.scan[0], oi);
+    scan_note_first(in_range && !stay, oi, &q.scan[0]);
 }
 
 // commit a run of certain stays: the lists do not change; nodeToNodeCounts does (plan.go:238-245)
@@ -181,13 +188,28 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
     const int tid = threadIdx.x;
     const int w = q.rec[(size_t)beg * q.RW + 1];
     unsigned long long lo = 0, hi = ~0ull;           // smallest tau with total(tau) >= R
+    // per node: count_le(lo - 1) and count_le(hi) bracket count_le(mid) of every later probe, so
+    // the inner searches shrink with the outer one (a node's count is monotone in tau)
+    constexpr int kPer = 8;                          // N <= 8192 = 8 * 1024
+    int c_lo[kPer], c_hi[kPer], c_mid[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; i++) { c_lo[i] = 0; c_hi[i] = R; c_mid[i] = 0; }
     while (lo < hi) {
         unsigned long long mid = lo + (hi - lo) / 2;
         long long sum = 0;
-        for (int n = tid; n < q.N; n += 1024) {
-            if (!q.alive[n]) continue;
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            const int n = tid + i * 1024;
+            if (n >= q.N || !q.alive[n]) continue;
             int ntn0 = q.NP > 0 ? q.ntn[(size_t)q.NX * q.N + n] : 0;
-            sum += fresh_count_le(q, n, q.cnt[q.s * q.NX + n], q.tot[n], ntn0, w, R, mid);
+            const int c0 = q.cnt[q.s * q.NX + n], t0 = q.tot[n];
+            int a = c_lo[i], b = c_hi[i];            // first c in [a, b] with key > mid
+            while (a < b) {
+                int m = a + (b - a) / 2;
+                if (fresh_key(q, n, c0, t0, ntn0, w, m) <= mid) a = m + 1; else b = m;
+            }
+            c_mid[i] = a;
+            sum += a;
         }
         part[tid] = sum;
         __syncthreads();
@@ -197,7 +219,15 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
         }
         long long total = part[0];
         __syncthreads();
-        if (total >= R) hi = mid; else lo = mid + 1;
+        if (total >= R) {
+            hi = mid;
+#pragma unroll
+            for (int i = 0; i < kPer; i++) c_hi[i] = c_mid[i];
+        } else {
+            lo = mid + 1;
+#pragma unroll
+            for (int i = 0; i < kPer; i++) c_lo[i] = c_mid[i];
+        }
     }
     const unsigned long long tau = lo;
     // picks strictly below tau, then the ties at tau in node order
@@ -304,6 +334,23 @@ __device__ __forceinline__ unsigned long long same_digit_lanes(int digit, bool v
         peers &= ((digit >> b) & 1) ? m : ~m;
     }
     return peers;
+}
+
+// bits in which the keys differ from keys[0]: byte positions that are equal everywhere need no pass
+__global__ void k_sort_varbits(int n, const unsigned long long* keys, unsigned long long* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = i < n ? (keys[i] ^ keys[0]) : 0ull;
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo |= (unsigned)__shfl_xor((int)lo, off, 64);
+        hi |= (unsigned)__shfl_xor((int)hi, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long bits = ((unsigned long long)hi << 32) | lo;
+        // most waves bring nothing new: look before paying for a contended atomic
+        if (bits & ~*(volatile unsigned long long*)out) atomicOr(out, bits);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_sort_hist(int n, int shift, const unsigned long long* keys, int n_tiles,

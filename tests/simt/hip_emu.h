@@ -238,6 +238,7 @@ inline int __double2hiint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int
 
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 inline int atomicMin(int* p, int v) {
     int old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
