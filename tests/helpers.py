@@ -29,3 +29,40 @@ def run_c_oracle(c):
     res = loader.plan(fp)
     out, w = problem.decode_result(fp, res)
     return out, w, {"iterations": res.iterations, "converged": res.converged}, fp, res
+
+
+def edge_cases():
+    """(args, kwargs) of problem.build_problem for degenerate and unusual inputs."""
+    from blance_amd import synth
+    M1 = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": 2}}
+    fresh = lambda P: {str(i): {"name": str(i), "nodesByState": {}} for i in range(P)}     # noqa: E731
+    hier24 = synth.hierarchy_names(24, rack=4, racks_per_zone=3, zones_per_dc=2, width=2)
+    n24 = ["n%02d" % i for i in range(24)]
+    prev = {str(i): {"name": str(i), "nodesByState": {"primary": ["n%d" % (i % 3)],
+                                                      "replica": ["n%d" % ((i + 1) % 3), "gone"]}} for i in range(30)}
+    cases = [
+        (({}, {}, ["a", "b"], [], ["a", "b"], M1), {}),
+        (({}, fresh(5), [], [], [], M1), {}),
+        (({}, fresh(5), ["a"], [], ["a"], M1), {}),
+        (({}, fresh(5), ["a", "b", "c"], [], [], M1), {"max_iterations": 0}),
+        (({}, fresh(5), ["a", "b", "c"], [], [], M1), {"max_iterations": 1}),
+        (({}, fresh(5), ["a", "b", "c"], [], [], {"primary": {"priority": 0, "constraints": 0},
+                                                  "replica": {"priority": 1, "constraints": 0}}), {}),
+        (({}, fresh(5), ["a", "b"], [], [], {"primary": {"priority": 0, "constraints": 1},
+                                             "replica": {"priority": 1, "constraints": 5}}), {}),
+        (({}, fresh(40), ["n%d" % i for i in range(12)], [], [], {"primary": {"priority": 0, "constraints": 1},
+                                                                  "replica": {"priority": 1, "constraints": 8}}), {}),
+        (({}, fresh(50), ["n%d" % i for i in range(7)], [], [], {"a": {"priority": 0, "constraints": 1},
+                                                                 "b": {"priority": 1, "constraints": 2},
+                                                                 "c": {"priority": 2, "constraints": 1}}), {}),
+        ((prev, prev, ["n0", "n1", "n2", "n3"], ["n0"], ["n3"], M1), {}),
+        (({}, fresh(64), n24, [], [], {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": 3}}),
+         {"node_hierarchy": hier24, "hierarchy_rules": {"replica": [{"includeLevel": 1, "excludeLevel": 0}]}}),
+        (({}, fresh(64), n24, [], [], M1),
+         {"node_hierarchy": hier24, "hierarchy_rules": {"replica": [{"includeLevel": 2, "excludeLevel": 1},
+                                                                    {"includeLevel": 3, "excludeLevel": 2}]}}),
+        (({}, fresh(64), n24, [], [], M1),
+         {"node_hierarchy": hier24, "hierarchy_rules": {"primary": [{"includeLevel": 3, "excludeLevel": 0}],
+                                                        "replica": [{"includeLevel": 2, "excludeLevel": 1}]}}),
+    ]
+    return cases

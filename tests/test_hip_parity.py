@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from blance_amd import hip, problem, synth
-from helpers import build_from_case
+from helpers import build_from_case, edge_cases
 from randgen import random_case, random_regular_case
 
 pytestmark = pytest.mark.gpu
@@ -244,6 +244,16 @@ def test_config5_full_size_digest(planner):
     fp2 = synth.config5_rebalance(fp1, r1, P, N)
     r2 = planner.plan(fp2)
     assert (r2.iterations, r2.digest()) == (want["rebalance"]["iterations"], want["rebalance"]["digest"])
+
+
+def test_edge_shapes(planner, eager_planner):
+    """Nothing to plan, no nodes, iteration caps, unmet constraints, 8 copies, three states, names only
+    in prevMap, exclude level 0, two rules for a state, rules on the top priority state."""
+    for pl in (planner, eager_planner):
+        for i, (a, k) in enumerate(edge_cases()):
+            fp = problem.build_problem(*a, **k)
+            got, want = pl.plan(fp), _oracle(fp)
+            assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), i
 
 
 def test_resident_replan_is_deterministic(planner):

@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 from blance_amd import hip, problem, synth
-from helpers import build_from_case
+from helpers import build_from_case, edge_cases
 from randgen import random_case, random_regular_case
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -195,6 +195,20 @@ def test_wide_hierarchy_regions(emu_lib):
     assert got.digest() == _oracle(fp).digest()
     assert got.struct.steps_batched > 0
     pl.close()
+
+
+def test_edge_shapes(emu_lib):
+    """Degenerate and unusual inputs: nothing to plan, no nodes, iteration caps, constraints the
+    cluster cannot meet, 8 copies, three states, names that occur only in prevMap, rules with
+    exclude level 0, two rules for one state, rules on the top priority state."""
+    cases = edge_cases()
+    for eager in (0, 1):
+        pl = hip.Planner(lib_path=emu_lib, chain_min_parts=eager)
+        for i, (a, k) in enumerate(cases):
+            fp = problem.build_problem(*a, **k)
+            got, want = pl.plan(fp), _oracle(fp)
+            assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), i
+        pl.close()
 
 
 def test_several_nodes_per_thread(emu_lib):
