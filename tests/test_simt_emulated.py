@@ -211,6 +211,27 @@ def test_edge_shapes(emu_lib):
         pl.close()
 
 
+def test_one_context_from_several_threads(emu_lib):
+    """calls on one blance_ctx are serialised by the library; goroutines
+    (here: Python threads, ctypes releases the GIL during the call) may share it."""
+    import threading
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=8)
+    fps = [synth.config_flat(3, P=96 + 8 * i, N=64) for i in range(4)] + [synth.config_flat(2, P=200 + i, N=16) for i in range(4)]
+    want = [_oracle(fp).digest() for fp in fps]
+    got = [None] * len(fps)
+
+    def work(i):
+        for _ in range(3):
+            got[i] = pl.plan(fps[i]).digest()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(fps))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == want
+    pl.close()
+
+
 def test_several_nodes_per_thread(emu_lib):
     """NX > T exercises the NPT > 1 register tiles."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64)
