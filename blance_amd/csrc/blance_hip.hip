@@ -797,7 +797,6 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int32_t* scal = c->scalars.as<int32_t>();
     int64_t launches = 0, steps = 0, batched = 0;
     int n_pass = 0;
-    unsigned chain_gave_up = 0;     // states whose chain pass had to be redone sequentially (this sweep)
 
     DevProblem d;
     d.N = N; d.NX = NX; d.M = M; d.L = L; d.P = P;
@@ -817,7 +816,6 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int iterations = 0, converged = 0;
     for (int it = 0; it < h.max_iterations; it++) {                 // plan.go:32
         const bool first = it == 0;
-        chain_gave_up = 0;
         d.node_removed = first ? c->node_removed.as<uint8_t>() : c->zeros_nx.as<uint8_t>();   // plan.go:53-55
         d.node_added = first ? c->node_added.as<uint8_t>() : c->zeros_nx.as<uint8_t>();
         const int add_nil = first ? h.nodes_to_add_nil : 0;
@@ -872,7 +870,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             // ---- region chains, when the state's single hierarchy rule allows them
             bool done = false;
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
-                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4 && !((chain_gave_up >> m) & 1)) {
+                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
                 blance_ctx::RuleRegions& rr = c->rule_regions[r0];
                 const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
@@ -999,7 +997,6 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                         batched += P;
                         done = true;
                     } else {                                        // not region-local after all: redo in order
-                        chain_gave_up |= 1u << m;                  // and do not try again in later sweeps
                         if (NP > 0)                                 // chains of big regions keep their rows in global memory
                             HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
                         HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
