@@ -2,7 +2,7 @@
 """One-off GPU stress: mid-size random problems (thousands of partitions, up to a
 thousand nodes; regular and ragged hierarchies, weights, removals, rebalances)
 through the HIP planner vs the CPU oracle, bit for bit.  Run on the GPU box:
-    python tools/stress_gpu.py [n_cases] [seed0]"""
+    python tools/stress_gpu.py [n_cases] [seed0] [--flat-heavy]"""
 import os
 import random
 import sys
@@ -13,6 +13,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from blance_amd import hip, problem, synth          # noqa: E402
 from oracle import loader                            # noqa: E402
+
+
+FLAT_HEAVY = "--flat-heavy" in sys.argv
+if FLAT_HEAVY:
+    sys.argv.remove("--flat-heavy")
 
 
 def case(seed):
@@ -27,11 +32,18 @@ def case(seed):
     k = rng.choice([1, 2, 2, 3])
     model = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
     rule = rng.choice([(2, 1), (2, 1), (1, 0), (2, 0), (3, 1), None])
+    if FLAT_HEAVY:                                  # the workgroup pass: flat, weighted, up to 8 nodes per thread
+        rule = rng.choice([None, None, (2, 1)])
+        if rng.random() < 0.3:
+            N = rng.choice([1500, 3000, 5000])
+            nodes = ["n%04d" % i for i in range(N)]
+            hier = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=4)
+            P = rng.choice([2500, 4000])
     rules = None if rule is None else {"replica": [{"includeLevel": rule[0], "excludeLevel": rule[1]}]}
     opts = dict(node_hierarchy=hier if rules else None, hierarchy_rules=rules)
-    if rng.random() < 0.4:
+    if rng.random() < (0.7 if FLAT_HEAVY else 0.4):
         opts["partition_weights"] = {str(i): rng.choice([1, 2, 3, 5]) for i in range(P) if rng.random() < 0.6}
-    if rng.random() < 0.3:
+    if rng.random() < (0.6 if FLAT_HEAVY else 0.3):
         opts["node_weights"] = {n: rng.choice([1, 1, 2, 3]) for n in nodes}
     if rng.random() < 0.3:
         opts["state_stickiness"] = {"primary": rng.choice([1, 5, 100]), "replica": rng.choice([1, 10])}
