@@ -545,13 +545,14 @@ static void launch_pass(blance_ctx* c, PassParams q) {
 
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     // T threads own NPT nodes each (register resident); one workgroup runs the pass.  A step is a
-    // chain of dependent instructions in every wave (about 11 cycles each, measured), so the
-    // width costs little: 2.7 us / step at 256 and 1,024 nodes, 3.7 at 4,096.
+    // chain of dependent instructions in every wave (about 11 cycles each, measured).
     const int NX = q.NX > 0 ? q.NX : 1;
+    // measured per general step (us): 1,024 nodes: 2.25 with 256 x 4, 1.93 with 512 x 2; 4,096 nodes: 3.43 with
+    // 512 x 8, 2.92 with 1024 x 4 -- two waves per SIMD hide each other's latency, more nodes per thread cost more
     int T = c->force_threads;
-    if (T != 64 && T != 256 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 256 : 1024);
+    if (T != 64 && T != 256 && T != 512 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 512 : 1024);
     if (T == 64 && NX > 256) T = 256;
-    if (T == 256 && NX > 1024) T = 1024;
+    if ((T == 256 || T == 512) && NX > 1024) T = 1024;
     const int npt = cdiv(NX, T);
     if (T == 64) {
         if (npt <= 1) launch_pass<64, 1>(c, q);
@@ -559,6 +560,8 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     } else if (T == 256) {
         if (npt <= 1) launch_pass<256, 1>(c, q);
         else launch_pass<256, 4>(c, q);
+    } else if (T == 512) {
+        launch_pass<512, 2>(c, q);
     } else {
         if (npt <= 2) launch_pass<1024, 2>(c, q);
         else if (npt <= 4) launch_pass<1024, 4>(c, q);

@@ -174,12 +174,13 @@ __device__ __forceinline__ int block_argmin(double s, int n, RedSlot* red, int& 
     }
     lds_barrier();
     // second stage: lane l takes wave (l mod W)'s slot; W <= 16 slots sit in one DPP row
+    constexpr int G = W <= 4 ? 4 : 16;             // W = 8: every slot sits twice in a row of 16
     const RedSlot mine = slot[threadIdx.x & (W - 1)];
-    const unsigned bh = row_min_u32<W>(mine.hi);
+    const unsigned bh = row_min_u32<G>(mine.hi);
     const bool k2 = mine.hi == bh;
-    const unsigned bl = row_min_u32<W>(k2 ? mine.lo : kKeyNoneV);
+    const unsigned bl = row_min_u32<G>(k2 ? mine.lo : kKeyNoneV);
     const bool k3 = k2 && mine.lo == bl;
-    return (int)row_min_u32<W>(k3 ? (unsigned)mine.n : kKeyNoneV);
+    return (int)row_min_u32<G>(k3 ? (unsigned)mine.n : kKeyNoneV);
     }
 }
 

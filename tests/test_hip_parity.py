@@ -123,7 +123,7 @@ def test_random_larger_instances(planner):
         _same(planner.plan(fp), _oracle(fp), seed)
 
 
-@pytest.mark.parametrize("threads", [64, 256, 1024])
+@pytest.mark.parametrize("threads", [64, 256, 512, 1024])
 def test_workgroup_shapes(threads, golden_cases):
     """Every workgroup shape of the pass kernel gives the same answer."""
     pl = hip.Planner(device_id=0, force_threads=threads)

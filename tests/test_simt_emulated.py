@@ -232,6 +232,14 @@ def test_one_context_from_several_threads(emu_lib):
     pl.close()
 
 
+def test_eight_waves(emu_lib):
+    """512 threads: the second argmin stage reads every wave's slot twice in a DPP row of 16."""
+    pl = hip.Planner(lib_path=emu_lib, force_threads=512)
+    for fp in (synth.config_flat(3, P=40, N=300), synth.config_flat(2, P=60, N=900)):
+        assert pl.plan(fp).digest() == _oracle(fp).digest()
+    pl.close()
+
+
 def test_several_nodes_per_thread(emu_lib):
     """NX > T exercises the NPT > 1 register tiles."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64)
