@@ -208,3 +208,11 @@ class FlatResult:
         h.update(self.warn_part[:n].tobytes())
         h.update(self.warn_state[:n].tobytes())
         return h.hexdigest()
+
+
+class PlanStats(C.Structure):
+    """blance_plan_stats of include/blance_hip.h."""
+    _fields_ = [("n_states", C.c_int32), ("n_nodes_next", C.c_int32),
+                ("load_min", C.POINTER(C.c_int64)), ("load_max", C.POINTER(C.c_int64)),
+                ("load_sum", C.POINTER(C.c_int64)), ("load_sumsq", C.POINTER(C.c_int64)),
+                ("nodes_used", C.POINTER(C.c_int32)), ("unmet_slots", C.POINTER(C.c_int64))]

@@ -789,6 +789,21 @@ static int dump_pass(blance_ctx* c, int sweep, int state, int P, int OW, const i
     return 0;
 }
 
+static DevProblem dev_problem(blance_ctx* c) {
+    const blance_problem& h = c->h;
+    DevProblem d;
+    d.N = h.n_nodes; d.NX = h.n_nodes_ext; d.M = h.n_states; d.L = c->L; d.P = h.n_parts;
+    d.weights_nil = h.partition_weights_nil;
+    d.node_removed = c->zeros_nx.as<uint8_t>();
+    d.node_added = c->zeros_nx.as<uint8_t>();
+    d.part_weight = c->part_weight.as<int32_t>();
+    d.part_has_weight = c->part_has_weight.as<uint8_t>();
+    d.live = c->live.as<int32_t>(); d.live_len = c->live_len.as<int32_t>(); d.live_kind = c->live_kind.as<uint8_t>();
+    d.prv = c->prv.as<int32_t>(); d.prv_len = c->prv_len.as<int32_t>(); d.prv_kind = c->prv_kind.as<uint8_t>();
+    d.in_prev = c->in_prev.as<uint8_t>(); d.never_equal = c->never_equal.as<uint8_t>();
+    return d;
+}
+
 static int plan_locked(blance_ctx* c, blance_result* res) {
     if (!c->uploaded) return fail(BLANCE_ERR_BAD_ARG, "no problem uploaded");
     HIPTRY(hipSetDevice(c->device));
@@ -801,14 +816,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int64_t launches = 0, steps = 0, batched = 0;
     int n_pass = 0;
 
-    DevProblem d;
-    d.N = N; d.NX = NX; d.M = M; d.L = L; d.P = P;
-    d.weights_nil = h.partition_weights_nil;
-    d.part_weight = c->part_weight.as<int32_t>();
-    d.part_has_weight = c->part_has_weight.as<uint8_t>();
-    d.live = c->live.as<int32_t>(); d.live_len = c->live_len.as<int32_t>(); d.live_kind = c->live_kind.as<uint8_t>();
-    d.prv = c->prv.as<int32_t>(); d.prv_len = c->prv_len.as<int32_t>(); d.prv_kind = c->prv_kind.as<uint8_t>();
-    d.in_prev = c->in_prev.as<uint8_t>(); d.never_equal = c->never_equal.as<uint8_t>();
+    DevProblem d = dev_problem(c);
 
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 64, sm));
@@ -1273,6 +1281,51 @@ extern "C" int blance_plan_resident(blance_ctx* c, blance_result* res) {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
     return plan_locked(c, res);
+}
+
+extern "C" int blance_plan_stats_get(blance_ctx* c, blance_plan_stats* st) {
+    if (!c || !st) return fail(BLANCE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->planned) return fail(BLANCE_ERR_BAD_ARG, "nothing planned yet");
+    const blance_problem& h = c->h;
+    const int N = h.n_nodes, NX = h.n_nodes_ext, M = h.n_states, P = h.n_parts;
+    if (st->n_states < M || !st->load_min || !st->load_max || !st->load_sum || !st->load_sumsq || !st->nodes_used ||
+        !st->unmet_slots)
+        return fail(BLANCE_ERR_BAD_ARG, "stats arrays missing or shorter than n_states");
+    HIPTRY(hipSetDevice(c->device));
+    hipStream_t sm = c->stream;
+    DevBuf load, out, cons, unmet;
+    struct Free { DevBuf* b[4]; ~Free() { for (DevBuf* x : b) x->release(); } } fr{{&load, &out, &cons, &unmet}};
+    if (load.reserve(sizeof(int32_t) * ((size_t)M * (NX > 0 ? NX : 1) + 1)) || out.reserve(sizeof(long long) * ((size_t)M * 5 + 1)) ||
+        cons.reserve(sizeof(int32_t) * ((size_t)M + 1)) || unmet.reserve(sizeof(long long) * ((size_t)M + 1)))
+        return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    std::vector<long long> host((size_t)M * 5 + 1), hun((size_t)M + 1, 0);
+    int n_next = 0;
+    if (c->iterations > 0 && M > 0) {
+        HIPTRY(hipMemsetAsync(load.p, 0, sizeof(int32_t) * (size_t)M * (NX > 0 ? NX : 1), sm));
+        HIPTRY(hipMemsetAsync(unmet.p, 0, sizeof(long long) * (size_t)M, sm));
+        HIPTRY(hipMemcpyAsync(cons.p, c->state_constraints.data(), sizeof(int32_t) * (size_t)M, hipMemcpyHostToDevice, sm));
+        DevProblem d = dev_problem(c);
+        if ((int64_t)P * M > 0)
+            BLANCE_LAUNCH_NOSYNC(k_stats_load, cdiv((int64_t)P * M, 256), 256, 0, sm, d, load.as<int32_t>(), cons.as<int32_t>(),
+                                 unmet.as<unsigned long long>());
+        BLANCE_LAUNCH(k_stats_reduce, M, 256, sizeof(long long) * 5 * 256 + 64, sm, N, NX, c->alive.as<uint8_t>(), load.as<int32_t>(), out.as<long long>());
+        HIPTRY(hipMemcpyAsync(host.data(), out.p, sizeof(long long) * (size_t)M * 5, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipMemcpyAsync(hun.data(), unmet.p, sizeof(long long) * (size_t)M, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipStreamSynchronize(sm));
+    }
+    if (c->iterations > 0) n_next = c->n_alive;
+    st->n_nodes_next = n_next;
+    for (int m = 0; m < M; m++) {
+        const bool any = c->iterations > 0 && n_next > 0;
+        st->load_min[m] = any ? host[(size_t)m * 5 + 0] : 0;
+        st->load_max[m] = any ? host[(size_t)m * 5 + 1] : 0;
+        st->load_sum[m] = any ? host[(size_t)m * 5 + 2] : 0;
+        st->load_sumsq[m] = any ? host[(size_t)m * 5 + 3] : 0;
+        st->nodes_used[m] = any ? (int32_t)host[(size_t)m * 5 + 4] : 0;
+        st->unmet_slots[m] = c->iterations > 0 ? hun[(size_t)m] : 0;
+    }
+    return BLANCE_OK;
 }
 
 extern "C" int blance_download(blance_ctx* c, blance_result* res) {

@@ -489,4 +489,48 @@ __global__ void k_calc_moves(MovesParams q) {
     q.n_moves[p] = n;
 }
 
+// ---- plan quality (blance_plan_stats_get): countStateNodes (plan.go:374-399) over the RESULT map
+__global__ void k_stats_load(DevProblem d, int32_t* load /* [M][NX] */, const int32_t* constraints,
+                             unsigned long long* unmet /* [M] */) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    const int p = idx / d.M, m = idx - p * d.M;
+    const int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
+    const int w = (!d.weights_nil && d.part_has_weight[p]) ? d.part_weight[p] : 1;     // plan.go:387-394
+    for (int i = 0; i < len; i++) atomicAdd(&load[(size_t)m * d.NX + d.live[(size_t)idx * d.L + i]], w);
+    const int k = constraints[m] > 0 ? constraints[m] : 0;
+    if (len < k) atomicAdd(&unmet[m], (unsigned long long)(k - len));
+}
+
+// one workgroup per state: min / max / sum / sum of squares / nodes in use over nodesNext
+__global__ __launch_bounds__(256) void k_stats_reduce(int N, int NX, const uint8_t* alive, const int32_t* load,
+                                                      long long* out /* [M][5] */) {
+    BLANCE_DYN_LDS(lds);
+    long long (*sh)[256] = (long long (*)[256])lds;      // [5][256]
+    const int m = blockIdx.x, tid = threadIdx.x;
+    long long mn = LLONG_MAX, mx = LLONG_MIN, sum = 0, sq = 0, used = 0;
+    for (int n = tid; n < N; n += 256) {
+        if (!alive[n]) continue;
+        const long long v = load[(size_t)m * NX + n];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        sum += v;
+        sq += v * v;
+        used += v > 0;
+    }
+    sh[0][tid] = mn; sh[1][tid] = mx; sh[2][tid] = sum; sh[3][tid] = sq; sh[4][tid] = used;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            sh[0][tid] = sh[0][tid + off] < sh[0][tid] ? sh[0][tid + off] : sh[0][tid];
+            sh[1][tid] = sh[1][tid + off] > sh[1][tid] ? sh[1][tid + off] : sh[1][tid];
+            sh[2][tid] += sh[2][tid + off];
+            sh[3][tid] += sh[3][tid + off];
+            sh[4][tid] += sh[4][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid < 5) out[m * 5 + tid] = sh[tid][0];
+}
+
 }  // namespace blance

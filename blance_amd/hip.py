@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libblance_hip.so")
 
 EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", "blance_validate",
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
-           "blance_plan_resident", "blance_download", "blance_calc_moves"]
+           "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get"]
 
 _libs = {}
 
@@ -55,6 +55,8 @@ def load_library(path=None):
     lib.blance_plan_resident.argtypes = [C.c_void_p, C.POINTER(abi.Result)]
     lib.blance_download.restype = C.c_int
     lib.blance_download.argtypes = [C.c_void_p, C.POINTER(abi.Result)]
+    lib.blance_plan_stats_get.restype = C.c_int
+    lib.blance_plan_stats_get.argtypes = [C.c_void_p, C.POINTER(abi.PlanStats)]
     lib.blance_calc_moves.restype = C.c_int
     lib.blance_calc_moves.argtypes = [C.c_void_p, C.POINTER(abi.MovesProblem), C.POINTER(abi.MovesResult)]
     if lib.blance_abi_version() != abi.ABI_VERSION:
@@ -102,6 +104,24 @@ class Planner:
         res = abi.FlatResult(fp)
         self._check(self.lib.blance_plan(self._h, C.byref(fp.as_struct()), C.byref(res.struct)))
         return res
+
+    def plan_stats(self, n_states):
+        """Per-state load statistics of the map the last plan produced (blance_plan_stats_get):
+        dict of numpy arrays load_min / load_max / load_sum / load_sumsq / nodes_used / unmet_slots
+        plus n_nodes_next."""
+        import numpy as np
+        a = {k: np.zeros(max(n_states, 1), dtype=np.int64) for k in ("load_min", "load_max", "load_sum", "load_sumsq", "unmet_slots")}
+        used = np.zeros(max(n_states, 1), dtype=np.int32)
+        st = abi.PlanStats()
+        st.n_states = n_states
+        for k, v in a.items():
+            setattr(st, k, v.ctypes.data_as(C.POINTER(C.c_int64)))
+        st.nodes_used = used.ctypes.data_as(C.POINTER(C.c_int32))
+        self._check(self.lib.blance_plan_stats_get(self._h, C.byref(st)))
+        out = {k: v[:n_states] for k, v in a.items()}
+        out["nodes_used"] = used[:n_states]
+        out["n_nodes_next"] = int(st.n_nodes_next)
+        return out
 
     def calc_moves(self, n_states, favor_min_nodes, beg_off, beg_nodes, end_off, end_nodes):
         """blance_calc_moves(): CalcPartitionMoves for every partition (CSR over

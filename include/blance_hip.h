@@ -238,6 +238,23 @@ typedef struct blance_moves_result {
 
 int blance_calc_moves(blance_ctx* ctx, const blance_moves_problem* pb, blance_moves_result* res);
 
+/* ---- plan quality: what a caller would otherwise get by re-walking the
+ * result map -- countStateNodes (plan.go:374-399) applied to the map the last blance_plan /
+ * blance_plan_resident produced, reduced per state over the nodes of nodesNext (plan.go:77).
+ * Arrays are the caller's, n_states entries each (state id order). */
+typedef struct blance_plan_stats {
+    int32_t n_states;        /* in: capacity of the arrays below (>= the problem's n_states) */
+    int32_t n_nodes_next;    /* out: nodes counted (nodesAll minus nodesToRemove) */
+    int64_t* load_min;       /* out: smallest weighted load of a node in this state */
+    int64_t* load_max;
+    int64_t* load_sum;       /* out: sum of the loads = sum over partitions of weight * len(list) on live nodes */
+    int64_t* load_sumsq;     /* out: sum of squares (variance = sumsq / n - (sum / n)^2) */
+    int32_t* nodes_used;     /* out: nodes with load > 0 */
+    int64_t* unmet_slots;    /* out: sum over partitions of max(0, constraints - len(list)); warnings of plan.go:231-234 */
+} blance_plan_stats;
+
+int blance_plan_stats_get(blance_ctx* ctx, blance_plan_stats* stats);
+
 /* Validate a problem without touching a device (sizes, id ranges, supported
  * envelope).  Same status codes as blance_plan. */
 int blance_validate(const blance_problem* pb);

@@ -1,0 +1,63 @@
+"""Plan-quality numbers: blance_plan_stats_get against oracle/stats_ref.py,
+on the emulated build (CPU) and on the device (-m gpu)."""
+import numpy as np
+import pytest
+
+from blance_amd import hip, problem, synth
+from helpers import build_from_case, edge_cases
+from oracle import stats_ref
+from randgen import random_case
+
+KEYS = ("load_min", "load_max", "load_sum", "load_sumsq", "nodes_used", "unmet_slots")
+
+
+def _check(pl, fp, tag):
+    res = pl.plan(fp)
+    got = pl.plan_stats(fp.n_states)
+    want = stats_ref.plan_stats(fp, res)
+    assert got["n_nodes_next"] == want["n_nodes_next"], tag
+    for k in KEYS:
+        assert np.array_equal(np.asarray(got[k], dtype=np.int64), np.asarray(want[k], dtype=np.int64)), (tag, k)
+    return res, got
+
+
+def _run(pl, golden_cases):
+    for c in golden_cases:
+        fp = build_from_case(c)
+        res, got = _check(pl, fp, c["source"])
+        # the warnings of plan.go:231-234 are exactly the (partition, state) pairs with unmet slots
+        assert (got["unmet_slots"].sum() > 0) == (res.n_warnings > 0), c["source"]
+    for seed in range(300, 380):
+        try:
+            fp = build_from_case(random_case(seed))
+        except problem.Unsupported:
+            continue
+        _check(pl, fp, seed)
+    for i, (a, k) in enumerate(edge_cases()):
+        _check(pl, problem.build_problem(*a, **k), ("edge", i))
+    c = synth.rebalance_case(P=400, N=48, hierarchy=True)
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    fp = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"],
+                               partition_weights=c["partitionWeights"], node_weights=c["nodeWeights"],
+                               node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
+    _, got = _check(pl, fp, "weighted")
+    assert got["load_sum"][0] == sum(c["partitionWeights"].values())          # every primary placed once
+
+
+def test_stats_emulated(golden_cases):
+    from test_simt_emulated import build_emu
+    pl = hip.Planner(lib_path=build_emu())
+    _run(pl, golden_cases)
+    with pytest.raises(hip.BlanceError):
+        hip.Planner(lib_path=build_emu()).plan_stats(2)                      # nothing planned yet
+    pl.close()
+
+
+@pytest.mark.gpu
+def test_stats_gpu(golden_cases):
+    pl = hip.Planner(device_id=0)
+    _run(pl, golden_cases)
+    fp = synth.config_flat(3, P=65536, N=4096)
+    _, got = _check(pl, fp, "cfg3 reduced")
+    assert got["load_max"][0] - got["load_min"][0] <= 1 and got["unmet_slots"].sum() == 0
+    pl.close()
