@@ -70,7 +70,6 @@ def main():
     ap.add_argument("--parts", type=int, default=0, help="override partition count (not the headline)")
     ap.add_argument("--nodes", type=int, default=0, help="override node count (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="also compare the result with the oracle (slow)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,9 +196,6 @@ def main():
                 want = json.load(f).get("config%d" % args.config)
             if want:
                 out["matches_oracle_digest"] = (want["rebalance"] if args.config == 5 else want)["digest"] == digest
-        if args.verify:
-            from oracle import loader
-            out["matches_oracle"] = loader.plan(fp).digest() == digest
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config)
         print(json.dumps(out), flush=True)

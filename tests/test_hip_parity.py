@@ -225,7 +225,7 @@ def _golden_digests():
 
 def test_config3_full_size_digest(planner):
     """BASELINE.json's headline configuration at its full size (1,048,576 x 4,096): the result's
-    SHA-256 equals the CPU oracle's (tools/make_config_digests.py, 141 s on one core)."""
+    SHA-256 equals the CPU oracle's (tests/tools/make_config_digests.py, 141 s on one core)."""
     want = _golden_digests()["config3"]
     got = planner.plan(synth.config_flat(3))
     assert (got.iterations, got.n_warnings) == (want["iterations"], want["warnings"])
@@ -234,7 +234,7 @@ def test_config3_full_size_digest(planner):
 
 def test_config5_full_size_digest(planner):
     """Config 5 at its full size: weighted plan over the old nodes, then the rebalance from it
-    (10 sweeps each, about 70 s of device time); digests from tools/make_config5_digest.py
+    (10 sweeps each, about 70 s of device time); digests from tests/tools/make_config5_digest.py
     (the CPU oracle needs 8 minutes for each)."""
     want = _golden_digests()["config5"]
     P, N = want["partitions"], want["nodes"]

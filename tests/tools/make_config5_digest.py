@@ -3,13 +3,13 @@
 partition weights, node weights, stickiness; 410 nodes removed + 410 added): the CPU oracle's
 digests of the initial plan over the old nodes and of the rebalance from that plan, stored in
 tests/golden/config_digests.json so the GPU test can check bit-parity at full size without the
-oracle's minutes.  Usage: python tools/make_config5_digest.py [P N]"""
+oracle's minutes.  Usage: python tests/tools/make_config5_digest.py [P N]"""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from blance_amd import synth          # noqa: E402
 from oracle import loader             # noqa: E402

@@ -2,13 +2,13 @@
 """Generates tests/golden/config_digests.json: the CPU oracle's result digest
 (abi.FlatResult.digest) for BASELINE.json's synthetic configs at FULL size, so
 GPU tests and bench.py can check bit-parity at 1M partitions without re-running
-the 2.5-minute single-core oracle.  Usage: python tools/make_config_digests.py"""
+the 2.5-minute single-core oracle.  Usage: python tests/tools/make_config_digests.py"""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from blance_amd import synth          # noqa: E402
 from oracle import loader             # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Rebalance timing on the GPU box (BASELINE.json config 5's shape at one-GPU size):
 plan a cluster, remove / add a tenth of the nodes, re-plan from the first plan.
-    python tools/rebalance_gpu.py P N [--weighted] [--flat] [--check]
+    python tests/tools/rebalance_gpu.py P N [--weighted] [--flat] [--check]
 --weighted keeps config 5's partition weights, node weights and stickiness,
 --flat drops the hierarchy, --check compares the rebalance with the CPU oracle."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from blance_amd import hip, problem, synth          # noqa: E402
 

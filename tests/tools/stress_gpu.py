@@ -2,13 +2,13 @@
 """One-off GPU stress: mid-size random problems (thousands of partitions, up to a
 thousand nodes; regular and ragged hierarchies, weights, removals, rebalances)
 through the HIP planner vs the CPU oracle, bit for bit.  Run on the GPU box:
-    python tools/stress_gpu.py [n_cases] [seed0] [--flat-heavy]"""
+    python tests/tools/stress_gpu.py [n_cases] [seed0] [--flat-heavy]"""
 import os
 import random
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from blance_amd import hip, problem, synth          # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5 at its named size on the GPU box: the initial plan over the old nodes,
 then the rebalance from it; both digests against tests/golden/config_digests.json (made by
-tools/make_config5_digest.py with the CPU oracle, ~8 minutes each).
+tests/tools/make_config5_digest.py with the CPU oracle, ~8 minutes each).
     python tools/config5_gpu.py [P N]      (other sizes: timings only)"""
 import json
 import os
