@@ -29,6 +29,7 @@ struct Abi {
     void (*ctx_destroy)(blance_ctx*) = nullptr;
     int (*plan)(blance_ctx*, const blance_problem*, blance_result*) = nullptr;
     const char* (*last_error)(void) = nullptr;
+    int (*calc_moves)(blance_ctx*, const blance_moves_problem*, blance_moves_result*) = nullptr;
 };
 std::unordered_map<void*, Abi> g_abi;
 
@@ -397,6 +398,7 @@ bool Library::open(const std::string& path, std::string* err) {
     a.ctx_destroy = (void (*)(blance_ctx*))dlsym(handle, "blance_ctx_destroy");
     a.plan = (int (*)(blance_ctx*, const blance_problem*, blance_result*))dlsym(handle, "blance_plan");
     a.last_error = (const char* (*)(void))dlsym(handle, "blance_last_error");
+    a.calc_moves = (int (*)(blance_ctx*, const blance_moves_problem*, blance_moves_result*))dlsym(handle, "blance_calc_moves");
     if (!a.validate || !a.result_capacity || !a.ctx_create || !a.ctx_destroy || !a.plan || !a.last_error) {
         if (err) *err = "library does not export the blance C ABI";
         return false;
@@ -480,6 +482,73 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // the last such store has the final map's content
     if ((res.iterations > 1 || !res.converged) && prevMap)
         for (auto& kv : out.nextMap) { (*prevMap)[kv.first] = kv.second; partitionsToAssign[kv.first] = kv.second; }
+    return out;
+}
+
+MovesOutcome CalcPartitionMovesBatch(Library& lib, const std::vector<std::string>& states,
+                                     const std::map<std::string, NodesByState>& begMap,
+                                     const std::map<std::string, NodesByState>& endMap, bool favorMinNodes) {
+    MovesOutcome out;
+    auto it = g_abi.find(lib.handle);
+    if (it == g_abi.end() || !it->second.calc_moves) { out.why = "library not open or without blance_calc_moves"; return out; }
+    // partitions: the end map's, then those only in the begin map (what the orchestrator walks)
+    std::vector<std::string> names;
+    for (auto& kv : endMap) names.push_back(kv.first);
+    for (auto& kv : begMap) if (!endMap.count(kv.first)) names.push_back(kv.first);
+    std::unordered_map<std::string, int32_t> ids;
+    std::vector<std::string> node_names;
+    auto nid = [&](const std::string& x) {
+        auto f = ids.find(x);
+        if (f != ids.end()) return f->second;
+        int32_t i = (int32_t)node_names.size();
+        ids.emplace(x, i);
+        node_names.push_back(x);
+        return i;
+    };
+    const int M = (int)states.size();
+    auto csr = [&](const std::map<std::string, NodesByState>& m, std::vector<int32_t>& off, std::vector<int32_t>& nodes) {
+        off.assign(1, 0);
+        static const NodesByState kNone;
+        for (auto& name : names) {
+            auto f = m.find(name);
+            const NodesByState& nbs = f == m.end() ? kNone : f->second;
+            for (auto& s : states) {
+                auto l = nbs.find(s);
+                if (l != nbs.end() && l->second) for (auto& x : *l->second) nodes.push_back(nid(x));
+                off.push_back((int32_t)nodes.size());
+            }
+            for (auto& kv : nbs) {               // keys outside `states` only feed flattenNodesByState (moves.go:47-48)
+                bool known = false;
+                for (auto& s : states) if (s == kv.first) known = true;
+                if (!known && kv.second) for (auto& x : *kv.second) nodes.push_back(nid(x));
+            }
+            off.push_back((int32_t)nodes.size());
+        }
+    };
+    std::vector<int32_t> boff, bnod, eoff, enod;
+    csr(begMap, boff, bnod);
+    csr(endMap, eoff, enod);
+    bnod.push_back(0); enod.push_back(0);        // never hand out null pointers
+    const int64_t cap = (int64_t)boff.back() + eoff.back() + 1;
+    std::vector<int32_t> op_off(names.size() + 1), op_node((size_t)cap), op_state((size_t)cap), op_kind((size_t)cap);
+    blance_moves_problem pb{};
+    pb.n_parts = (int32_t)names.size(); pb.n_states = M; pb.favor_min_nodes = favorMinNodes ? 1 : 0;
+    pb.beg_off = boff.data(); pb.beg_nodes = bnod.data(); pb.end_off = eoff.data(); pb.end_nodes = enod.data();
+    blance_moves_result res{};
+    res.op_off = op_off.data(); res.op_node = op_node.data(); res.op_state = op_state.data(); res.op_kind = op_kind.data();
+    res.capacity = cap;
+    if (it->second.calc_moves((blance_ctx*)lib.ctx, &pb, &res) != BLANCE_OK) {
+        out.why = std::string("blance_calc_moves: ") + it->second.last_error();
+        return out;
+    }
+    static const char* kOps[] = {"add", "del", "promote", "demote"};     // BLANCE_OP_*
+    for (size_t i = 0; i < names.size(); i++) {
+        auto& v = out.moves[names[i]];
+        for (int32_t j = op_off[i]; j < op_off[i + 1]; j++)
+            v.push_back({node_names[(size_t)op_node[(size_t)j]], op_state[(size_t)j] < 0 ? "" : states[(size_t)op_state[(size_t)j]],
+                         kOps[op_kind[(size_t)j]]});
+    }
+    out.ok = true;
     return out;
 }
 

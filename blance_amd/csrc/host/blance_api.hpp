@@ -78,6 +78,22 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
                           const StringList& nodesToAdd, const PartitionModel& model,
                           const PlanNextMapOptions& options);
 
+// CalcPartitionMoves, moves.go:41-119 (NodeStateOp: moves.go:21-27), for every partition of the two
+// maps in one device call -- the loop of OrchestrateMoves, orchestrate.go:273-287.  Partitions missing
+// from one map count as holding nothing there; a nil NodesByState likewise.
+struct NodeStateOp {
+    std::string Node, State, Op;     // Op: "add", "del", "promote", "demote"
+};
+using NodesByState = std::map<std::string, StringList>;
+struct MovesOutcome {
+    bool ok = false;
+    std::string why;
+    std::map<std::string, std::vector<NodeStateOp>> moves;      // by partition name
+};
+MovesOutcome CalcPartitionMovesBatch(Library& lib, const std::vector<std::string>& states,
+                                     const std::map<std::string, NodesByState>& begMap,
+                                     const std::map<std::string, NodesByState>& endMap, bool favorMinNodes);
+
 // misc.go:13-51
 std::map<std::string, bool> StringsToMap(const std::vector<std::string>& strs);
 std::vector<std::string> StringsRemoveStrings(const std::vector<std::string>& a, const std::vector<std::string>& remove);

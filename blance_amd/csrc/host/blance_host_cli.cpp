@@ -89,11 +89,52 @@ static std::string dump_map(const PartitionMap& m) {
     return o.str();
 }
 
+static std::map<std::string, NodesByState> read_nbs_map() {
+    std::map<std::string, NodesByState> m;
+    for (int i = 0, n = std::stoi(line()); i < n; i++) {
+        std::string name = line();
+        NodesByState nbs;
+        for (int j = 0, ns = std::stoi(line()); j < ns; j++) { std::string state = line(); nbs[state] = read_list(); }
+        m[name] = nbs;
+    }
+    return m;
+}
+
+// `blance_host_cli <lib> moves`: cases of (favorMinNodes, states, begMap, endMap) -> NodeStateOps per partition
+static int run_moves(Library& lib) {
+    int n_cases = std::stoi(line());
+    std::cout << "[";
+    for (int ci = 0; ci < n_cases; ci++) {
+        const bool favor = line() == "1";
+        std::vector<std::string> states = *read_list();
+        auto beg = read_nbs_map();
+        auto end = read_nbs_map();
+        MovesOutcome r = CalcPartitionMovesBatch(lib, states, beg, end, favor);
+        if (ci) std::cout << ",";
+        if (!r.ok) { std::cout << "{\"error\":" << q(r.why) << "}"; continue; }
+        std::cout << "{";
+        bool first = true;
+        for (auto& kv : r.moves) {
+            if (!first) std::cout << ",";
+            first = false;
+            std::cout << q(kv.first) << ":[";
+            for (size_t i = 0; i < kv.second.size(); i++)
+                std::cout << (i ? "," : "") << "[" << q(kv.second[i].Node) << "," << q(kv.second[i].State) << ","
+                          << q(kv.second[i].Op) << "]";
+            std::cout << "]";
+        }
+        std::cout << "}";
+    }
+    std::cout << "]\n";
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: blance_host_cli <libblance_hip.so>\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: blance_host_cli <libblance_hip.so> [moves]\n"); return 2; }
     Library lib;
     std::string err;
     if (!lib.open(argv[1], &err)) { fprintf(stderr, "cannot use %s: %s\n", argv[1], err.c_str()); return 3; }
+    if (argc > 2 && std::string(argv[2]) == "moves") return run_moves(lib);
     int n_cases = std::stoi(line());
     std::cout << "[";
     for (int ci = 0; ci < n_cases; ci++) {

@@ -144,3 +144,76 @@ def test_cpp_mirror_on_golden_cases_gpu(golden_cases):
     from blance_amd import hip
     _check(golden_cases, run_cli(hip.LIB_PATH, golden_cases))
     _check(golden_cases, run_cli(hip.LIB_PATH, golden_cases, eager=True))
+
+
+# ---- CalcPartitionMoves through the C++ mirror (blance::CalcPartitionMovesBatch)
+def _nbs_map(out, m):
+    out.append(str(len(m)))
+    for name, nbs in m.items():
+        out.append(name)
+        out.append(str(len(nbs)))
+        for state, lst in nbs.items():
+            out.append(state)
+            _list(out, lst)
+
+
+def run_moves_cli(lib, cases):
+    """cases: (favorMinNodes, states, begMap, endMap) with maps {partition: nodesByState}."""
+    out = [str(len(cases))]
+    for favor, states, beg, end in cases:
+        out.append("1" if favor else "0")
+        _list(out, states)
+        _nbs_map(out, beg)
+        _nbs_map(out, end)
+    p = subprocess.run([build_cli(), lib, "moves"], input="\n".join(out) + "\n", capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout)
+
+
+def _moves_cases():
+    import random
+    from test_moves import random_pair
+    with open(os.path.join(ROOT, "tests", "golden", "moves_cases.json")) as f:
+        golden = json.load(f)["calcPartitionMoves"]
+    cases = []
+    for favor in (False, True):
+        rows = [c for c in golden if c["favorMinNodes"] == favor]
+        cases.append((favor, rows[0]["states"], {str(i): c["before"] for i, c in enumerate(rows)},
+                      {str(i): c["after"] for i, c in enumerate(rows)}))
+    rng = random.Random(11)
+    states = ["primary", "replica", "dead"]
+    nodes = ["n%d" % i for i in range(7)]
+    for favor in (False, True):
+        beg, end = {}, {}
+        for i in range(300):
+            b, e = random_pair(rng, states, nodes)
+            if rng.random() < 0.9:
+                beg["p%d" % i] = b
+            if rng.random() < 0.9:
+                end["p%d" % i] = e
+        cases.append((favor, states, beg, end))
+    return cases
+
+
+def _check_moves(results, cases):
+    from oracle import moves_ref
+    for got, (favor, states, beg, end) in zip(results, cases):
+        assert "error" not in got, got
+        names = set(beg) | set(end)
+        assert set(got) == names
+        for name in names:
+            want = moves_ref.calc_partition_moves(states, beg.get(name, {}), end.get(name, {}), favor)
+            assert [tuple(m) for m in got[name]] == [tuple(m) for m in want], (name, favor)
+
+
+def test_cpp_moves_mirror_emulated():
+    from test_simt_emulated import build_emu
+    cases = _moves_cases()
+    _check_moves(run_moves_cli(build_emu(), cases), cases)
+
+
+@pytest.mark.gpu
+def test_cpp_moves_mirror_gpu():
+    from blance_amd import hip
+    cases = _moves_cases()
+    _check_moves(run_moves_cli(hip.LIB_PATH, cases), cases)
