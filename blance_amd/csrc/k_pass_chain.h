@@ -136,7 +136,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     int* cszL = clsL + size;                         // leaves covered by class c
     int* recbuf = cszL + size;                       // [64][kCW]
     int* outbuf = recbuf + 64 * kCW;                 // [64][OW]
-    int* ntn_l = outbuf + 64 * q.OW;                 // [size][ST] nodeToNodeCounts rows, padded stride
+    int* markL = outbuf + 64 * q.OW;                 // [size + 1] first lane of a batch per top priority node
+    int* ntn_l = markL + size + 1;                   // [size][ST] nodeToNodeCounts rows, padded stride
     const int ST = size + 1;
     if (!FAST && NP > 0) {
         for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = (double)i / (double)NP;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             for (int i = lane; i < (size + 1) * ST; i += 64) ntn_l[i] = 0;    // last row: "" (flat mode)
     }
     for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
+    for (int i = lane; i <= size; i += 64) markL[i] = INT_MAX;
     __syncthreads();
 
     // lane l owns leaves lo + l + 64 u
@@ -330,11 +332,13 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             // an own node also listed in a higher priority state is no candidate (the
             // record keeps such leaves under "higher"; gather refuses nodes held twice)
             // an earlier step of the batch with the same top priority node would have bumped my row
-            if (NP > 0) {
-                for (int e = 0; e < 64; e++) {
-                    const int t2 = __builtin_amdgcn_readlane(vtl, e);
-                    if (e < a && t2 == vtl) fail = true;
-                }
+            if (NP > 0) {                              // (one LDS minimum per lane instead of 64 lane compares)
+                const int mt = (vtl >= 0 && vtl <= size) ? vtl : size;
+                if (active) atomicMin(&markL[mt], a);
+                BLANCE_WAVE_SYNC();
+                if (active && markL[mt] < a) fail = true;
+                BLANCE_WAVE_SYNC();
+                if (active) markL[mt] = INT_MAX;
             }
             if (!active) fail = false;
             const unsigned long long fm = __ballot(fail);
