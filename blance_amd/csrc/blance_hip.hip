@@ -750,11 +750,13 @@ static void launch_chain_mode(blance_ctx* c, const ChainParams& q, size_t lds, b
 static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
     int nptc = cdiv(max_size, 64);
     size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
-    if (!q.flat || q.ntn_in_lds) q.ntn_in_lds = ntn_bytes <= 100 * 1024;   // flat mode may insist on global rows
     const bool fast = q.NP == 0 && !c->any_node_weight && !c->no_fast_keys;
     size_t lds = sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
-                 sizeof(int32_t) * 64 * (size_t)(kCW + q.OW) + sizeof(int32_t) * ((size_t)max_size + 1) +
-                 (q.NP > 0 && q.ntn_in_lds ? ntn_bytes : 0) + 64;
+                 sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * ((size_t)max_size + 1) + 64;
+    // the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU);
+    // flat mode may insist on global rows
+    if (!q.flat || q.ntn_in_lds) q.ntn_in_lds = ntn_bytes <= 100 * 1024 && lds + ntn_bytes <= 156 * 1024;
+    if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
     if (q.k <= 2) {
         if (nptc <= 2) launch_chain_mode<2, 2>(c, q, lds, fast);
         else if (nptc <= 4) launch_chain_mode<4, 2>(c, q, lds, fast);

@@ -65,6 +65,7 @@ struct PassParams {
 //   15..18 leaves of its lower priority nodes inside the region, 19..22 their states
 //   23 leaves covered by the top priority node's exclude class
 constexpr int kChainOwn = 4, kChainHigh = 4, kChainLow = 4;
+constexpr int kChainStage = 256;                 // steps whose records / outputs one staging round of k_pass_chain holds in LDS
 constexpr int kChainMaxLeaves = 512;             // leaves of one region (one wave64, 8 leaves per lane)
 constexpr int kCW = 24;
 constexpr int kCOwn = 7, kCHigh = 11, kCLow = 15, kCLowState = 19;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     if (cbeg >= cend && !(q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1])) return;   // no step, no event
     const int N = q.N, NX = q.NX, M = q.M, NP = q.NP, s = q.s, k = q.k;
     // LDS: quotient tables, mirrors of the per-leaf registers (read by the stay
-    // validators), a 64-step staging area for records and outputs (no global memory
+    // validators), a kChainStage-step staging area for records and outputs (no global memory
     // operation inside the step loop), the region's nodeToNodeCounts rows
     double* lp_tab = (double*)lds;                   // [kLpTab]
     double* ff_tab = lp_tab + kLpTab;                // [kFfTab]
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     int* flgL = wgtL + size;                         // bit 0 alive (in nodesNext), bit 1 has weight
     int* clsL = flgL + size;                         // exclude class of the leaf's node, -1 if none
     int* cszL = clsL + size;                         // leaves covered by class c
-    int* recbuf = cszL + size;                       // [64][kCW]
-    int* outbuf = recbuf + 64 * kCW;                 // [64][OW]
-    int* markL = outbuf + 64 * q.OW;                 // [size + 1] first lane of a batch per top priority node
+    int* recbuf = cszL + size;                       // [kChainStage][kCW]
+    int* outbuf = recbuf + kChainStage * kCW;        // [kChainStage][OW]
+    int* markL = outbuf + kChainStage * q.OW;                 // [size + 1] first lane of a batch per top priority node
     int* ntn_l = markL + size + 1;                   // [size][ST] nodeToNodeCounts rows, padded stride
     const int ST = size + 1;
     if (!FAST && NP > 0) {
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     };
     PH_DECL;
 
-    for (int base = cbeg; base < cend && !escaped; base += 64) {
-      const int nb = cend - base < 64 ? cend - base : 64;
+    for (int base = cbeg; base < cend && !escaped; base += kChainStage) {
+      const int nb = cend - base < kChainStage ? cend - base : kChainStage;
       PH(0);
       for (int i = lane; i < nb * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
       __syncthreads();
