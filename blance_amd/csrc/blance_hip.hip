@@ -967,7 +967,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 bool lean = false;
                 if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4) {
                     const int nptc = cdiv(rr.max_size, 64);
-                    const size_t lds = sizeof(int32_t) * ((size_t)rr.max_size + 64 * (size_t)(kCW + OW)) + 64;
+                    const size_t lds = sizeof(int32_t) * ((size_t)rr.max_size + kChainStage * (size_t)(kCW + OW)) + 64;
                     if (k <= 2) {
                         if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 2>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
                         else { auto kern = k_pass_chain_blank<4, 2>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }

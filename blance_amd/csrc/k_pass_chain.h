@@ -762,8 +762,8 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
     if (cbeg >= cend) return;
     const int k = q.k;
     int* nidL = (int*)lds;                           // [size]
-    int* recbuf = nidL + size;                       // [64][kCW]
-    int* outbuf = recbuf + 64 * kCW;                 // [64][OW] leaf indices, turned into node ids at the flush
+    int* recbuf = nidL + size;                       // [kChainStage][kCW]
+    int* outbuf = recbuf + kChainStage * kCW;        // [kChainStage][OW] leaf indices, turned into node ids at the flush
     int nid[NPTC], cntv[NPTC], cls[NPTC];
     unsigned alive_m = 0;
     bool bad = size > 256 || q.NP != 0 || (q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1]);
@@ -806,13 +806,15 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
                                       : kKeyNone;
     }
     bool failed = __ballot(bad) != 0;
-    for (int base = cbeg; base < cend && !failed; base += 64) {
-        const int nb = cend - base < 64 ? cend - base : 64;
-        for (int i = lane; i < nb * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
-        __syncthreads();
+    for (int base = cbeg; base < cend && !failed; base += kChainStage) {
+      const int nbs = cend - base < kChainStage ? cend - base : kChainStage;     // steps staged this round
+      for (int i = lane; i < nbs * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
+      __syncthreads();
+      for (int sub = 0; sub < nbs && !failed; sub += 64) {                         // 64 steps: lane r keeps step r's words
+        const int nb = nbs - sub < 64 ? nbs - sub : 64;
         const bool active = lane < nb;
-        const int* rp = recbuf + (active ? lane : 0) * kCW;
-        const int w0 = recbuf[1];
+        const int* rp = recbuf + (sub + (active ? lane : 0)) * kCW;
+        const int w0 = recbuf[sub * kCW + 1];
         const int tcv = rp[6];
         int hv[kChainHigh];
 #pragma unroll
@@ -878,14 +880,16 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
         if (__ballot(esc)) { failed = true; break; }
         if (active) {
 #pragma unroll
-            for (int c = 0; c < KM; c++) if (c < k) outbuf[lane * q.OW + 1 + c] = my_w[c];
+            for (int c = 0; c < KM; c++) if (c < k) outbuf[(sub + lane) * q.OW + 1 + c] = my_w[c];
         }
-        __syncthreads();
-        for (int i = lane; i < nb * q.OW; i += 64) {
-            const int c = i % q.OW;
-            q.out[(size_t)base * q.OW + i] = c == 0 ? k : nidL[outbuf[i]];
-        }
-        __syncthreads();
+      }
+      if (failed) break;
+      __syncthreads();
+      for (int i = lane; i < nbs * q.OW; i += 64) {
+          const int c = i % q.OW;
+          q.out[(size_t)base * q.OW + i] = c == 0 ? k : nidL[outbuf[i]];
+      }
+      __syncthreads();
     }
     if (failed) {
         if (lane == 0) q.flags[1] = 1;
