@@ -183,7 +183,9 @@ typedef struct blance_result {
 typedef struct blance_options {
     int32_t engine;           /* BLANCE_ENGINE_*                                         */
     int32_t device_id;        /* HIP device ordinal                                      */
-    int32_t reserved[6];
+    int32_t reserved[6];      /* zero in production.  Test knobs: [0] workgroup size of k_pass_seq (64 / 256 / 512 /
+                               * 1024), [1] smallest pass handed to the bulk engines, [2] & 1 = k_pass_seq without
+                               * verified-stay speculation                                                    */
 } blance_options;
 
 typedef struct blance_ctx blance_ctx;   /* opaque: device buffers, stream, events */
