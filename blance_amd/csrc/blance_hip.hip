@@ -19,6 +19,7 @@
 #endif
 
 #include <limits.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +36,7 @@
 
 #include "dev_common.h"
 #include "k_pass_seq.h"
+#include "k_pass_tree.h"
 #include "k_pass_chain.h"
 #include "k_flat.h"
 #include "k_sweep.h"
@@ -94,6 +96,9 @@ struct blance_ctx {
     int any_node_weight = 0;
     bool no_fast_keys = false;      // a chain left the packed keys' range during this pass
     bool no_seq_spec = false;       // test knob (options.reserved[2] & 1): k_pass_seq without stay speculation
+    bool no_tree = false;           // test knob (& 2): flat passes never on k_pass_tree
+    bool tree_dense = false;        // test knob (& 4): k_pass_tree scores every node in every general step
+    bool tree_always = false;       // test knob (& 8): k_pass_tree even when a k_pass_seq workgroup size is forced
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -256,6 +261,9 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->force_threads = opt ? opt->reserved[0] : 0;
     if (opt && opt->reserved[1] > 0) c->chain_min_parts = opt->reserved[1];
     c->no_seq_spec = opt && (opt->reserved[2] & 1);
+    c->no_tree = opt && (opt->reserved[2] & 2);
+    c->tree_dense = opt && (opt->reserved[2] & 4);
+    c->tree_always = opt && (opt->reserved[2] & 8);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -543,7 +551,23 @@ static void launch_pass(blance_ctx* c, PassParams q) {
     }
 }
 
+// Flat passes (no hierarchy rule for the state) of up to kTreeMaxNodes node names: one wave64,
+// bound-ordered candidates (k_pass_tree.h) -- the cost of a step does not grow with the cluster.
+static bool dispatch_tree(blance_ctx* c, PassParams q) {
+    if (c->no_tree || c->engine == BLANCE_ENGINE_SEQUENTIAL) return false;
+    if (c->force_threads != 0 && !c->tree_always) return false;
+    if (q.rule_begin < q.rule_end || q.NX > kTreeMaxNodes || q.NX < 1 || q.k < 1 || q.k > 4) return false;
+    const size_t lds = tree_lds_bytes(q.NX, q.RW);
+    if (lds > 160 * 1024) return false;
+    q.spec = c->tree_dense ? 2 : 0;
+    if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
+    if (q.k <= 2) { auto kern = k_pass_tree<2>; BLANCE_LAUNCH(kern, 1, 64, lds, c->stream, q); }
+    else { auto kern = k_pass_tree<4>; BLANCE_LAUNCH(kern, 1, 64, lds, c->stream, q); }
+    return true;
+}
+
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
+    if (dispatch_tree(c, q)) return 0;
     // T threads own NPT nodes each (register resident); one workgroup runs the pass.  A step is a
     // chain of dependent instructions in every wave (about 11 cycles each, measured).
     const int NX = q.NX > 0 ? q.NX : 1;

@@ -69,14 +69,16 @@ class Planner:
     """One blance_ctx: a planner bound to one gfx950 device."""
 
     def __init__(self, device_id=0, engine=abi.ENGINE_AUTO, lib_path=None, force_threads=0,
-                 chain_min_parts=0, seq_speculation=True):
+                 chain_min_parts=0, seq_speculation=True, tree="auto"):
         self.lib = load_library(lib_path)
         opt = abi.Options()
         opt.engine = engine
         opt.device_id = device_id
         opt.reserved[0] = force_threads      # workgroup size of the sequential pass (0 = auto)
         opt.reserved[1] = chain_min_parts    # smallest pass run as region chains (0 = default)
-        opt.reserved[2] = 0 if seq_speculation else 1   # test knob: k_pass_seq without verified stays
+        # test knobs: 1 = k_pass_seq without verified stays; k_pass_tree (flat passes): 2 = never,
+        # 4 = every general step scores all nodes, 8 = also when a k_pass_seq workgroup size is forced
+        opt.reserved[2] = (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))
         self._h = h

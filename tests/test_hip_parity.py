@@ -194,16 +194,44 @@ def test_config5_miniature_hierarchy(planner):
     _rebalance(planner, P=6000, N=256, hierarchy=True)
 
 
-@pytest.mark.parametrize("N", [600, 1500, 5000])
+@pytest.mark.parametrize("N", [600, 1500, 4096, 5000])
 def test_config5_wide_flat_cluster(planner, N):
-    """Flat clusters beyond one wave64's reach: the workgroup pass (k_pass_seq) with
-    verified-stay speculation, weights and stickiness; same answer with it switched off."""
+    """Flat clusters beyond one wave64's registers: up to 4,096 names the tournament-tree pass
+    (k_pass_tree), beyond that the workgroup pass (k_pass_seq) with verified-stay speculation;
+    weights and stickiness.  Same answer from k_pass_seq with and without its speculation."""
     r1, r2 = _rebalance(planner, P=5000, N=N, hierarchy=False)
     assert r2.struct.steps_batched > 0
-    plain = hip.Planner(device_id=0, seq_speculation=False)
-    p1, p2 = _rebalance(plain, P=5000, N=N, hierarchy=False)
-    plain.close()
-    assert (p1.digest(), p2.digest()) == (r1.digest(), r2.digest())
+    for kw in (dict(tree="off"), dict(tree="off", seq_speculation=False)):
+        plain = hip.Planner(device_id=0, **kw)
+        p1, p2 = _rebalance(plain, P=5000, N=N, hierarchy=False)
+        plain.close()
+        assert (p1.digest(), p2.digest()) == (r1.digest(), r2.digest())
+
+
+def test_tree_pass_dense_mode(golden_cases):
+    """k_pass_tree with its candidate walk switched off: every general step scores all nodes."""
+    pl = hip.Planner(device_id=0, tree="dense")
+    for c in golden_cases:
+        fp = build_from_case(c)
+        _same(pl.plan(fp), _oracle(fp), c["source"])
+    for seed in range(300):
+        try:
+            fp = build_from_case(random_case(seed))
+        except problem.Unsupported:
+            continue
+        _same(pl.plan(fp), _oracle(fp), seed)
+    _rebalance(pl, P=3000, N=700, hierarchy=False)
+    pl.close()
+
+
+@pytest.mark.parametrize("P,N", [(30000, 1000), (20000, 4096), (50000, 300)])
+def test_tree_pass_flat_weighted(planner, P, N):
+    """Larger weighted flat instances (config 5's generator at reduced size): initial plan and rebalance."""
+    fp1 = synth.config5_initial(P, N)
+    r1 = planner.plan(fp1)
+    _same(r1, _oracle(fp1), ("config5 initial", P, N))
+    fp2 = synth.config5_rebalance(fp1, r1, P, N)
+    _same(planner.plan(fp2), _oracle(fp2), ("config5 rebalance", P, N))
 
 
 def test_wide_hierarchy_regions(planner):
