@@ -5,25 +5,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 // (fp64 scores must keep the reference's operation order, plan.go:634-689).
-#ifndef BLANCE_SIMT_EMU
-#include <hip/hip_runtime.h>
-#define BLANCE_LAUNCH(kern, grid, block, lds, stream, ...) \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
-#define BLANCE_LAUNCH_NOSYNC BLANCE_LAUNCH   /* kernel has no barrier / cross-lane op */
-#define BLANCE_DYN_LDS(ptr)                                        \
-    extern __shared__ __align__(16) unsigned char blance_lds_[];   \
-    unsigned char* ptr = blance_lds_
-// a wave64 runs in lockstep: LDS writes of one lane are seen by the other lanes'
-// later reads without a barrier; this only pins the compiler's schedule
-#define BLANCE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
-
-#include <limits.h>
-#include <math.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+#include "dev_prelude.h"
 
 #include <algorithm>
 #include <mutex>
@@ -31,15 +13,13 @@
 #include <string>
 #include <vector>
 
-#include "../../include/blance_hip.h"
-#include "blance_kernels.h"
-
-#include "dev_common.h"
-#include "k_pass_seq.h"
-#include "k_pass_tree.h"
-#include "k_pass_chain.h"
 #include "k_flat.h"
 #include "k_sweep.h"
+#ifdef BLANCE_SIMT_EMU          /* the emulator build is one translation unit */
+#include "tu_seq.hip"
+#include "tu_tree.hip"
+#include "tu_chain.hip"
+#endif
 
 
 // ============================================================================
@@ -99,6 +79,7 @@ struct blance_ctx {
     bool no_tree = false;           // test knob (& 2): flat passes never on k_pass_tree
     bool tree_dense = false;        // test knob (& 4): k_pass_tree scores every node in every general step
     bool tree_always = false;       // test knob (& 8): k_pass_tree even when a k_pass_seq workgroup size is forced
+    bool tree_long = false;         // test knob (& 16): k_pass_tree decodes the record in every general step
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -264,6 +245,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->no_tree = opt && (opt->reserved[2] & 2);
     c->tree_dense = opt && (opt->reserved[2] & 4);
     c->tree_always = opt && (opt->reserved[2] & 8);
+    c->tree_long = opt && (opt->reserved[2] & 16);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -527,71 +509,17 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     return BLANCE_OK;
 }
 
-template <int T, int NPT, bool HIER, int KM>
-static void launch_pass_v(blance_ctx* c, const PassParams& q, size_t lds) {
-    auto kern = k_pass_seq<T, NPT, HIER, KM>;
-    BLANCE_LAUNCH(kern, 1, T, lds, c->stream, q);
-}
-
-template <int T, int NPT>
-static void launch_pass(blance_ctx* c, PassParams q) {
-    size_t lds = sizeof(RedSlot) * 2 * (T / 64) + sizeof(double) * kLpTab + 64;
-    // flat passes: LDS mirrors for the verified-stay speculation (k_pass_seq.h)
-    const size_t mirrors = sizeof(int32_t) * (3 * (size_t)q.NX + 4) + 32;
-    const bool rules = q.rule_begin < q.rule_end;
-    q.spec = (!rules && !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL &&
-              lds + mirrors <= 150 * 1024) ? 1 : 0;
-    if (q.spec) lds += mirrors;
-    if (rules) {
-        if (q.k <= 2) launch_pass_v<T, NPT, true, 2>(c, q, lds);
-        else launch_pass_v<T, NPT, true, kMaxK>(c, q, lds);
-    } else {
-        if (q.k <= 2) launch_pass_v<T, NPT, false, 2>(c, q, lds);
-        else launch_pass_v<T, NPT, false, kMaxK>(c, q, lds);
-    }
-}
-
-// Flat passes (no hierarchy rule for the state) of up to kTreeMaxNodes node names: one wave64,
-// bound-ordered candidates (k_pass_tree.h) -- the cost of a step does not grow with the cluster.
-static bool dispatch_tree(blance_ctx* c, PassParams q) {
-    if (c->no_tree || c->engine == BLANCE_ENGINE_SEQUENTIAL) return false;
-    if (c->force_threads != 0 && !c->tree_always) return false;
-    if (q.rule_begin < q.rule_end || q.NX > kTreeMaxNodes || q.NX < 1 || q.k < 1 || q.k > 4) return false;
-    const size_t lds = tree_lds_bytes(q.NX, q.RW);
-    if (lds > 160 * 1024) return false;
-    q.spec = c->tree_dense ? 2 : 0;
-    if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
-    if (q.k <= 2) { auto kern = k_pass_tree<2>; BLANCE_LAUNCH(kern, 1, 64, lds, c->stream, q); }
-    else { auto kern = k_pass_tree<4>; BLANCE_LAUNCH(kern, 1, 64, lds, c->stream, q); }
-    return true;
-}
-
+// A state pass (or a sub-range of one) in order.  Flat passes (no hierarchy rule for the state) of up
+// to kTreeMaxNodes node names: one wave64 with bound-ordered candidates (k_pass_tree.h) -- the cost
+// of a step does not grow with the cluster; everything else: the workgroup pass k_pass_seq.
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
-    if (dispatch_tree(c, q)) return 0;
-    // T threads own NPT nodes each (register resident); one workgroup runs the pass.  A step is a
-    // chain of dependent instructions in every wave (about 11 cycles each, measured).
-    const int NX = q.NX > 0 ? q.NX : 1;
-    // measured per general step (us): 1,024 nodes: 2.25 with 256 x 4, 1.93 with 512 x 2; 4,096 nodes: 3.43 with
-    // 512 x 8, 2.92 with 1024 x 4 -- two waves per SIMD hide each other's latency, more nodes per thread cost more
-    int T = c->force_threads;
-    if (T != 64 && T != 256 && T != 512 && T != 1024) T = NX <= 256 ? 64 : (NX <= 1024 ? 512 : 1024);
-    if (T == 64 && NX > 256) T = 256;
-    if ((T == 256 || T == 512) && NX > 1024) T = 1024;
-    const int npt = cdiv(NX, T);
-    if (T == 64) {
-        if (npt <= 1) launch_pass<64, 1>(c, q);
-        else launch_pass<64, 4>(c, q);
-    } else if (T == 256) {
-        if (npt <= 1) launch_pass<256, 1>(c, q);
-        else launch_pass<256, 4>(c, q);
-    } else if (T == 512) {
-        launch_pass<512, 2>(c, q);
-    } else {
-        if (npt <= 2) launch_pass<1024, 2>(c, q);
-        else if (npt <= 4) launch_pass<1024, 4>(c, q);
-        else if (npt <= 8) launch_pass<1024, 8>(c, q);
-        else return fail(BLANCE_ERR_UNSUPPORTED, "too many nodes for the register-resident pass");
+    const bool tree = !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always);
+    if (tree && launch_pass_tree(c->stream, q, (c->tree_dense ? 1 : 0) | (c->tree_long ? 2 : 0))) {
+        if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
+        return 0;
     }
+    if (launch_pass_seq(c->stream, q, c->force_threads, !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL))
+        return fail(BLANCE_ERR_UNSUPPORTED, "too many nodes for the register-resident pass");
     return 0;
 }
 
@@ -629,7 +557,6 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
     return 0;
 }
 
-static int dispatch_pass(blance_ctx* c, const PassParams& q);
 static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size);
 
 // Steps [beg, end) of a flat pass on ONE wave64 (clusters of <= 256 node names): the
@@ -758,43 +685,9 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     return 0;
 }
 
-template <int NPTC, int KM, bool FAST>
-static void launch_chain(blance_ctx* c, const ChainParams& q, size_t lds) {
-    auto kern = k_pass_chain<NPTC, KM, FAST>;
-    BLANCE_LAUNCH(kern, q.n_regions, 64, lds, c->stream, q);
-}
-
-template <int NPTC, int KM>
-static void launch_chain_mode(blance_ctx* c, const ChainParams& q, size_t lds, bool fast) {
-    if (fast) launch_chain<NPTC, KM, true>(c, q, lds);
-    else launch_chain<NPTC, KM, false>(c, q, lds);
-}
-
-// one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
 static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
-    int nptc = cdiv(max_size, 64);
-    size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
     const bool fast = q.NP == 0 && !c->any_node_weight && !c->no_fast_keys;
-    size_t lds = sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
-                 sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * ((size_t)max_size + 1) + 64;
-    // the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU);
-    // flat mode may insist on global rows
-    if (!q.flat || q.ntn_in_lds) q.ntn_in_lds = ntn_bytes <= 100 * 1024 && lds + ntn_bytes <= 156 * 1024;
-    if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
-    if (q.k <= 2) {
-        if (nptc <= 2) launch_chain_mode<2, 2>(c, q, lds, fast);
-        else if (nptc <= 4) launch_chain_mode<4, 2>(c, q, lds, fast);
-        else if (nptc <= 8) launch_chain_mode<8, 2>(c, q, lds, fast);
-        else return false;
-    } else if (q.k <= 4) {
-        if (nptc <= 2) launch_chain_mode<2, 4>(c, q, lds, fast);
-        else if (nptc <= 4) launch_chain_mode<4, 4>(c, q, lds, fast);
-        else if (nptc <= 8) launch_chain_mode<8, 4>(c, q, lds, fast);
-        else return false;
-    } else {
-        return false;
-    }
-    return true;
+    return launch_chain(c->stream, q, max_size, fast);
 }
 
 // developer aid: BLANCE_DUMP_SWEEP=<i> prints every step's choice of sweep i (pass order)
@@ -990,15 +883,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 // does the whole pass or changes nothing that is not restored below
                 bool lean = false;
                 if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4) {
-                    const int nptc = cdiv(rr.max_size, 64);
-                    const size_t lds = sizeof(int32_t) * ((size_t)rr.max_size + kChainStage * (size_t)(kCW + OW)) + 64;
-                    if (k <= 2) {
-                        if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 2>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
-                        else { auto kern = k_pass_chain_blank<4, 2>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
-                    } else {
-                        if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 4>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
-                        else { auto kern = k_pass_chain_blank<4, 4>; BLANCE_LAUNCH(kern, B, 64, lds, sm, cq); }
-                    }
+                    launch_chain_blank(sm, cq, rr.max_size);
                     int32_t fl[2] = {0, 0};
                     HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
                     HIPTRY(hipStreamSynchronize(sm));

@@ -1,0 +1,38 @@
+// Common prelude of every translation unit of libblance_hip.so (and of the SIMT emulator build, which
+// includes them all into one): launch macros, the parameter blocks, the device helpers.
+#pragma once
+#ifndef BLANCE_SIMT_EMU
+#include <hip/hip_runtime.h>
+#define BLANCE_LAUNCH(kern, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+#define BLANCE_LAUNCH_NOSYNC BLANCE_LAUNCH   /* kernel has no barrier / cross-lane op */
+#define BLANCE_DYN_LDS(ptr)                                        \
+    extern __shared__ __align__(16) unsigned char blance_lds_[];   \
+    unsigned char* ptr = blance_lds_
+// a wave64 runs in lockstep: LDS writes of one lane are seen by the other lanes'
+// later reads without a barrier; this only pins the compiler's schedule
+#define BLANCE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/blance_hip.h"
+#include "blance_kernels.h"
+#include "dev_common.h"
+
+namespace blance {
+// ---- launch wrappers: one translation unit per pass-kernel family (they compile in parallel)
+// k_pass_seq (tu_seq.hip): 0, or -1 when the cluster is too wide for the register-resident pass
+int launch_pass_seq(hipStream_t stream, PassParams q, int force_threads, bool allow_spec);
+// k_pass_tree (tu_tree.hip): false when the pass is outside its envelope (nothing launched)
+bool launch_pass_tree(hipStream_t stream, PassParams q, int knobs);
+// k_pass_chain (tu_chain.hip): one wave64 per region; false when the shape has no variant
+bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
+// k_pass_chain_blank (tu_chain.hip): the lean first-sweep kernel
+void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size);
+}  // namespace blance

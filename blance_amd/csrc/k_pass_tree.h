@@ -35,7 +35,7 @@ namespace blance {
 // The walk is bounded (kWalkCap candidates); beyond that the step is resolved by
 // scoring every node (dense_pick) -- correctness never depends on the bound.
 // ============================================================================
-constexpr int kTreeMaxNodes = 4096;      // LDS budget: 21 bytes per node + tables
+constexpr int kTreeMaxNodes = 4096;      // LDS budget: 25 bytes per node + tables
 constexpr int kWalkCap = 24;
 
 #ifndef BLANCE_SIMT_EMU
@@ -96,24 +96,26 @@ __device__ __forceinline__ bool key_less(unsigned long long a, int an, unsigned 
 template <int KM>
 __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
     typedef unsigned long long u64;
+    constexpr int KH = 2, KO = 4;                    // higher / other state nodes a lane keeps for the short general step
     BLANCE_DYN_LDS(lds);
     const int lane = threadIdx.x;
     const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k, RW = q.RW;
     const int SW = 1 + L;                            // words per state inside a record
     const int G = (NX + 63) >> 6, NXp = G << 6;
     const int walk_cap = (q.spec & 2) ? 0 : kWalkCap;   // test knob: every general step scores all nodes
+    const bool no_short = (q.spec & 4) != 0;         // test knob: every general step decodes its record
 
     u64* gB = (u64*)lds;                             // [NXp] sortable image of g, ~0 for nodes that are no candidates
     int* cntL = (int*)(gB + NXp);                    // [NXp] stateNodeCounts[s]
     int* totL = cntL + NXp;                          // [NXp] nodePartitionCounts (plan.go:118-124)
     int* wL = totL + NXp;                            // [NXp] node weights
     int* recS = wL + NXp;                            // [64 * RW] step records of the batch
-    int* sn = recS + 64 * RW;                        // [64 groups][64 steps] prefetched nodeToNodeCounts entries
-    double* lpT = (double*)(sn + 64 * 64);           // [kLpTab] c / NP
+    double* lpT = (double*)(recS + 64 * RW);         // [kLpTab] c / NP
     double* ffT = lpT + kLpTab;                      // [kFfTab] (0.001 * t) / NP
     u64* stkB = (u64*)(ffT + kFfTab);                // [kWalkCap] leaves taken out of the tree during a walk
     int* stkN = (int*)(stkB + kWalkCap);             // [kWalkCap]
-    unsigned char* flL = (unsigned char*)(stkN + kWalkCap);   // [NXp] 1: in nodesNext, 2: has a weight
+    int* ntL = stkN + kWalkCap;                      // [NXp] folded mode: the shared row of nodeToNodeCounts
+    unsigned char* flL = (unsigned char*)(ntL + NXp);   // [NXp] 1: in nodesNext, 2: has a weight
 
     for (int i = lane; i < kLpTab; i += 64) lpT[i] = NP > 0 ? (double)i / (double)NP : 0.0;
     for (int i = lane; i < kFfTab; i += 64) ffT[i] = NP > 0 ? (0.001 * (double)i) / (double)NP : 0.0;
@@ -127,11 +129,18 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             w = q.node_weight[n];
             fl = ((n < N && q.alive[n]) ? 1 : 0) | (q.node_has_weight[n] ? 2 : 0);
         }
-        cntL[n] = c; totL[n] = t; wL[n] = w; flL[n] = (unsigned char)fl;
-        gB[n] = (fl & 1) ? sortable_bits(tree_score(c, 0, t, fl >> 1, w, NP, 0.0, q.booster_kind, lpT, ffT)) : ~0ull;
+        cntL[n] = c; totL[n] = t; wL[n] = w; flL[n] = (unsigned char)fl; ntL[n] = 0;
     }
     BLANCE_WAVE_SYNC();
 
+    // Folded mode: while every step of a batch has the SAME nodeToNodeCounts row (partitions without a
+    // top priority node: row ""), that row's term is part of the leaf keys -- a candidate's exact score
+    // is its leaf and a walk never reads the matrix.  fold = the row, or -1.
+    int fold = -1;
+    auto leaf_key = [&](int n) -> u64 {
+        return (flL[n] & 1) ? sortable_bits(tree_score(cntL[n], fold >= 0 ? ntL[n] : 0, totL[n], (flL[n] >> 1) & 1, wL[n], NP,
+                                                      0.0, q.booster_kind, lpT, ffT)) : ~0ull;
+    };
     // group minima: lane i keeps the smallest (g, node) of leaves [64 i, 64 i + 64)
     unsigned gm_hi = kKeyNoneV, gm_lo = kKeyNoneV;
     int gm_n = INT_MAX;
@@ -141,25 +150,37 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         rh = m.hi; rl = m.lo;
         rn = (m.hi & m.lo) == kKeyNoneV ? INT_MAX : i * 64 + m.lane;
     };
-    for (int i = 0; i < G; i++) {
-        unsigned rh, rl; int rn;
-        scan_group(i, rh, rl, rn);
-        if (lane == i) { gm_hi = rh; gm_lo = rl; gm_n = rn; }
-    }
+    auto rebuild_tree = [&]() {
+        for (int i = 0; i < G; i++) gB[i * 64 + lane] = leaf_key(i * 64 + lane);
+        BLANCE_WAVE_SYNC();
+        for (int i = 0; i < G; i++) {
+            unsigned rh, rl; int rn;
+            scan_group(i, rh, rl, rn);
+            if (lane == i) { gm_hi = rh; gm_lo = rl; gm_n = rn; }
+        }
+    };
+    rebuild_tree();
     bool root_valid = false;
     u64 rootB = ~0ull;
     int root_n = INT_MAX;
 
-    // which word of the record's state lists this lane looks at in a general step
+    // which word of the record's state lists this lane looks at when a general step decodes its record
     const int slot_t = lane / SW, slot_ix = lane - slot_t * SW;
     const bool slot_ok = lane < M * SW;
     const bool slot_higher = slot_ok && ((q.higher_mask >> slot_t) & 1);
 
     long long n_bulk = 0;
-    int snn = INT_MAX;                               // the node my group's prefetched entries belong to
+    PH_DECL;
+#ifdef BLANCE_PHASE_PROF
+    long long pc_general = 0, pc_taken = 0, pc_miss = 0, pc_batches = 0, pc_scans = 0, pc_short = 0, pc_stay = 0, pc_reorder = 0, pc_half = 0;
+#define PC(x) (x)++
+#else
+#define PC(x)
+#endif
 
     for (int oi = q.beg; oi < q.end; oi += 64) {
         const int B = q.end - oi < 64 ? q.end - oi : 64;
+        PH(11); PC(pc_batches);
         BLANCE_AGENT_FENCE();                        // earlier bumps of nodeToNodeCounts are visible to the loads below
         for (int r = 0; r < RW; r++) {
             const int idx = r * 64 + lane;
@@ -167,15 +188,22 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         }
         BLANCE_WAVE_SYNC();
 
-        // ---- lane j looks at step oi + j: can it be a certain stay?
+        PH(0);
+        // ---- lane j looks at step oi + j: can it be a certain stay?  What it learns about the step
+        // (weight, row, own / higher / other nodes, exact scores of the own nodes) stays in its registers.
         const bool act = lane < B;
         const int* rj = recS + (act ? lane : 0) * RW;
         int row = NX;
-        int ownv[KM], ntn_own[KM];
+        const int wj = rj[1];
+        int ownv[KM], ntn_own[KM], hv[KH], ov[KO];
+        unsigned oKh[KM], oKl[KM];
 #pragma unroll
-        for (int j = 0; j < KM; j++) { ownv[j] = 0; ntn_own[j] = 0; }
+        for (int j = 0; j < KM; j++) { ownv[j] = 0; ntn_own[j] = 0; oKh[j] = kKeyNoneV; oKl[j] = kKeyNoneV; }
+#pragma unroll
+        for (int j = 0; j < KH; j++) hv[j] = -1;
+#pragma unroll
+        for (int j = 0; j < KO; j++) ov[j] = -1;
         bool pok = act;                              // own list complete and inside nodesAll: ntn_own is loaded
-        bool sfail = !act;
         const double vstick = __hiloint2double(rj[3], rj[2]);
         {
             const int hT = rj[kRecHead + q.top_state * SW];
@@ -192,75 +220,123 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                     }
                 }
             }
-            if (!pok) sfail = true;
-            if (!sfail) {
+        }
+        // simple: every own node is a candidate, held once, in no other list; few nodes in the other lists
+        bool simple = pok;
+        if (simple) {
 #pragma unroll
-                for (int j = 0; j < KM; j++) {
-                    if (j < k) {
-                        if (!(flL[ownv[j]] & 1)) sfail = true;
+            for (int j = 0; j < KM; j++) {
+                if (j < k) {
+                    if (!(flL[ownv[j]] & 1)) simple = false;
 #pragma unroll
-                        for (int jj = 0; jj < KM; jj++) if (jj < j && ownv[jj] == ownv[j]) sfail = true;
-                    }
+                    for (int jj = 0; jj < KM; jj++) if (jj < j && ownv[jj] == ownv[j]) simple = false;
                 }
-                // held in another state as well: excluded (higher) or demoted (lower) -- not a plain stay
-                for (int t = 0; t < M; t++) {
-                    if (t == s) continue;
-                    const int h = rj[kRecHead + t * SW];
-                    if ((h >> 16) == kListAbsent) continue;
-                    for (int jj = 0; jj < (h & 0xffff); jj++) {
-                        const int x = rj[kRecHead + t * SW + 1 + jj];
+            }
+            int n_h = 0, n_o = 0;
+            for (int t = 0; t < M; t++) {
+                if (t == s) continue;
+                const int h = rj[kRecHead + t * SW];
+                if ((h >> 16) == kListAbsent) continue;
+                const bool higher = (q.higher_mask >> t) & 1;
+                for (int jj = 0; jj < (h & 0xffff); jj++) {
+                    const int x = rj[kRecHead + t * SW + 1 + jj];
 #pragma unroll
-                        for (int j = 0; j < KM; j++) if (j < k && ownv[j] == x) sfail = true;
+                    for (int j = 0; j < KM; j++) if (j < k && ownv[j] == x) simple = false;   // excluded or demoted: not a plain stay
+                    if (higher) {
+                        if (n_h >= KH) simple = false;
+#pragma unroll
+                        for (int e = 0; e < KH; e++) if (e == n_h) hv[e] = x;
+                        n_h++;
+                    } else {
+                        if (n_o >= KO || x > 0xffff) simple = false;
+#pragma unroll
+                        for (int e = 0; e < KO; e++) if (e == n_o) ov[e] = x | (t << 16);
+                        n_o++;
                     }
                 }
             }
         }
+        PH(1);
         bool dirty = false;                          // an earlier step of the batch bumps my row
         if (NP > 0) {
 #pragma unroll
             for (int j = 0; j < KM; j++)
                 if (pok && j < k) ntn_own[j] = BLANCE_LD_COHERENT(q.ntn + (size_t)row * N + ownv[j]);
-            for (int i = 0; i < G; i++) {
-                const int gn = __builtin_amdgcn_readlane(gm_n, i);
-                int v = 0;
-                if (act && gn < N) v = BLANCE_LD_COHERENT(q.ntn + (size_t)row * N + gn);
-                sn[i * 64 + lane] = v;
-            }
-            snn = gm_n;
             for (int i = 0; i < B - 1; i++) {
                 const int ri = __builtin_amdgcn_readlane(row, i);
                 if (lane > i && row == ri) dirty = true;
             }
         }
+        if (NP > 0) {
+            // every step of the batch without a top priority node: fold the shared row "" into the leaves
+            const int want = (__ballot(act && row != NX) == 0) ? NX : -1;
+            if (want != fold) {
+                fold = want;
+#ifdef BLANCE_FOLD_TRACE
+                if (lane == 0) printf("[tree] batch at step %d: fold -> %d\n", oi, fold);
+#endif
+                if (fold >= 0)
+                    for (int i = 0; i < G; i++) {
+                        const int n = i * 64 + lane;
+                        ntL[n] = n < N ? BLANCE_LD_COHERENT(q.ntn + (size_t)fold * N + n) : 0;
+                    }
+                BLANCE_WAVE_SYNC();
+                rebuild_tree();
+                root_valid = false;
+            }
+        }
+        PH(2);
         u64 lastB = 0;
         int lastN = -1;
-        if (!sfail) {
-            u64 prevB = 0;
-            int prevN = -1;
+        bool sfail = !simple;
+        bool stale = false;                          // an earlier general step of the batch touched my own nodes
+        int sortv[KM];                               // the own nodes in (score, position) order: what a stay emits
+#pragma unroll
+        for (int j = 0; j < KM; j++) sortv[j] = 0;
+        if (simple) {
+            u64 sK[KM];
+#pragma unroll
+            for (int j = 0; j < KM; j++) sK[j] = ~0ull;
 #pragma unroll
             for (int j = 0; j < KM; j++) {
                 if (j < k) {
                     const int o = ownv[j];
                     const u64 b = sortable_bits(tree_score(cntL[o], ntn_own[j], totL[o], (flL[o] >> 1) & 1, wL[o], NP,
                                                            vstick, q.booster_kind, lpT, ffT));
-                    if (j > 0 && !key_less(prevB, prevN, b, o)) sfail = true;     // the list order is the score order
-                    prevB = b; prevN = o;
+                    oKh[j] = (unsigned)(b >> 32); oKl[j] = (unsigned)b;
+                    // insertion into the sorted prefix: keeping the same nodes in another order changes no counter
+                    u64 cb = b;
+                    int cn = o;
+#pragma unroll
+                    for (int e = 0; e < KM; e++) {
+                        if (e <= j) {
+                            const bool first = e == j || key_less(cb, cn, sK[e], sortv[e]);
+                            if (first) {
+                                const u64 tb = sK[e]; const int tn = sortv[e];
+                                sK[e] = cb; sortv[e] = cn;
+                                cb = tb; cn = tn;
+                            }
+                        }
+                    }
                 }
             }
-            lastB = prevB; lastN = prevN;
+#pragma unroll
+            for (int j = 0; j < KM; j++) if (j == k - 1) { lastB = sK[j]; lastN = sortv[j]; }
         }
         BLANCE_WAVE_SYNC();
 
+        PH(3);
         // ---- the batch in order: validated runs at once, the other steps one by one
         int cur = 0;
         while (cur < B) {
+            PH(11);
             if (!root_valid) {
                 const TreeMin m = wave_min_u64_lane(gm_hi, gm_lo);
                 rootB = ((u64)m.hi << 32) | m.lo;
                 root_n = __builtin_amdgcn_readlane(gm_n, m.lane);
                 root_valid = true;
             }
-            const bool fail = sfail || dirty || !key_less(lastB, lastN, rootB, root_n);
+            const bool fail = sfail || dirty || fold >= 0 || !key_less(lastB, lastN, rootB, root_n);
             const u64 fm = __ballot(act && fail) & (~0ull << cur);
             const int f = fm ? __ffsll((long long)fm) - 1 : B;
             if (lane >= cur && lane < f) {          // certain stays: plan.go:299-301 leaves everything as it is
@@ -269,73 +345,27 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
 #pragma unroll
                 for (int j = 0; j < KM; j++) {
                     if (j < k) {
-                        o[1 + j] = ownv[j];
+                        o[1 + j] = sortv[j];
                         if (NP > 0) atomicAdd(q.ntn + (size_t)row * N + ownv[j], 1);   // plan.go:238-245
                     }
                 }
             }
             n_bulk += f - cur;
+            PH(4);
             if (f >= B) break;
+            PC(pc_general);
 
             // ================= general step for lane f's record =================
             const int* rf = recS + f * RW;
-            const int p = uni(rf[0]), w = uni(rf[1]);
-            const double stick = __hiloint2double(uni(rf[3]), uni(rf[2]));
-            int top = -1;
-            {
-                const int hT = uni(rf[kRecHead + q.top_state * SW]);
-                if ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) top = uni(rf[kRecHead + q.top_state * SW + 1]);
-            }
-            const int rowf = top < 0 ? NX : top;
-            const bool pv_ok = NP > 0 && __builtin_amdgcn_readlane(pok ? 1 : 0, f) != 0 &&
-                               __builtin_amdgcn_readlane(dirty ? 1 : 0, f) == 0;
-            const bool sn_ok = NP > 0 && __builtin_amdgcn_readlane(dirty ? 1 : 0, f) == 0;
-
-            // my word of the record's lists, and what it is
-            int wd = -1;
-            bool valid = false;
-            bool hdr_present = false;
-            if (slot_ok) {
-                const int hdr = rf[kRecHead + slot_t * SW];
-                hdr_present = (hdr >> 16) != kListAbsent;
-                wd = rf[kRecHead + lane];
-                valid = slot_ix >= 1 && hdr_present && slot_ix - 1 < (hdr & 0xffff);
-            }
-            const u64 m_own = __ballot(valid && slot_t == s);
-            const u64 m_high = __ballot(valid && slot_higher);
-            const u64 m_oth = __ballot(valid && slot_t != s);
-            const bool any_higher_key = __ballot(slot_ok && slot_ix == 0 && slot_higher && hdr_present) != 0;
-            auto in_list = [&](int x, u64 mask) -> bool { return (__ballot(valid && wd == x) & mask) != 0; };
-
-            // the partition's own nodes, scored exactly by the lanes that hold them
-            const bool is_own = (m_own >> lane) & 1;
-            bool own_first = is_own;                 // first occurrence of the node in the list
-            bool own_elig = is_own && wd < N && (flL[wd < NXp && wd >= 0 ? wd : 0] & 1);
-            for (u64 mm = m_own; mm; mm &= mm - 1) {
-                const int h = __ffsll((long long)mm) - 1;
-                const int y = __builtin_amdgcn_readlane(wd, h);
-                if (is_own && lane > h && wd == y) own_first = false;
-            }
-            for (u64 mm = m_high; mm; mm &= mm - 1) {
-                const int h = __ffsll((long long)mm) - 1;
-                const int y = __builtin_amdgcn_readlane(wd, h);
-                if (is_own && wd == y) own_elig = false;              // plan.go:146-154
-            }
-            own_elig = own_elig && own_first;
-            int own_nt = 0;
-            if (NP > 0) {
-                bool have = false;
-#pragma unroll
-                for (int j = 0; j < KM; j++) {
-                    const int v = __builtin_amdgcn_readlane(ntn_own[j], f);
-                    if (pv_ok && is_own && slot_ix - 1 == j) { own_nt = v; have = true; }
-                }
-                if (own_elig && !have) own_nt = BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + wd);
-            }
-            u64 own_b = ~0ull;
-            if (own_elig)
-                own_b = sortable_bits(tree_score(cntL[wd], own_nt, totL[wd], (flL[wd] >> 1) & 1, wL[wd], NP, stick,
-                                                 q.booster_kind, lpT, ffT));
+            const int rowf = __builtin_amdgcn_readlane(row, f);
+            const int w = __builtin_amdgcn_readlane(wj, f);
+            const bool dirty_f = __builtin_amdgcn_readlane(dirty ? 1 : 0, f) != 0;
+            const bool quick = !no_short && !dirty_f && __builtin_amdgcn_readlane((simple && !stale) ? 1 : 0, f) != 0;
+            // the first candidate's nodeToNodeCounts entry: in flight while the step is decoded
+            const bool pre_ok = NP > 0 && fold < 0 && !dirty_f && root_n < N;
+            int pre_nt = 0;
+            if (pre_ok) pre_nt = BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + root_n);
+            const int pre_n = root_n;
 
             // the k best (score, position) so far; wave uniform, ascending
             u64 bB[KM];
@@ -353,13 +383,89 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                     }
                 }
             };
-            for (u64 mm = __ballot(own_elig); mm; mm &= mm - 1) {
-                const int h = __ffsll((long long)mm) - 1;
-                const unsigned bh = (unsigned)__builtin_amdgcn_readlane((int)(own_b >> 32), h);
-                const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)own_b, h);
-                insert(((u64)bh << 32) | bl, __builtin_amdgcn_readlane(wd, h));
-            }
 
+            // ---- what the step knows about its partition: from lane f's registers (quick), or from the record
+            int qown[KM], qh[KH], qo[KO];           // quick: own / higher / other nodes, wave uniform
+#pragma unroll
+            for (int j = 0; j < KM; j++) qown[j] = -1;
+#pragma unroll
+            for (int j = 0; j < KH; j++) qh[j] = -1;
+#pragma unroll
+            for (int j = 0; j < KO; j++) qo[j] = -1;
+            double stick = 0.0;
+            int wd = -1;                             // record decode: my word of the record's lists, and what it is
+            bool valid = false, own_first = false;
+            u64 m_own = 0, m_high = 0, m_oth = 0;
+            if (quick) {
+                PC(pc_short);
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < k) {
+                        qown[j] = __builtin_amdgcn_readlane(ownv[j], f);
+                        const unsigned bh = (unsigned)__builtin_amdgcn_readlane((int)oKh[j], f);
+                        const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)oKl[j], f);
+                        insert(((u64)bh << 32) | bl, qown[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < KH; j++) qh[j] = __builtin_amdgcn_readlane(hv[j], f);
+#pragma unroll
+                for (int j = 0; j < KO; j++) qo[j] = __builtin_amdgcn_readlane(ov[j], f);
+            } else {
+                stick = __hiloint2double(uni(rf[3]), uni(rf[2]));
+                bool hdr_present = false;
+                if (slot_ok) {
+                    const int hdr = rf[kRecHead + slot_t * SW];
+                    hdr_present = (hdr >> 16) != kListAbsent;
+                    wd = rf[kRecHead + lane];
+                    valid = slot_ix >= 1 && hdr_present && slot_ix - 1 < (hdr & 0xffff);
+                }
+                m_own = __ballot(valid && slot_t == s);
+                m_high = __ballot(valid && slot_higher);
+                m_oth = __ballot(valid && slot_t != s);
+                // the partition's own nodes, scored exactly by the lanes that hold them
+                const bool is_own = (m_own >> lane) & 1;
+                own_first = is_own;                  // first occurrence of the node in the list
+                bool own_elig = is_own && wd < N && (flL[is_own ? wd : 0] & 1);
+                for (u64 mm = m_own; mm; mm &= mm - 1) {
+                    const int h = __ffsll((long long)mm) - 1;
+                    const int y = __builtin_amdgcn_readlane(wd, h);
+                    if (is_own && lane > h && wd == y) own_first = false;
+                }
+                for (u64 mm = m_high; mm; mm &= mm - 1) {
+                    const int h = __ffsll((long long)mm) - 1;
+                    const int y = __builtin_amdgcn_readlane(wd, h);
+                    if (is_own && wd == y) own_elig = false;          // plan.go:146-154
+                }
+                own_elig = own_elig && own_first;
+                int own_nt = 0;
+                if (NP > 0 && own_elig) own_nt = fold >= 0 ? ntL[wd] : BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + wd);
+                u64 own_b = ~0ull;
+                if (own_elig)
+                    own_b = sortable_bits(tree_score(cntL[wd], own_nt, totL[wd], (flL[wd] >> 1) & 1, wL[wd], NP, stick,
+                                                     q.booster_kind, lpT, ffT));
+                for (u64 mm = __ballot(own_elig); mm; mm &= mm - 1) {
+                    const int h = __ffsll((long long)mm) - 1;
+                    const unsigned bh = (unsigned)__builtin_amdgcn_readlane((int)(own_b >> 32), h);
+                    const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)own_b, h);
+                    insert(((u64)bh << 32) | bl, __builtin_amdgcn_readlane(wd, h));
+                }
+            }
+            // is node c (wave uniform) one of the partition's own or higher priority nodes?
+            auto skip_node = [&](int c) -> bool {
+                if (quick) {
+                    bool hit = false;
+#pragma unroll
+                    for (int j = 0; j < KM; j++) hit = hit || (j < k && qown[j] == c);
+#pragma unroll
+                    for (int j = 0; j < KH; j++) hit = hit || qh[j] == c;
+                    return hit;
+                }
+                return (__ballot(valid && wd == c) & (m_own | m_high)) != 0;
+            };
+
+            PH(5);
+            PH(6);
             // ---- walk the candidates in (g, position) order
             unsigned wm_hi = gm_hi, wm_lo = gm_lo;
             int wm_n = gm_n;
@@ -375,12 +481,15 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                 const u64 cB = nextB;
                 if (lane == 0) { stkB[n_taken] = cB; stkN[n_taken] = c; }
                 n_taken++;
-                const bool skip = in_list(c, m_own | m_high);                   // own: scored above; higher: no candidate
-                if (!skip) {
+                PC(pc_taken);
+                if (!skip_node(c)) {                                            // own: scored already; higher: no candidate
                     int nt = 0;
-                    if (NP > 0) {
-                        const bool pref = sn_ok && __builtin_amdgcn_readlane(snn, gl) == c;
-                        nt = pref ? uni(sn[gl * 64 + f]) : uni(BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + c));
+                    if (NP > 0 && fold < 0) {                                  // folded: the leaf is the exact score
+                        const bool pref = pre_ok && pre_n == c;
+                        nt = pref ? uni(pre_nt) : uni(BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + c));
+#ifdef BLANCE_PHASE_PROF
+                        if (!pref) pc_miss++;
+#endif
                     }
                     u64 eB = cB;                                               // entry 0: the score IS g
                     if (nt != 0)
@@ -401,6 +510,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                 next_n = __builtin_amdgcn_readlane(wm_n, m.lane);
                 next_lane = m.lane;
             }
+            PH(7);
             // put the walked leaves back (the chosen ones get new values below)
             if (n_taken > 0) {
                 BLANCE_WAVE_SYNC();
@@ -409,6 +519,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             }
             if (dense) {
                 // ---- rare: score every node (exactly what the reference's sort sees), k successive minima
+                if (quick) stick = __hiloint2double(uni(rf[3]), uni(rf[2]));
 #pragma unroll
                 for (int j = 0; j < KM; j++) { bB[j] = ~0ull; bN[j] = INT_MAX; }
                 for (int pick = 0; pick < k; pick++) {
@@ -420,13 +531,20 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
 #pragma unroll
                         for (int j = 0; j < KM; j++) if (bN[j] == n) el = false;
                         bool own = false;
-                        for (u64 mm = m_high | m_own; mm; mm &= mm - 1) {
-                            const int h = __ffsll((long long)mm) - 1;
-                            const int y = __builtin_amdgcn_readlane(wd, h);
-                            if (y == n) { if ((m_high >> h) & 1) el = false; else own = true; }
+                        if (quick) {
+#pragma unroll
+                            for (int j = 0; j < KM; j++) if (j < k && qown[j] == n) own = true;
+#pragma unroll
+                            for (int j = 0; j < KH; j++) if (qh[j] == n) el = false;
+                        } else {
+                            for (u64 mm = m_high | m_own; mm; mm &= mm - 1) {
+                                const int h = __ffsll((long long)mm) - 1;
+                                const int y = __builtin_amdgcn_readlane(wd, h);
+                                if (y == n) { if ((m_high >> h) & 1) el = false; else own = true; }
+                            }
                         }
                         if (el) {
-                            const int nt = NP > 0 ? BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + n) : 0;
+                            const int nt = NP <= 0 ? 0 : (fold >= 0 ? ntL[n] : BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + n));
                             const u64 b = sortable_bits(tree_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP,
                                                                    own ? stick : 0.0, q.booster_kind, lpT, ffT));
                             if (key_less(b, n, lb, ln)) { lb = b; ln = n; }
@@ -445,39 +563,81 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             int n_out = 0;
 #pragma unroll
             for (int j = 0; j < KM; j++) if (j < k && bN[j] != INT_MAX) n_out++;
+            PH(8);
+#ifdef BLANCE_PHASE_PROF
+            if (quick) {
+                bool same = n_out == k;
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < k && bN[j] != qown[j]) same = false;
+                if (same) pc_stay++;
+                int kept = 0;
+#pragma unroll
+                for (int j = 0; j < KM; j++)
+#pragma unroll
+                    for (int jj = 0; jj < KM; jj++) if (j < k && jj < n_out && bN[jj] == qown[j]) kept++;
+                if (!same && kept == k) pc_reorder++;
+                if (kept == k - 1 && k > 1) pc_half++;
+            }
+#endif
 
             // ---- commit (plan.go:238-245, :290-301).  A node of this state's old list leaves it, a
             // chosen node enters it, and a node that is either also leaves every OTHER list of the
-            // partition that holds it.  Own nodes are handled by the lanes that hold them, newly
-            // chosen ones by lanes 60..63 (never list words: records are at most 64 words).
+            // partition that holds it.  Own nodes are settled by lanes of their own (quick: lanes
+            // 0..k-1, else the lanes that hold them), newly chosen ones by lanes 60..63 (never list
+            // words: records are at most 64 words).
             int hx = -1;                             // the node this lane settles
             bool h_own = false, h_chosen = false;
-            if (own_first) { hx = wd; h_own = true; }
-#pragma unroll
-            for (int j = 0; j < KM; j++) {
-                if (j < n_out) {
-                    const bool inown = in_list(bN[j], m_own);
-                    if (h_own && wd == bN[j]) h_chosen = true;
-                    if (!inown && lane == 60 + j) { hx = bN[j]; h_chosen = true; }
-                }
-            }
             int n_oth = 0;
-            for (u64 mm = m_oth; mm; mm &= mm - 1) {
-                const int h = __ffsll((long long)mm) - 1;
-                const int y = __builtin_amdgcn_readlane(wd, h);
-                const int ty = __builtin_amdgcn_readlane(slot_t, h);
-                if (hx >= 0 && hx == y) {
-                    n_oth++;
-                    q.cnt[ty * NX + y] -= w;         // only this lane touches that counter
+            if (quick) {
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < k && lane == j) { hx = qown[j]; h_own = true; }
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < n_out) {
+                        bool inown = false;
+#pragma unroll
+                        for (int jj = 0; jj < KM; jj++) inown = inown || (jj < k && qown[jj] == bN[j]);
+                        if (h_own && hx == bN[j]) h_chosen = true;
+                        if (!inown && lane == 60 + j) { hx = bN[j]; h_chosen = true; }
+                    }
+                }
+                if (lane >= 60 && hx >= 0) {         // a chosen node the partition holds in another state: promoted / demoted
+#pragma unroll
+                    for (int e = 0; e < KO; e++) {
+                        if (qo[e] >= 0 && (qo[e] & 0xffff) == hx) {
+                            n_oth++;
+                            q.cnt[(qo[e] >> 16) * NX + hx] -= w;
+                        }
+                    }
+                }
+            } else {
+                if (own_first) { hx = wd; h_own = true; }
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < n_out) {
+                        const bool inown = (__ballot(valid && wd == bN[j]) & m_own) != 0;
+                        if (h_own && wd == bN[j]) h_chosen = true;
+                        if (!inown && lane == 60 + j) { hx = bN[j]; h_chosen = true; }
+                    }
+                }
+                for (u64 mm = m_oth; mm; mm &= mm - 1) {
+                    const int h = __ffsll((long long)mm) - 1;
+                    const int y = __builtin_amdgcn_readlane(wd, h);
+                    const int ty = __builtin_amdgcn_readlane(slot_t, h);
+                    if (hx >= 0 && hx == y) {
+                        n_oth++;
+                        q.cnt[ty * NX + y] -= w;     // only this lane touches that counter
+                    }
                 }
             }
             const int ds = (h_chosen ? w : 0) - (h_own ? w : 0);
-            const bool changed = hx >= 0 && (ds != 0 || n_oth > 0);
+            const bool bumped = fold >= 0 && h_chosen;      // folded: the chosen node's row entry is part of its leaf
+            const bool changed = hx >= 0 && (ds != 0 || n_oth > 0 || bumped);
             if (changed) {
-                const int c2 = cntL[hx] + ds, t2 = totL[hx] + ds - w * n_oth;
-                cntL[hx] = c2; totL[hx] = t2;
-                gB[hx] = (flL[hx] & 1) ? sortable_bits(tree_score(c2, 0, t2, (flL[hx] >> 1) & 1, wL[hx], NP, 0.0,
-                                                                  q.booster_kind, lpT, ffT)) : ~0ull;
+                cntL[hx] += ds;
+                totL[hx] += ds - w * n_oth;
+                if (bumped) ntL[hx] += 1;
+                gB[hx] = leaf_key(hx);
             }
             if (NP > 0 && lane < n_out) {
                 int cn = INT_MAX;
@@ -486,6 +646,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                 if (cn < N) atomicAdd(q.ntn + (size_t)rowf * N + cn, 1);         // plan.go:238-245
             }
             BLANCE_WAVE_SYNC();
+            PH(9);
             // the tree: a smaller leaf replaces its group's minimum in place, a grown minimum needs a scan
             const u64 chm = __ballot(changed);
             for (u64 mm = chm; mm; mm &= mm - 1) {
@@ -499,32 +660,47 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                 if (key_less(nb, x, ob, on)) {
                     if (lane == gl) { gm_hi = (unsigned)(nb >> 32); gm_lo = (unsigned)nb; gm_n = x; }
                 } else if (on == x && nb != ob) {
+                    PC(pc_scans);
                     unsigned rh, rl; int rn;
                     scan_group(gl, rh, rl, rn);
                     if (lane == gl) { gm_hi = rh; gm_lo = rl; gm_n = rn; }
                 }
                 // later lanes of the batch that hold x were validated against its old counters
 #pragma unroll
-                for (int j = 0; j < KM; j++) if (lane > f && j < k && ownv[j] == x) sfail = true;
+                for (int j = 0; j < KM; j++) if (lane > f && j < k && ownv[j] == x) { sfail = true; stale = true; }
             }
             if (chm) root_valid = false;
 
             if (lane == 0) {
-                const int is_nil = (n_out == 0 && q.n_alive == 0 && !any_higher_key && !q.hier);
+                int is_nil = 0;
+                if (n_out == 0 && q.n_alive == 0 && !q.hier) {                   // plan.go:142: a nil slice stays nil
+                    bool any_higher_key = false;
+                    for (int t = 0; t < M; t++)
+                        if (((q.higher_mask >> t) & 1) && (rf[kRecHead + t * SW] >> 16) != kListAbsent) any_higher_key = true;
+                    is_nil = !any_higher_key;
+                }
                 int* o = q.out + (size_t)(oi + f) * q.OW;
                 o[0] = n_out | (is_nil << 16);
 #pragma unroll
                 for (int j = 0; j < KM; j++) if (j < k) o[1 + j] = j < n_out ? bN[j] : -1;
                 if (n_out < k) {                     // plan.go:230-235
                     const int wi = *q.warn_count;
-                    q.warn_part[wi] = p;
+                    q.warn_part[wi] = rf[0];
                     q.warn_state[wi] = s;
                     *q.warn_count = wi + 1;
                 }
             }
             cur = f + 1;
+            PH(10);
         }
     }
+#ifdef BLANCE_PHASE_PROF
+    if (lane == 0) {
+        printf("[tree] k %d steps %d batches %lld general %lld (short %lld: stays %lld reorders %lld one-kept %lld) walked %lld prefetch-miss %lld commit-scans %lld\n",
+               k, q.end - q.beg, pc_batches, pc_general, pc_short, pc_stay, pc_reorder, pc_half, pc_taken, pc_miss, pc_scans);
+        for (int i_ = 0; i_ < 12; i_++) printf("[tree phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
+    }
+#endif
     if (lane == 0 && q.spec_count) *q.spec_count += n_bulk;
     BLANCE_WAVE_SYNC();
     for (int i = 0; i < G; i++) {
@@ -536,7 +712,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
 // dynamic LDS of k_pass_tree for a pass
 static inline size_t tree_lds_bytes(int NX, int RW) {
     const size_t NXp = (size_t)((NX + 63) / 64) * 64;
-    return NXp * (8 + 4 + 4 + 4 + 1) + sizeof(int32_t) * (size_t)(64 * RW + 64 * 64) +
+    return NXp * (8 + 4 + 4 + 4 + 4 + 1) + sizeof(int32_t) * (size_t)(64 * RW) +
            sizeof(double) * (kLpTab + kFfTab) + (size_t)kWalkCap * 12 + 64;
 }
 

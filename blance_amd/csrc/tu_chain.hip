@@ -1,0 +1,57 @@
+// Translation unit of k_pass_chain / k_pass_chain_blank: region chains and their launch wrappers.
+#include "dev_prelude.h"
+#include "k_pass_chain.h"
+
+namespace blance {
+
+template <int NPTC, int KM, bool FAST>
+static void launch_chain_v(hipStream_t stream, const ChainParams& q, size_t lds) {
+    auto kern = k_pass_chain<NPTC, KM, FAST>;
+    BLANCE_LAUNCH(kern, q.n_regions, 64, lds, stream, q);
+}
+
+template <int NPTC, int KM>
+static void launch_chain_mode(hipStream_t stream, const ChainParams& q, size_t lds, bool fast) {
+    if (fast) launch_chain_v<NPTC, KM, true>(stream, q, lds);
+    else launch_chain_v<NPTC, KM, false>(stream, q, lds);
+}
+
+// one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
+bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast) {
+    int nptc = (max_size + 63) / 64;
+    size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
+    size_t lds = sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
+                 sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * ((size_t)max_size + 1) + 64;
+    // the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU);
+    // flat mode may insist on global rows
+    if (!q.flat || q.ntn_in_lds) q.ntn_in_lds = ntn_bytes <= 100 * 1024 && lds + ntn_bytes <= 156 * 1024;
+    if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
+    if (q.k <= 2) {
+        if (nptc <= 2) launch_chain_mode<2, 2>(stream, q, lds, fast);
+        else if (nptc <= 4) launch_chain_mode<4, 2>(stream, q, lds, fast);
+        else if (nptc <= 8) launch_chain_mode<8, 2>(stream, q, lds, fast);
+        else return false;
+    } else if (q.k <= 4) {
+        if (nptc <= 2) launch_chain_mode<2, 4>(stream, q, lds, fast);
+        else if (nptc <= 4) launch_chain_mode<4, 4>(stream, q, lds, fast);
+        else if (nptc <= 8) launch_chain_mode<8, 4>(stream, q, lds, fast);
+        else return false;
+    } else {
+        return false;
+    }
+    return true;
+}
+
+void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size) {
+    const int nptc = (max_size + 63) / 64, B = q.n_regions;
+    const size_t lds = sizeof(int32_t) * ((size_t)max_size + kChainStage * (size_t)(kCW + q.OW)) + 64;
+    if (q.k <= 2) {
+        if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 2>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); }
+        else { auto kern = k_pass_chain_blank<4, 2>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); }
+    } else {
+        if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 4>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); }
+        else { auto kern = k_pass_chain_blank<4, 4>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); }
+    }
+}
+
+}  // namespace blance

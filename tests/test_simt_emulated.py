@@ -17,7 +17,8 @@ EMU_SRC = os.path.join(HERE, "simt", "emu_lib.cpp")
 EMU_SO = os.path.join(HERE, "simt", "_build", "libblance_emu.so")
 DEPS = [EMU_SRC, os.path.join(HERE, "simt", "hip_emu.h"), os.path.join(HERE, "..", "include", "blance_hip.h")] + [
     os.path.join(HERE, "..", "blance_amd", "csrc", f) for f in
-    ("blance_hip.hip", "blance_kernels.h", "dev_common.h", "k_pass_seq.h", "k_pass_tree.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h")]
+    ("blance_hip.hip", "tu_seq.hip", "tu_tree.hip", "tu_chain.hip", "dev_prelude.h", "blance_kernels.h", "dev_common.h",
+     "k_pass_seq.h", "k_pass_tree.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h")]
 
 
 def build_emu():
@@ -172,7 +173,7 @@ def test_sequential_pass_speculation(emu_lib):
     fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
     digests = []
     for spec in (True, False):
-        pl = hip.Planner(lib_path=emu_lib, seq_speculation=spec)
+        pl = hip.Planner(lib_path=emu_lib, seq_speculation=spec, tree="off")
         r1 = pl.plan(fp1)
         assert r1.digest() == _oracle(fp1).digest()
         plan1, _ = problem.decode_result(fp1, r1)

@@ -19,7 +19,7 @@ def _oracle(fp):
     return loader.plan(fp)
 
 
-@pytest.mark.parametrize("mode", ["on", "dense"])
+@pytest.mark.parametrize("mode", ["on", "dense", "long"])
 def test_golden_cases_tree(emu_lib, golden_cases, mode):
     for eager in (0, 1):                         # 1: the flat bulk driver hands sub-ranges to the tree kernel
         pl = hip.Planner(lib_path=emu_lib, tree=mode, chain_min_parts=eager)
@@ -49,7 +49,7 @@ def test_random_instances_tree(emu_lib):
 
 def test_random_instances_tree_dense_and_bulk(emu_lib):
     pd = hip.Planner(lib_path=emu_lib, tree="dense")
-    pb = hip.Planner(lib_path=emu_lib, tree="on", chain_min_parts=1)
+    pb = hip.Planner(lib_path=emu_lib, tree="long", chain_min_parts=1)
     for seed in range(500, 760):
         try:
             fp = build_from_case(random_case(seed))
@@ -62,8 +62,8 @@ def test_random_instances_tree_dense_and_bulk(emu_lib):
     pb.close()
 
 
-def _rebalance(pl, P, N, check_stays=False):
-    c = synth.rebalance_case(P=P, N=N, hierarchy=False)
+def _rebalance(pl, P, N, check_stays=False, **kw):
+    c = synth.rebalance_case(P=P, N=N, hierarchy=False, **kw)
     fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
     opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
                 node_weights=c["nodeWeights"], node_hierarchy=None, hierarchy_rules=None)
@@ -87,9 +87,21 @@ def test_rebalance_tree(emu_lib):
     _rebalance(pl, 300, 100)
     _rebalance(pl, 300, 300, check_stays=True)
     pl.close()
-    pl = hip.Planner(lib_path=emu_lib, tree="dense")
-    _rebalance(pl, 120, 70)
-    pl.close()
+    for mode in ("dense", "long", "dense-long"):
+        pl = hip.Planner(lib_path=emu_lib, tree=mode)
+        _rebalance(pl, 120, 70)
+        pl.close()
+
+
+def test_folded_row_tree(emu_lib):
+    """Half of the nodes removed: hundreds of consecutive steps have no top priority node and share the
+    row "" of nodeToNodeCounts -- k_pass_tree folds that row into its leaves for whole batches, and
+    unfolds when a mixed batch comes."""
+    for mode in ("on", "dense", "long"):
+        pl = hip.Planner(lib_path=emu_lib, tree=mode)
+        _rebalance(pl, 500, 40, remove_frac=0.5, add_frac=0.3)
+        _rebalance(pl, 260, 130, remove_frac=0.6, add_frac=0.1)
+        pl.close()
 
 
 def test_reduced_configs_tree(emu_lib):
@@ -102,7 +114,7 @@ def test_reduced_configs_tree(emu_lib):
 
 def test_edge_shapes_tree(emu_lib):
     cases = edge_cases()
-    for mode in ("on", "dense"):
+    for mode in ("on", "dense", "long"):
         pl = hip.Planner(lib_path=emu_lib, tree=mode)
         for i, (a, k) in enumerate(cases):
             fp = problem.build_problem(*a, **k)
