@@ -296,6 +296,26 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     oi[j] = li;
                     on[j] = nidL[li];
                     oc[j + 1] = clsL[li];
+                    // the partition's own nodes: candidates, scored exactly
+                    if (!(flgL[li] & 1)) fail = true;
+                    const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
+                    so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
+                                        q.booster_kind, lp_tab, ff_tab);
+                }
+            }
+            // A step that keeps its nodes emits them in (score, position) order -- slot j takes the best
+            // node left (plan.go:185-226) -- which need not be the list order; no counter changes
+            // either way.  Sort them (insertion sort, k <= 4) and check the slots in that order.
+#pragma unroll
+            for (int j = 1; j < KM; j++) {
+#pragma unroll
+                for (int e = j; e > 0; e--) {
+                    if (e < k && better(so[e], on[e], so[e - 1], on[e - 1])) {
+                        const double ts = so[e]; so[e] = so[e - 1]; so[e - 1] = ts;
+                        const int tn = on[e]; on[e] = on[e - 1]; on[e - 1] = tn;
+                        const int ti = oi[e]; oi[e] = oi[e - 1]; oi[e - 1] = ti;
+                        const int tc = oc[e + 1]; oc[e + 1] = oc[e]; oc[e] = tc;
+                    }
                 }
             }
             // anchors top, own_0 .. own_{k-2}: their exclude classes must leave candidates,
@@ -316,19 +336,10 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     }
                 }
             }
-            // the partition's own nodes: candidates, in list order, below the bound
+            // every one of them below the bound
 #pragma unroll
-            for (int j = 0; j < KM; j++) {
-                if (j < k) {
-                    const int li = oi[j];
-                    if (!(flgL[li] & 1)) fail = true;
-                    const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
-                    so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
-                                        q.booster_kind, lp_tab, ff_tab);
-                    if (j > 0 && !better(so[j - 1], on[j - 1], so[j], on[j])) fail = true;
-                    if (!better(so[j], on[j], gmin_s, gmin_n)) fail = true;
-                }
-            }
+            for (int j = 0; j < KM; j++)
+                if (j < k && !better(so[j], on[j], gmin_s, gmin_n)) fail = true;
             // an own node also listed in a higher priority state is no candidate (the
             // record keeps such leaves under "higher"; gather refuses nodes held twice)
             // an earlier step of the batch with the same top priority node would have bumped my row
