@@ -651,21 +651,40 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             continue;
         }
         if (first_nonfresh - pos >= kMinFreshRun && c->n_alive > 0) {
-            const int R = first_nonfresh - pos;
-            BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, R, c->f_m.as<int32_t>(),
+            int R = first_nonfresh - pos;
+            // NumPartitions == 0: steps may each exclude one node (k_fresh_excl); one more element of the
+            // exclusion-free sequence is needed then
+            const int RS = q.NP == 0 ? R + 1 : R;
+            BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, RS, c->f_m.as<int32_t>(),
                           c->f_moff.as<int32_t>());
-            BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(R, 256), 256, 0, sm, fq, pos, R, c->f_moff.as<int32_t>(),
+            BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
                                  c->f_keys_a.as<unsigned long long>(), c->f_vals_a.as<int32_t>());
-            int e = radix_sort_pairs(c, R, launches);
+            int e = radix_sort_pairs(c, RS, launches);
             if (e) return e;
-            BLANCE_LAUNCH_NOSYNC(k_fresh_commit_steps, cdiv(R, 256), 256, 0, sm, fq, pos, R, c->f_vals_a.as<int32_t>());
-            BLANCE_LAUNCH_NOSYNC(k_fresh_commit_nodes, cdiv(q.N, 256), 256, 0, sm, fq, pos, c->f_m.as<int32_t>(), q.cnt);
-            *launches += 4;
-            *batched += R;
-            pos += R;
-            dirty = true;
-            seq_batch = 256;
-            continue;
+            const int32_t* picks = c->f_vals_a.as<int32_t>();
+            if (q.NP == 0) {
+                int32_t bad = INT_MAX;
+                HIPTRY(hipMemcpyAsync(scal + 10, &bad, sizeof bad, hipMemcpyHostToDevice, sm));
+                BLANCE_LAUNCH(k_fresh_excl, 1, 1024, 2048 + 64, sm, fq, pos, R, c->f_vals_a.as<int32_t>(),
+                              c->f_vals_b.as<int32_t>(), scal + 10);
+                HIPTRY(hipMemcpyAsync(&bad, scal + 10, sizeof bad, hipMemcpyDeviceToHost, sm));
+                HIPTRY(hipStreamSynchronize(sm));
+                *launches += 1;
+                if (bad < R) R = bad;               // a pending node came up again: the run ends before that step
+                picks = c->f_vals_b.as<int32_t>();
+                HIPTRY(hipMemsetAsync(c->f_m.p, 0, sizeof(int32_t) * ((size_t)q.N + 1), sm));
+                if (R > 0) BLANCE_LAUNCH_NOSYNC(k_fresh_hist, cdiv(R, 256), 256, 0, sm, R, picks, c->f_m.as<int32_t>());
+            }
+            if (R > 0) {
+                BLANCE_LAUNCH_NOSYNC(k_fresh_commit_steps, cdiv(R, 256), 256, 0, sm, fq, pos, R, picks);
+                BLANCE_LAUNCH_NOSYNC(k_fresh_commit_nodes, cdiv(q.N, 256), 256, 0, sm, fq, pos, c->f_m.as<int32_t>(), q.cnt);
+                *launches += 4;
+                *batched += R;
+                pos += R;
+                dirty = true;
+                seq_batch = 256;
+                continue;
+            }
         }
         int B = P - pos < seq_batch ? P - pos : seq_batch;
         int e;

@@ -99,16 +99,22 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
     int top = ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) ? r[kRecHead + q.top_state * SW + 1] : -1;
     int hs = r[kRecHead + q.s * SW];
     int own_len = (hs >> 16) == kListAbsent ? 0 : (hs & 0xffff);
-    int all_len = 0;                                   // nodes the partition holds in any state
+    int all_len = 0, high_len = 0;                     // nodes the partition holds in any / in higher priority states
     for (int t = 0; t < q.M; t++) {
         int h = r[kRecHead + t * SW];
-        if ((h >> 16) != kListAbsent) all_len += h & 0xffff;
+        if ((h >> 16) == kListAbsent) continue;
+        all_len += h & 0xffff;
+        if ((q.higher_mask >> t) & 1) high_len += h & 0xffff;
     }
     // ---- fresh identical to step beg?
     {
         const int32_t* r0 = q.rec + (size_t)beg * q.RW;
-        // no node anywhere: nothing to exclude, demote or promote (plan.go:290-297)
-        bool fresh = q.k == 1 && all_len == 0 && w > 0 && w == r0[1] && top < 0;
+        // no node anywhere: nothing to exclude, demote or promote (plan.go:290-297).  With
+        // NumPartitions == 0 no score term depends on the partition (plan.go:638,:647), so one node
+        // in a higher priority state -- just not a candidate, plan.go:146-154 -- is allowed too
+        // (k_fresh_excl), and the top priority node does not matter.
+        bool fresh = q.k == 1 && w > 0 && w == r0[1] &&
+                     (q.NP == 0 ? (all_len == high_len && high_len <= 1) : (all_len == 0 && top < 0));
         scan_note_first(in_range && !fresh, oi, &q.scan[1]);
     }
     // ---- certain stay?
@@ -320,6 +326,78 @@ __global__ void k_fresh_commit_nodes(FlatParams q, int beg, const int32_t* m, in
     if (m[n] == 0) return;
     cnt[q.s * q.NX + n] += m[n] * w;                 // plan.go:299-301
     if (q.NP > 0) q.ntn[(size_t)q.NX * q.N + n] += m[n];
+}
+
+// ---- fresh run, NumPartitions == 0, every step with at most ONE node that is no candidate (its
+// higher priority node, plan.go:146-154).  S = the sequence of picks the run would make without
+// the exclusions (k_fresh_threshold / emit / sort, one element more than steps).  A step whose
+// turn falls on its own excluded node h takes the next element instead and leaves h at the head
+// of the queue: "pending".  A pending node is taken by the first later step that does not exclude
+// it too.  So the state between steps is one bit (is a node pending -- it can only be the previous
+// step's excluded node), the step function b' = b ? A_t : B_t with A_t = (e_t == e_{t-1}),
+// B_t = (S[t] == e_t) is known per step, and a scan over function composition resolves the run:
+//   pick_t = b_t ? (A_t ? S[t + 1] : e_{t-1}) : (B_t ? S[t + 1] : S[t]).
+// Exact as long as the pending node does not come up again in S while it waits (its next pick
+// would then be due before anybody may take it): the first step where it does is reported and
+// the run ends there.
+__device__ __forceinline__ int fresh_excluded(const FlatParams& q, int oi) {
+    const int32_t* r = q.rec + (size_t)oi * q.RW;
+    const int SW = 1 + q.L;
+    for (int t = 0; t < q.M; t++) {
+        if (!((q.higher_mask >> t) & 1)) continue;
+        const int h = r[kRecHead + t * SW];
+        if ((h >> 16) != kListAbsent && (h & 0xffff) > 0) return r[kRecHead + t * SW + 1];
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(1024) void k_fresh_excl(FlatParams q, int beg, int R, const int32_t* S /* [R + 1] */,
+                                                     int32_t* picks /* [R] */, int32_t* first_bad) {
+    BLANCE_DYN_LDS(lds);
+    unsigned char* comp = (unsigned char*)lds;       // [1024] composite step function of a thread's slice: bit x = f(x)
+    unsigned char* tmp = comp + 1024;
+    const int tid = threadIdx.x;
+    const int per = (R + 1023) / 1024;
+    const int t0 = tid * per < R ? tid * per : R, t1 = t0 + per < R ? t0 + per : R;
+    unsigned f = 2;                                  // identity: f(0) = 0, f(1) = 1
+    int eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
+    for (int t = t0; t < t1; t++) {
+        const int e = fresh_excluded(q, beg + t);
+        const unsigned A = (e >= 0 && e == eprev) ? 1u : 0u, B = (e >= 0 && S[t] == e) ? 1u : 0u;
+        const unsigned f0 = (f & 1) ? A : B, f1 = (f & 2) ? A : B;
+        f = f0 | (f1 << 1);
+        eprev = e;
+    }
+    comp[tid] = (unsigned char)f;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan under composition (earlier function first)
+        unsigned mine = comp[tid];
+        if (tid >= off) {
+            const unsigned early = comp[tid - off];
+            const unsigned g0 = (mine >> (early & 1)) & 1, g1 = (mine >> ((early >> 1) & 1)) & 1;
+            mine = g0 | (g1 << 1);
+        }
+        tmp[tid] = (unsigned char)mine;
+        __syncthreads();
+        comp[tid] = tmp[tid];
+        __syncthreads();
+    }
+    unsigned b = tid > 0 ? (comp[tid - 1] & 1u) : 0u;   // the run starts with nothing pending
+    eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
+    for (int t = t0; t < t1; t++) {
+        const int e = fresh_excluded(q, beg + t);
+        const unsigned A = (e >= 0 && e == eprev) ? 1u : 0u, B = (e >= 0 && S[t] == e) ? 1u : 0u;
+        const unsigned nb = b ? A : B;               // pending after this step: then it is e
+        picks[t] = b ? (A ? S[t + 1] : eprev) : (B ? S[t + 1] : S[t]);
+        if (nb && S[t + 1] == e) atomicMin(first_bad, t);
+        b = nb;
+        eprev = e;
+    }
+}
+
+__global__ void k_fresh_hist(int n, const int32_t* picks, int32_t* m) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) atomicAdd(&m[picks[j]], 1);
 }
 
 // ---- stable LSD radix sort of (64-bit key, 32-bit value) pairs, 8 bits per pass.

@@ -247,3 +247,32 @@ def test_several_nodes_per_thread(emu_lib):
     for fp in (synth.config_flat(3, P=96, N=200), synth.config_flat(2, P=150, N=100)):
         assert pl.plan(fp).digest() == _oracle(fp).digest()
     pl.close()
+
+
+def test_fresh_runs_with_excluded_node(emu_lib):
+    """k_fresh_excl: a fresh plan's replica pass (NumPartitions == 0) where every partition only excludes
+    its primary -- skewed primaries give long waits of the excluded node at the head of the queue, few
+    nodes make it come up again while it waits (the run is cut there), node weights bend the sequence."""
+    import random
+    model = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": 1}}
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=1)
+    bulk = 0
+    for seed in range(40):
+        rnd = random.Random(seed)
+        n = rnd.choice([2, 3, 5, 9, 40, 70])
+        nodes = ["n%02d" % i for i in range(n)]
+        hot = nodes[: rnd.choice([1, 2, n])]
+        parts = {}
+        for i in range(rnd.choice([30, 200, 700])):
+            prim = rnd.choice(hot) if rnd.random() < 0.8 else rnd.choice(nodes)
+            nbs = {"primary": [prim]} if rnd.random() < 0.95 else {}
+            parts[str(i)] = {"name": str(i), "nodesByState": nbs}
+        kw = {}
+        if seed % 3 == 0:
+            kw["node_weights"] = {x: rnd.choice([1, 2, 3]) for x in nodes}
+        fp = problem.build_problem({}, parts, nodes, [], nodes, model, max_iterations=rnd.choice([1, 10]), **kw)
+        got, want = pl.plan(fp), _oracle(fp)
+        assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
+        bulk += got.struct.steps_batched > 0
+    assert bulk > 20
+    pl.close()

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Summaries of rocprofv3 runs (rocpd SQLite databases) for profiles/:
+    profile_summary.py trace <results.db> <calls> <out.txt> <title>
+    profile_summary.py pmc   <out.txt> <out.json|-> <title> <db> [<db> ...]
+`pmc` sums every counter found in the given databases per kernel (one row per kernel, one column per
+counter) -- counters collected in separate passes simply come from separate databases."""
+import hashlib
+import json
+import os
+import re
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["blance_amd/csrc/k_pass_chain.h", "blance_amd/csrc/k_pass_tree.h", "blance_amd/csrc/k_pass_seq.h",
+                  "blance_amd/csrc/k_flat.h", "blance_amd/csrc/k_sweep.h", "blance_amd/csrc/dev_common.h",
+                  "blance_amd/csrc/blance_hip.hip"]
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def tables(cur):
+    t = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    return lambda k: [x for x in t if k in x][0]
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = re.sub(r"^_ZN6blance\d+", "", name)
+    return name[:60]
+
+
+def trace(db, calls, out, title):
+    cur = sqlite3.connect(db).cursor()
+    g = tables(cur)
+    rows = cur.execute(
+        "select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+        "from %s d join %s s on d.kernel_id=s.id group by s.kernel_name order by 3 desc" % (g("kernel_dispatch"), g("kernel_symbol"))).fetchall()
+    tot = sum(r[2] for r in rows)
+    lines = [title, "kernel sources sha256[:16] %s" % source_hash(),
+             "total kernel time %.3f ms (%.3f ms per PlanNextMap call over %d calls)" % (tot / 1e6, tot / 1e6 / calls, calls),
+             "%-62s %6s %12s %12s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "share")]
+    for r in rows:
+        lines.append("%-62s %6d %12.3f %12.1f %12.1f %12.1f %6.1f%%" % (short(r[0]), r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:12]))
+
+
+def pmc(out, out_json, title, dbs):
+    per = {}            # kernel -> {counter: sum, "calls": n}
+    counters = []
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        g = tables(cur)
+        rows = cur.execute(
+            "select s.kernel_name, i.name, count(distinct d.id), sum(e.value) from %s e join %s i on e.pmc_id=i.id join %s d on "
+            "e.event_id=d.event_id join %s s on d.kernel_id=s.id group by s.kernel_name, i.name"
+            % (g("pmc_event"), g("info_pmc"), g("kernel_dispatch"), g("kernel_symbol"))).fetchall()
+        for k, c, n, v in rows:
+            per.setdefault(k, {"calls": n})[c] = v
+            per[k]["calls"] = max(per[k]["calls"], n)
+            if c not in counters:
+                counters.append(c)
+    order = sorted(per, key=lambda k: -max(per[k].get(c, 0) for c in counters))
+    lines = [title, "kernel sources sha256[:16] %s" % source_hash(),
+             "%-62s %6s " % ("kernel", "calls") + " ".join("%18s" % c for c in counters)]
+    for k in order:
+        lines.append("%-62s %6d " % (short(k), per[k]["calls"]) + " ".join("%18.0f" % per[k].get(c, 0) for c in counters))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:10]))
+    if out_json != "-":
+        json.dump({"source_hash": source_hash(), "title": title,
+                   "git_head": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
+                   "kernels": {short(k): per[k] for k in order}}, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])
