@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the PlanNextMap hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|5]
 
-One "step" = one whole PlanNextMap call (every sweep of planNextMapEx,
-plan.go:23-58) on BASELINE.json's config 3: 1,048,576 partitions x 4,096 nodes,
-primary + 2 replicas, 3-level rack/zone/DC hierarchy with an exclusion rule.
-The problem is uploaded once (inputs resident in HBM when the timed region
-starts); value = partition-state assignments per second over the timed steps.
+One "step" = one whole PlanNextMap call (every sweep of planNextMapEx, plan.go:23-58) on
+BASELINE.json's config 3: 1,048,576 partitions x 4,096 nodes, primary + 2 replicas, 3-level
+rack/zone/DC hierarchy with an exclusion rule.  The problem is uploaded once (inputs resident in
+HBM when the timed region starts); value = partition-state assignments per second over the timed
+steps.
 
-Multi-GPU (N > 1): replicas only -- every rank plans its own instance of the
-same shape (see DESIGN.md "Multi-GPU"); value = all ranks' assignments / max
-time over ranks.
+N > 1 (one process per GPU; `--gpus N` launches the ranks itself through torch.distributed.run
+when it is not already running under it):
+  * value: every rank plans an instance of the same shape (replicas, weak scaling) -- all ranks'
+    assignments / the slowest rank's time;
+  * "sharded": ONE plan with its region chains sharded over the ranks and RCCL all-reduces of the
+    pass outputs and the load-vector change after every chain pass (BASELINE.json config 4),
+    timed the same way and reported beside it, whatever it is (DESIGN.md "Multi-GPU").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,15 +29,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SCLK_GHZ = 2.4            # MI355X_MICROARCH.md: 256 CU x 2.4 GHz
+N_CUS, SIMDS_PER_CU = 256, 4
+K_CW = 24                 # words of a compact chain step record (blance_kernels.h kCW)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(parts, nodes, cfg):
-    """The CPU oracle (a port of the reference's algorithm, 1 core -- the Go
-    planner is single threaded) on a bounded sample: the SAME node count,
-    hierarchy and model, 1/4 of the partitions, run to convergence.  Per-step
-    cost is O(nodes), so assignments/s carries over to the full size."""
+    """CPU legs, one core each (the Go planner is single threaded), on a bounded sample of the same
+    workload: (i) "port": oracle/blance_oracle.c, the id-based restatement; (ii) "naive": the
+    string-keyed proxy of the reference's Go code path (hash maps + comparison sort calling Score
+    twice per compare, plan.go:617-689), on a smaller sample, extrapolated linearly in partitions."""
     from blance_amd import synth
     from oracle import loader
+    info = {"unit": "assignments/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
     if cfg == 5:
         # config 5 (weighted rebalance, 10 sweeps): 1/32 of the partitions; the plan it starts
         # from is made on the GPU (untimed), the oracle is timed on the rebalance only
@@ -42,35 +62,81 @@ def cpu_baseline(parts, nodes, cfg):
         pl = hip.Planner()
         fp = synth.config5_rebalance(fp1, pl.plan(fp1), sample_parts, nodes)
         pl.close()
-        t0 = time.perf_counter()
-        res = loader.plan(fp)
-        dt = time.perf_counter() - t0
-        return {"value": synth.assignments(fp) / dt, "unit": "assignments/s", "cores": 1, "kind": "port",
-                "sample": "oracle/blance_oracle.c, the rebalance PlanNextMap (%d sweeps) on %d partitions x %d nodes "
-                          "(1/32 of the partitions, same generator), %.1f s" % (res.iterations, sample_parts, nodes, dt),
-                "host_cpus": os.cpu_count()}
-    sample_parts = max(1024, parts // 4)
-    fp = synth.config_flat(cfg, P=sample_parts, N=nodes)
+        what = "the rebalance PlanNextMap"
+        frac = "1/32"
+    else:
+        sample_parts = max(1024, parts // 4)
+        fp = synth.config_flat(cfg, P=sample_parts, N=nodes)
+        what = "full PlanNextMap"
+        frac = "1/4"
     t0 = time.perf_counter()
     res = loader.plan(fp)
     dt = time.perf_counter() - t0
-    return {"value": synth.assignments(fp) / dt, "unit": "assignments/s", "cores": 1, "kind": "port",
-            "sample": "oracle/blance_oracle.c, full PlanNextMap (%d sweeps) on %d partitions x %d nodes "
-                      "(1/4 of the partitions, same nodes/hierarchy/model), %.1f s"
-                      % (res.iterations, sample_parts, nodes, dt),
-            "host_cpus": os.cpu_count()}
+    info["value"] = synth.assignments(fp) / dt
+    info["sample"] = ("oracle/blance_oracle.c, %s (%d sweeps) on %d partitions x %d nodes (%s of the partitions, same "
+                      "nodes/hierarchy/model; per-step cost is O(nodes), so assignments/s carries over), %.1f s"
+                      % (what, res.iterations, sample_parts, nodes, frac, dt))
+    try:
+        from oracle import naive_loader
+        info["naive_proxy"] = naive_loader.timed_sample(cfg, nodes)
+    except Exception as e:                                  # the proxy is optional test infrastructure
+        info["naive_proxy"] = {"error": str(e)[:200]}
+    return info
+
+
+def profile_json(name):
+    """A PMC summary committed under profiles/ -- only if it was taken from the kernel sources as they are now."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, "no %s" % name
+    with open(path) as f:
+        data = json.load(f)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import profile_summary
+        now = profile_summary.source_hash()
+    except Exception:
+        now = None
+    if now != data.get("source_hash"):
+        return None, "%s was taken from other kernel sources (%s, now %s)" % (name, data.get("source_hash"), now)
+    return data, "profiles/%s (git %s, kernel sources %s)" % (name, data.get("git_head"), data.get("source_hash"))
+
+
+def kernel_counters(data, prefix):
+    """Sum the counters of every kernel whose short name starts with one of `prefix`."""
+    tot, calls = {}, 0
+    for name, row in (data or {}).get("kernels", {}).items():
+        if not any(name.startswith(p) for p in prefix):
+            continue
+        calls += row.get("calls", 0)
+        for k, v in row.items():
+            if k != "calls":
+                tot[k] = tot.get(k, 0) + v
+    return tot, calls
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks."""
+    port = 29400 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config: 3 (headline), 2, or 5 (weighted rebalance; ~40 s per step)")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config: 3 (headline), 2, or 5 (weighted rebalance)")
     ap.add_argument("--parts", type=int, default=0, help="override partition count (not the headline)")
     ap.add_argument("--nodes", type=int, default=0, help="override node count (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,6 +147,7 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()               # what RCCL's communicator reports
 
     from blance_amd import dist_util, hip, synth
     pl = hip.Planner(device_id=local_rank)          # raises without the HIP library / a device
@@ -95,72 +162,118 @@ def main():
     pl.upload(fp)
     upload_s = time.perf_counter() - t0
 
-    for _ in range(args.warmup):
-        pl.plan_resident()
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    pass_ms = flat_ms = device_ms = 0.0
-    pass_launches = flat_passes = 0
-    iterations = 0
-    for _ in range(args.steps):
-        r = pl.plan_resident()                      # returns after the device finished the call
-        pass_ms += r.pass_kernel_ms
-        pass_launches += r.pass_kernel_launches
-        flat_ms += r.flat_pass_ms
-        flat_passes += r.flat_passes
-        device_ms += r.device_ms
-        iterations = r.iterations
-        batched, sequential = r.steps_batched, r.steps_sequential
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        dt = dist_util.max_over_ranks(dt)
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            pl.plan_resident()
+        barrier()
+        t0 = time.perf_counter()
+        acc = {"pass_ms": 0.0, "pass_launches": 0, "flat_ms": 0.0, "flat_passes": 0, "device_ms": 0.0}
+        r = None
+        for _ in range(steps):
+            r = pl.plan_resident()                  # returns after the device finished the call
+            acc["pass_ms"] += r.pass_kernel_ms
+            acc["pass_launches"] += r.pass_kernel_launches
+            acc["flat_ms"] += r.flat_pass_ms
+            acc["flat_passes"] += r.flat_passes
+            acc["device_ms"] += r.device_ms
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = dist_util.max_over_ranks(dt)
+        return dt, acc, r
 
+    dt, acc, r = timed(args.steps, args.warmup)
+    iterations, batched, sequential = r.iterations, r.steps_batched, r.steps_sequential
     assignments = synth.assignments(fp)
     value = assignments * args.steps * world / dt
 
-    out = None
+    sharded = None
+    if dist is not None:                            # one plan over all ranks (config 4)
+        replica_digest = pl.download().digest()
+        dist_util.shard_plan_rccl(pl, dist)
+        sdt, sacc, sr = timed(args.steps, args.warmup)
+        sdig = pl.download().digest()
+        box = [None] * world
+        dist.all_gather_object(box, sdig)
+        sharded = {"what": "one PlanNextMap with its region chains sharded over the ranks; RCCL int32 sum all-reduce of "
+                           "the pass outputs, the load-vector change and the chain flags after every chain pass",
+                   "rccl_world_size": world, "ms_per_step": sdt * 1e3 / args.steps,
+                   "value": assignments * args.steps / sdt, "unit": "assignments/s", "scaling": "strong",
+                   "device_ms_per_step": sacc["device_ms"] / args.steps,
+                   "same_digest_on_every_rank": len(set(box)) == 1,
+                   "same_digest_as_single_rank_plan": sdig == replica_digest,
+                   "speedup_vs_one_rank_of_this_run": (dt / args.steps) / (sdt / args.steps)}
+
     if rank == 0:
         t1 = time.perf_counter()
         res = pl.download()
         download_s = time.perf_counter() - t1
         digest = res.digest()
-        # Dominant kernel: the state-pass kernel (k_pass_chain on config 3), one launch per
-        # hierarchy-rule state pass, timed by hipEvents on the planner's stream.  Algorithmic
-        # bytes per launch: SURVEY.md 8(d), P * (N * (16 + 4 k [rules]) + 40) for that state.
-        per_state = synth.algorithmic_bytes_per_state(fp)
+        M = fp.n_states
+        k_by_state = [int(fp.state_constraints[m]) for m in range(M)]
+        RW = 4 + M * (1 + max(k_by_state + [1]))
         kernel_states = synth.pass_kernel_states(fp)
-        alg_per_launch = (sum(per_state[m] for m in kernel_states) / max(len(kernel_states), 1))
-        kernel_label = "k_pass_chain / k_pass_chain_blank (state-pass kernel, one launch per replica pass)"
-        dom_ms, dom_launches = pass_ms, pass_launches
-        if args.config == 5:
-            kernel_label = "k_pass_seq (workgroup pass, one launch per replica pass)"
-        if not pass_launches and flat_passes:        # every pass went through the flat driver (config 2)
-            kernel_label = "flat driver passes (k_flat_*, k_fresh_*, k_sort_*, flat chain; several launches per pass)"
-            flat_states = [m for m in range(len(per_state)) if per_state[m] and m not in kernel_states]
-            alg_per_launch = sum(per_state[m] for m in flat_states) / max(len(flat_states), 1)
-            dom_ms, dom_launches = flat_ms, flat_passes
+        # ---- dominant kernel and the bytes its schedule has to move per launch (DESIGN.md "Measurement"):
+        # every step reads its record and writes its choice; nothing else leaves registers / LDS
+        if acc["pass_launches"]:
+            dom_ms, dom_launches = acc["pass_ms"], acc["pass_launches"]
+            if args.config == 5:
+                kernel_label = "k_pass_tree (flat replica pass, one wave64, one launch per pass)"
+                words = RW + 1 + max(k_by_state)
+                prof_prefix = ("k_pass_tree",)
+                chains = 1
+            else:
+                kernel_label = "k_pass_chain_blank / k_pass_chain (one wave64 per hierarchy region, one launch per replica pass)"
+                words = K_CW + 1 + max(k_by_state)
+                prof_prefix = ("k_pass_chain",)
+                chains = -(-N // 128)                # zones of 8 racks x 16 nodes
+        else:
+            dom_ms, dom_launches = acc["flat_ms"], acc["flat_passes"]
+            kernel_label = "flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)"
+            words = RW + 2
+            prof_prefix = ("k_flat", "k_fresh", "k_sort")
+            chains = None
+        bytes_per_launch = 4.0 * words * P
         avg_launch_ms = dom_ms / max(dom_launches, 1)
-        achieved = alg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if dom_launches else 0.0
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if dom_launches else 0.0
+        # measured HBM traffic of that kernel, from the committed PMC passes of the same sources
+        hbm, hbm_src = profile_json("r2_pmc_hbm_config%d.json" % args.config)
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(prof) and args.config == 3 and not args.parts and not args.nodes:
-            with open(prof) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        whole = synth.algorithmic_bytes_per_sweep(fp) * iterations * args.steps / (device_ms * 1e-3) / 1e9
-        # what actually bounds the kernel: the dependent chain of one region
+        headline_shape = not args.parts and not args.nodes
+        if hbm and headline_shape:
+            tot, calls = kernel_counters(hbm, prof_prefix)
+            if calls:
+                # gfx950: FETCH_SIZE (KB) counts half of a streaming read's bytes (MI355X_MICROARCH.md, HBM)
+                traffic = (2.0 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024 / calls
+        # what actually bounds the kernel: one dependent chain per wave
         critical = None
-        if args.config == 3 and dom_launches:
-            regions = -(-N // 128)                                # zones of 8 racks x 16 nodes
-            chain_steps = -(-P // regions)
-            critical = {"regions": regions, "dependent_steps_per_launch": chain_steps,
-                        "avg_ns_per_dependent_step": avg_launch_ms * 1e6 / chain_steps}
+        sq, sq_src = profile_json("r2_pmc_sq_config%d.json" % args.config)
+        if chains and dom_launches:
+            chain_steps = -(-P // chains)
+            ns = avg_launch_ms * 1e6 / chain_steps
+            critical = {"chains_per_launch": chains, "dependent_steps_per_chain": chain_steps,
+                        "avg_ns_per_dependent_step": ns, "avg_cycles_per_dependent_step": ns * SCLK_GHZ}
+            if sq and headline_shape:
+                tot, calls = kernel_counters(sq, prof_prefix)
+                if calls and tot.get("SQ_WAVES"):
+                    instr = tot.get("SQ_INSTS_VALU", 0) + tot.get("SQ_INSTS_SALU", 0) + tot.get("SQ_INSTS_LDS", 0) + \
+                        tot.get("SQ_INSTS_SMEM", 0) + tot.get("SQ_INSTS_VMEM_RD", 0) + tot.get("SQ_INSTS_VMEM_WR", 0)
+                    per_step = instr / tot["SQ_WAVES"] / chain_steps
+                    critical.update({
+                        "instructions_per_step_per_wave": per_step,
+                        "cycles_per_instruction": ns * SCLK_GHZ / per_step if per_step else None,
+                        # a lone wave64 issues at most one VALU instruction per 4 cycles (16 lanes x 4)
+                        "issue_bound_ns_per_step": per_step * 4 / SCLK_GHZ,
+                        "issue_bound_frac": (per_step * 4 / SCLK_GHZ) / ns if ns else None,
+                        "wave_active_frac": tot.get("SQ_ACTIVE_INST_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
+                        "wave_waiting_frac": tot.get("SQ_WAIT_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
+                        "counters_from": sq_src})
+        dense = synth.algorithmic_bytes_per_sweep(fp) * iterations * args.steps / (acc["device_ms"] * 1e-3) / 1e9
         out = {
             "metric": "partition-state assignments/sec at 1M partitions x 4,096 nodes",
             "value": value, "unit": "assignments/s", "n_gpus": world, "steps": args.steps,
@@ -175,34 +288,58 @@ def main():
                        "partitions": P, "nodes": N, "assignments_per_call": assignments,
                        "sweeps_per_call": iterations, "parallelism": "replicas x%d" % world,
                        "steps_bulk": int(batched), "steps_one_by_one": int(sequential),
-                       "headline": bool(args.config == 3 and not args.parts and not args.nodes)},
+                       "headline": bool(args.config == 3 and headline_shape)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_label, "launches": dom_launches,
-                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": alg_per_launch,
-                         "whole_call_algorithmic_GBps": whole, "critical_path": critical,
-                         "note": "algorithmic bytes are what the reference's dense per-step scan reads "
-                                 "(SURVEY.md 8d); the kernel keeps tables in registers/LDS and resolves "
-                                 "verified stays in bulk, so measured HBM traffic is far below them"},
-            "device_ms_per_step": device_ms / args.steps,
-            "pass_kernel_ms_per_step": pass_ms / args.steps, "flat_pass_ms_per_step": flat_ms / args.steps,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": hbm_src,
+                         "kernel": kernel_label, "launches": dom_launches, "avg_launch_ms": avg_launch_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_model": "%d partitions x %d words x 4 B: every step reads its record and writes its "
+                                                    "choice; load tables stay in registers / LDS (DESIGN.md 5)" % (P, words),
+                         "occupancy": ({"waves": chains, "cus": N_CUS, "simd_slots": N_CUS * SIMDS_PER_CU,
+                                        "simd_slots_used_frac": chains / float(N_CUS * SIMDS_PER_CU)} if chains else None),
+                         "critical_path": critical,
+                         "reference_dense_scan_equivalent_GBps": dense,
+                         "note": "the kernel is bound by the latency of one dependent chain per wave, not by HBM: frac is the "
+                                 "honest HBM fraction of the bytes the implemented schedule moves; "
+                                 "reference_dense_scan_equivalent_GBps prices the SAME wall time at the bytes the reference's "
+                                 "dense per-step scan would read (SURVEY.md 8d) -- not executed work, may exceed the HBM peak"},
+            "device_ms_per_step": acc["device_ms"] / args.steps,
+            "pass_kernel_ms_per_step": acc["pass_ms"] / args.steps, "flat_pass_ms_per_step": acc["flat_ms"] / args.steps,
             "transfers": {"upload_s": upload_s, "download_s": download_s,
                           "value_incl_transfers": assignments / (dt / args.steps + upload_s + download_s)},
             "result_sha256": digest,
         }
+        if sharded:
+            out["sharded"] = sharded
         ref = os.path.join(ROOT, "tests", "golden", "config_digests.json")
-        if os.path.exists(ref) and not args.parts and not args.nodes:
+        if os.path.exists(ref) and headline_shape:
             with open(ref) as f:
                 want = json.load(f).get("config%d" % args.config)
             if want:
                 out["matches_oracle_digest"] = (want["rebalance"] if args.config == 5 else want)["digest"] == digest
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config)
+            out["host_end_to_end"] = host_end_to_end(args.config)
         print(json.dumps(out), flush=True)
     pl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_end_to_end(cfg):
+    """What a caller of the API sees: the C++ mirror of PlanNextMapEx from string maps to string maps
+    (interning + blance_plan + un-interning), timed by its driver (blance_host_cli --bench)."""
+    cli = os.path.join(ROOT, "blance_amd", "lib", "blance_host_cli")
+    if cfg != 3 or not os.path.exists(cli):
+        return None
+    try:
+        p = subprocess.run([cli, os.path.join(ROOT, "blance_amd", "lib", "libblance_hip.so"), "bench", "3"],
+                           capture_output=True, text=True, timeout=600)
+        line = [x for x in p.stdout.splitlines() if x.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (p.stdout + p.stderr)[-300:]}
+    except Exception as e:
+        return {"error": str(e)[:200]}
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -208,6 +208,14 @@ class FlatResult:
         h.update(self.warn_part[:n].tobytes())
         h.update(self.warn_state[:n].tobytes())
         return h.hexdigest()
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class Comm(C.Structure):
+    """blance_comm: a caller-provided int32 sum all-reduce for a plan sharded over ranks."""
+    _fields_ = [("rank", C.c_int32), ("n_ranks", C.c_int32), ("allreduce_sum_i32", ALLREDUCE_FN), ("user", C.c_void_p)]
 
 
 class PlanStats(C.Structure):

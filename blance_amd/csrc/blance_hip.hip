@@ -67,6 +67,11 @@ struct blance_ctx {
     std::mutex mu;
     bool uploaded = false;
     bool planned = false;
+    // one plan on several ranks (include/blance_hip.h "one plan on several GPUs")
+    blance_comm comm{0, 1, nullptr, nullptr};
+    void* rccl_comm = nullptr;      // ncclComm_t of blance_comm_init_rccl
+    DevBuf cnt_base, cnt_delta;
+    int64_t comm_calls = 0, comm_bytes = 0;
 
     // host copy of the small parts of the problem
     blance_problem h{};
@@ -125,6 +130,7 @@ struct blance_ctx {
         for (DevBuf* b : all) b->release();
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
         rule_regions.clear();
+        cnt_base.release(); cnt_delta.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &n_ev, &chain_oi,
                           &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
                           &fl_one, &fl_reglo, &fl_reghi, &f_tot, &f_g,
@@ -134,6 +140,7 @@ struct blance_ctx {
     }
 };
 
+static void comm_release(blance_ctx* c);
 extern "C" int blance_abi_version(void) { return BLANCE_ABI_VERSION; }
 extern "C" const char* blance_last_error(void) { return g_last_error.c_str(); }
 
@@ -259,6 +266,7 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     c->free_all();
     for (hipEvent_t e : c->pass_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -570,7 +578,7 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
     memset(&cq, 0, sizeof cq);
     cq.N = q.N; cq.NX = q.NX; cq.M = q.M; cq.L = q.L; cq.s = q.s; cq.k = q.k; cq.NP = q.NP; cq.OW = q.OW;
     cq.booster_kind = q.booster_kind;
-    cq.n_regions = 1; cq.flat = 1;
+    cq.n_regions = 1; cq.n_launch = 1; cq.flat = 1;
     cq.reg_lo = c->fl_reglo.as<int32_t>(); cq.reg_hi = c->fl_reghi.as<int32_t>();
     cq.reg_off = c->reg_off.as<int32_t>();
     cq.leaf_node = c->fl_iota.as<int32_t>(); cq.leaf_cls = c->fl_iota.as<int32_t>(); cq.cls_size = c->fl_one.as<int32_t>();
@@ -728,6 +736,116 @@ static int dump_pass(blance_ctx* c, int sweep, int state, int P, int OW, const i
     return 0;
 }
 
+// ---- collectives of a sharded plan ---------------------------------------------------------
+#ifndef BLANCE_SIMT_EMU
+#include <dlfcn.h>
+struct Id128 { char b[128]; };                  // ncclUniqueId, passed by value
+namespace {
+// RCCL is bound at run time (dlopen): a single-GPU caller never loads it
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+}
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+static int rccl_load() {
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(BLANCE_ERR_COMM, "librccl.so not found: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(BLANCE_ERR_COMM, "librccl.so lacks an entry point");
+    g_rccl.lib = lib;
+    return 0;
+}
+#endif
+
+extern "C" int blance_comm_unique_id(void* id_out_128) {
+#ifndef BLANCE_SIMT_EMU
+    if (!id_out_128) return fail(BLANCE_ERR_BAD_ARG, "null id buffer");
+    int st = rccl_load();
+    if (st) return st;
+    int e = g_rccl.GetUniqueId(id_out_128);
+    if (e) return fail(BLANCE_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return BLANCE_OK;
+#else
+    (void)id_out_128;
+    return fail(BLANCE_ERR_COMM, "no RCCL in the emulator build");
+#endif
+}
+
+extern "C" int blance_comm_init_rccl(blance_ctx* c, int32_t n_ranks, int32_t rank, const void* id_128) {
+#ifndef BLANCE_SIMT_EMU
+    if (!c || !id_128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(BLANCE_ERR_BAD_ARG, "bad communicator arguments");
+    std::lock_guard<std::mutex> g(c->mu);
+    int st = rccl_load();
+    if (st) return st;
+    HIPTRY(hipSetDevice(c->device));
+    if (c->rccl_comm) { g_rccl.CommDestroy(c->rccl_comm); c->rccl_comm = nullptr; }
+    Id128 id;
+    memcpy(id.b, id_128, sizeof id.b);
+    void* comm = nullptr;
+    int e = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
+    if (e) return fail(BLANCE_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    c->rccl_comm = comm;
+    c->comm = blance_comm{rank, n_ranks, nullptr, nullptr};
+    return BLANCE_OK;
+#else
+    (void)c; (void)n_ranks; (void)rank; (void)id_128;
+    return fail(BLANCE_ERR_COMM, "no RCCL in the emulator build");
+#endif
+}
+
+extern "C" int blance_comm_set(blance_ctx* c, const blance_comm* comm) {
+    if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!comm) { c->comm = blance_comm{0, 1, nullptr, nullptr}; return BLANCE_OK; }
+    if (comm->n_ranks < 1 || comm->rank < 0 || comm->rank >= comm->n_ranks || (comm->n_ranks > 1 && !comm->allreduce_sum_i32))
+        return fail(BLANCE_ERR_BAD_ARG, "bad communicator");
+    c->comm = *comm;
+    return BLANCE_OK;
+}
+
+static void comm_release(blance_ctx* c) {
+#ifndef BLANCE_SIMT_EMU
+    if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
+#endif
+    c->rccl_comm = nullptr;
+}
+
+// in-place int32 sum over the ranks, ordered with the kernels of the planner's stream
+static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
+    if (c->comm.n_ranks <= 1 || n <= 0) return 0;
+    c->comm_calls++;
+    c->comm_bytes += n * 4;
+    if (c->comm.allreduce_sum_i32) {
+        HIPTRY(hipStreamSynchronize(c->stream));
+        if (c->comm.allreduce_sum_i32(c->comm.user, buf, n)) return fail(BLANCE_ERR_COMM, "the caller's all-reduce failed");
+        return 0;
+    }
+#ifndef BLANCE_SIMT_EMU
+    if (!c->rccl_comm) return fail(BLANCE_ERR_COMM, "no communicator");
+    int e = g_rccl.AllReduce(buf, buf, (size_t)n, /* ncclInt32 */ 2, /* ncclSum */ 0, c->rccl_comm, c->stream);
+    if (e) return fail(BLANCE_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return 0;
+#else
+    return fail(BLANCE_ERR_COMM, "no communicator");
+#endif
+}
+#define COMMTRY(expr) do { int e__ = (expr); if (e__) return e__; } while (0)
+
 static DevProblem dev_problem(blance_ctx* c) {
     const blance_problem& h = c->h;
     DevProblem d;
@@ -880,6 +998,10 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
                 cq.NP = NP; cq.OW = OW; cq.booster_kind = h.booster_kind;
                 cq.n_regions = B;
+                // a sharded plan: this rank walks the chains of its slice of the regions
+                const bool sharded = c->comm.n_ranks > 1 && B >= c->comm.n_ranks;
+                cq.region_base = sharded ? (int)((int64_t)B * c->comm.rank / c->comm.n_ranks) : 0;
+                cq.n_launch = sharded ? (int)((int64_t)B * (c->comm.rank + 1) / c->comm.n_ranks) - cq.region_base : B;
                 cq.reg_lo = rr.reg_lo.as<int32_t>(); cq.reg_hi = rr.reg_hi.as<int32_t>();
                 cq.reg_off = c->reg_off.as<int32_t>();
                 cq.leaf_node = c->leaf_node.as<int32_t>();
@@ -897,12 +1019,20 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                     BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
                                          rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
                 cq.cnt_out = cq.cnt;
+                const size_t cnt_words = (size_t)(M + 1) * NX;
+                if (sharded) {                                     // what the ranks will sum up: outputs, load changes
+                    RESERVE(cnt_base, sizeof(int32_t) * (cnt_words + 1));
+                    RESERVE(cnt_delta, sizeof(int32_t) * (cnt_words + 1));
+                    HIPTRY(hipMemcpyAsync(c->cnt_base.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+                    HIPTRY(hipMemsetAsync(c->out.p, 0, sizeof(int32_t) * (size_t)P * OW, sm));
+                }
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
                 // a fresh plan's first sweep: every step blank -> the lean kernel; it either
                 // does the whole pass or changes nothing that is not restored below
                 bool lean = false;
                 if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4) {
                     launch_chain_blank(sm, cq, rr.max_size);
+                    if (sharded) COMMTRY(comm_allreduce(c, scal + 4, 8));       // did every rank's chains make it?
                     int32_t fl[2] = {0, 0};
                     HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
                     HIPTRY(hipStreamSynchronize(sm));
@@ -916,9 +1046,14 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                             BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state,
                                                  c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
                         HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
+                        if (sharded) HIPTRY(hipMemsetAsync(c->out.p, 0, sizeof(int32_t) * (size_t)P * OW, sm));
                     }
                 }
-                bool launched = lean || dispatch_chain(c, cq, rr.max_size);
+                bool launched = lean;
+                if (!lean) {
+                    launched = dispatch_chain(c, cq, rr.max_size);
+                    if (launched && sharded) COMMTRY(comm_allreduce(c, scal + 4, 8));
+                }
                 HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
                 launches += 8;
                 if (launched) {
@@ -932,6 +1067,16 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                         fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
                                 m, fl[2], P, fl[3]);
                     if (!fl[0] && !fl[1]) {
+                        if (sharded) {
+                            // every rank's chains wrote their own steps' outputs and their own regions' loads
+                            BLANCE_LAUNCH_NOSYNC(k_vec_sub, cdiv((int64_t)cnt_words, 256), 256, 0, sm, (int)cnt_words, c->cnt.as<int32_t>(),
+                                                 c->cnt_base.as<int32_t>(), c->cnt_delta.as<int32_t>());
+                            COMMTRY(comm_allreduce(c, c->cnt_delta.as<int32_t>(), (int64_t)cnt_words));
+                            BLANCE_LAUNCH_NOSYNC(k_vec_add, cdiv((int64_t)cnt_words, 256), 256, 0, sm, (int)cnt_words, c->cnt_base.as<int32_t>(),
+                                                 c->cnt_delta.as<int32_t>(), c->cnt.as<int32_t>());
+                            COMMTRY(comm_allreduce(c, c->out.as<int32_t>(), (int64_t)P * OW));
+                            launches += 2;
+                        }
                         if (dump_pass(c, it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
                         BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, OW, c->chain_order.as<int32_t>(),
                                              c->rec.as<int32_t>(), c->out.as<int32_t>());

@@ -5,6 +5,8 @@
 // tests/test_host_cpp.py drives both on the reference's golden inputs.
 #include "blance_api.hpp"
 
+#include <chrono>
+
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
@@ -435,6 +437,10 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
                           const PlanNextMapOptions& options) {
     PlanOutcome out;
     Flat f;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
     try {
         build(f, prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model, options);
     } catch (const Unsupported& u) {
@@ -452,7 +458,12 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     res.out_off = out_off.data(); res.out_nodes = out_nodes.data(); res.out_kind = out_kind.data();
     res.out_capacity = cap;
     res.warn_part = warn_part.data(); res.warn_state = warn_state.data(); res.warn_capacity = (int64_t)PM;
+    out.intern_ms = ms_since(t_begin);
+    const auto t_plan = std::chrono::steady_clock::now();
     if (abi.plan((blance_ctx*)lib.ctx, &f.pb, &res) != BLANCE_OK) { out.why = abi.last_error(); return out; }
+    out.plan_ms = ms_since(t_plan);
+    out.device_ms = res.device_ms;
+    const auto t_un = std::chrono::steady_clock::now();
     out.handled = true;
     out.iterations = res.iterations;
     out.converged = res.converged != 0;
@@ -482,6 +493,7 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // the last such store has the final map's content
     if ((res.iterations > 1 || !res.converged) && prevMap)
         for (auto& kv : out.nextMap) { (*prevMap)[kv.first] = kv.second; partitionsToAssign[kv.first] = kv.second; }
+    out.unintern_ms = ms_since(t_un);
     return out;
 }
 

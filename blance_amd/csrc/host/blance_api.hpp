@@ -59,6 +59,8 @@ struct PlanOutcome {
     Warnings warnings;
     int iterations = 0;
     bool converged = false;
+    // where the call's time went (ms): strings -> ids, blance_plan (H2D + device + D2H), ids -> strings
+    double intern_ms = 0.0, plan_ms = 0.0, unintern_ms = 0.0, device_ms = 0.0;
 };
 
 // The C ABI entry points, resolved at run time so that one binary can drive

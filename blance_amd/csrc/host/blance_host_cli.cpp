@@ -2,6 +2,7 @@
 // oriented text form from stdin (written by tests/test_host_cpp.py), runs it
 // through blance::PlanNextMapEx over the library given as argv[1], prints the
 // result, the warnings and the (mutated) input maps as JSON.
+#include <chrono>
 #include <iostream>
 #include <sstream>
 
@@ -129,12 +130,68 @@ static int run_moves(Library& lib) {
     return 0;
 }
 
+// `blance_host_cli <lib> bench 3 [P N]`: what a caller of the API pays end to end -- BASELINE.json config 3
+// built as the reference's own argument types (string-keyed maps), through blance::PlanNextMapEx and back
+// to a PartitionMap of strings; one warm-up call, one timed call, a JSON line with the breakdown.
+static int run_bench(Library& lib, int cfg, int P, int N) {
+    if (cfg != 3) { fprintf(stderr, "bench: only config 3\n"); return 2; }
+    char buf[32];
+    std::vector<std::string> nodes;
+    for (int i = 0; i < N; i++) { snprintf(buf, sizeof buf, "n%04d", i); nodes.push_back(buf); }
+    PartitionModel model;
+    model["primary"] = std::make_shared<PartitionModelState>(PartitionModelState{0, 1});
+    model["replica"] = std::make_shared<PartitionModelState>(PartitionModelState{1, 2});
+    PlanNextMapOptions o;
+    o.NodeHierarchy.emplace();
+    const int n_racks = (N + 15) / 16, n_zones = (n_racks + 7) / 8;
+    for (int i = 0; i < N; i++) { snprintf(buf, sizeof buf, "r%03d", i / 16); (*o.NodeHierarchy)[nodes[i]] = buf; }
+    for (int r = 0; r < n_racks; r++) {
+        char z[32];
+        snprintf(buf, sizeof buf, "r%03d", r); snprintf(z, sizeof z, "z%02d", r / 8);
+        (*o.NodeHierarchy)[buf] = z;
+    }
+    for (int z = 0; z < n_zones; z++) {
+        char d[32];
+        snprintf(buf, sizeof buf, "z%02d", z); snprintf(d, sizeof d, "d%d", z / 8);
+        (*o.NodeHierarchy)[buf] = d;
+    }
+    o.HierarchyRules_.emplace();
+    (*o.HierarchyRules_)["replica"].push_back(std::make_shared<HierarchyRule>(HierarchyRule{2, 1}));
+    PlanOutcome r;
+    double build_ms = 0.0, total_ms = 0.0;
+    for (int round = 0; round < 2; round++) {          // the planner mutates its input maps: fresh ones per call
+        auto t0 = std::chrono::steady_clock::now();
+        PartitionMap prev, assign;
+        for (int i = 0; i < P; i++) {
+            auto p = std::make_shared<Partition>();
+            p->Name = std::to_string(i);
+            p->NodesByState.emplace();
+            assign[p->Name] = p;
+        }
+        build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        auto t1 = std::chrono::steady_clock::now();
+        r = PlanNextMapEx(lib, &prev, assign, nodes, std::vector<std::string>{}, nodes, model, o);
+        total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        if (!r.handled) { fprintf(stderr, "bench: not handled: %s\n", r.why.c_str()); return 4; }
+    }
+    const double assignments = 3.0 * P;
+    printf("{\"what\": \"blance::PlanNextMapEx (C++ mirror of api.go:147), string maps in -> string maps out, second call\", "
+           "\"partitions\": %d, \"nodes\": %d, \"sweeps\": %d, \"total_ms\": %.3f, \"intern_ms\": %.3f, "
+           "\"blance_plan_ms\": %.3f, \"device_ms\": %.3f, \"unintern_ms\": %.3f, \"caller_builds_input_maps_ms\": %.3f, "
+           "\"assignments_per_s\": %.1f, \"result_partitions\": %zu}\n",
+           P, N, r.iterations, total_ms, r.intern_ms, r.plan_ms, r.device_ms, r.unintern_ms, build_ms,
+           assignments / (total_ms * 1e-3), r.nextMap.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: blance_host_cli <libblance_hip.so> [moves]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: blance_host_cli <libblance_hip.so> [moves | bench 3 [P N]]\n"); return 2; }
     Library lib;
     std::string err;
     if (!lib.open(argv[1], &err)) { fprintf(stderr, "cannot use %s: %s\n", argv[1], err.c_str()); return 3; }
     if (argc > 2 && std::string(argv[2]) == "moves") return run_moves(lib);
+    if (argc > 3 && std::string(argv[2]) == "bench")
+        return run_bench(lib, std::stoi(argv[3]), argc > 5 ? std::stoi(argv[4]) : 1 << 20, argc > 5 ? std::stoi(argv[5]) : 4096);
     int n_cases = std::stoi(line());
     std::cout << "[";
     for (int ci = 0; ci < n_cases; ci++) {

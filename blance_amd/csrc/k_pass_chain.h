@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     BLANCE_DYN_LDS(lds);
     if (q.flags[0]) return;
     const int lane = threadIdx.x;
-    const int rg = blockIdx.x;
+    const int rg = q.region_base + blockIdx.x;
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
     if (cbeg >= cend && !(q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1])) return;   // no step, no event
@@ -767,7 +767,7 @@ template <int NPTC, int KM>
 __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
     BLANCE_DYN_LDS(lds);
     const int lane = threadIdx.x;
-    const int rg = blockIdx.x;
+    const int rg = q.region_base + blockIdx.x;
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
     if (cbeg >= cend) return;

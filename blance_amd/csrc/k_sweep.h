@@ -334,6 +334,16 @@ __global__ void k_region_offsets(int B, int n_chunks, int P, const int32_t* offs
     reg_off[b] = b == B ? P : offsets[(size_t)b * n_chunks];
 }
 
+// element-wise difference / sum of int32 vectors (the load change a rank of a sharded plan contributes)
+__global__ void k_vec_sub(int n, const int32_t* a, const int32_t* b, int32_t* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - b[i];
+}
+__global__ void k_vec_add(int n, const int32_t* a, const int32_t* b, int32_t* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 // Step records in pass order: what findBestNodes needs to know about its partition.
 __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
                          const int32_t* state_stickiness, const uint8_t* state_has_stickiness,

@@ -7,7 +7,7 @@ namespace blance {
 template <int NPTC, int KM, bool FAST>
 static void launch_chain_v(hipStream_t stream, const ChainParams& q, size_t lds) {
     auto kern = k_pass_chain<NPTC, KM, FAST>;
-    BLANCE_LAUNCH(kern, q.n_regions, 64, lds, stream, q);
+    BLANCE_LAUNCH(kern, q.n_launch, 64, lds, stream, q);
 }
 
 template <int NPTC, int KM>
@@ -43,7 +43,7 @@ bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast) {
 }
 
 void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size) {
-    const int nptc = (max_size + 63) / 64, B = q.n_regions;
+    const int nptc = (max_size + 63) / 64, B = q.n_launch;
     const size_t lds = sizeof(int32_t) * ((size_t)max_size + kChainStage * (size_t)(kCW + q.OW)) + 64;
     if (q.k <= 2) {
         if (nptc <= 2) { auto kern = k_pass_chain_blank<2, 2>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); }

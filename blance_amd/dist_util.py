@@ -1,7 +1,14 @@
-"""The little torch.distributed plumbing bench.py needs for N > 1: one process
-per GPU, no data-path collective (the plan of one problem is one dependent
-chain of greedy steps -- DESIGN.md "Multi-GPU": replicas only); ranks only
-agree on the slowest rank's time."""
+"""torch.distributed plumbing for N > 1 (one process per GPU):
+
+  * shard_plan_rccl(planner, dist): the ranks join the library's own RCCL communicator, after which
+    one plan's region chains are sharded over them (include/blance_hip.h "one plan on several GPUs");
+  * gloo_allreduce(dist): the caller-provided collective for GPU-less tests (the SIMT emulator's
+    "device" memory is host memory, summed through a gloo all-reduce);
+  * max_over_ranks(seconds): the slowest rank's wall time for bench.py.
+"""
+import ctypes
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -14,7 +21,16 @@ def max_over_ranks(seconds):
     return float(t.item())
 
 
-def replica_seed(rank):
-    """Every rank plans an instance of the same shape; kept as a hook for
-    per-rank variation of the synthetic input."""
-    return 1000003 * (rank + 1)
+def shard_plan_rccl(planner, d=dist):
+    """Plans made through `planner` from now on run sharded over the ranks of `d` (RCCL inside the
+    library).  Every rank must upload the same problem and make the same calls."""
+    return planner.comm_init_rccl(d)
+
+
+def gloo_allreduce(d=dist):
+    """allreduce(address, count) over host memory, for hip.Planner.comm_set_callback()."""
+    def allreduce(ptr, count):
+        arr = np.ctypeslib.as_array((ctypes.c_int32 * count).from_address(ptr))
+        t = torch.from_numpy(arr)
+        d.all_reduce(t, op=d.ReduceOp.SUM)         # in place: t shares arr's memory
+    return allreduce

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libblance_hip.so")
 
 EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", "blance_validate",
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
-           "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get"]
+           "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get",
+           "blance_comm_unique_id", "blance_comm_init_rccl", "blance_comm_set"]
 
 _libs = {}
 
@@ -59,6 +60,12 @@ def load_library(path=None):
     lib.blance_plan_stats_get.argtypes = [C.c_void_p, C.POINTER(abi.PlanStats)]
     lib.blance_calc_moves.restype = C.c_int
     lib.blance_calc_moves.argtypes = [C.c_void_p, C.POINTER(abi.MovesProblem), C.POINTER(abi.MovesResult)]
+    lib.blance_comm_unique_id.restype = C.c_int
+    lib.blance_comm_unique_id.argtypes = [C.c_void_p]
+    lib.blance_comm_init_rccl.restype = C.c_int
+    lib.blance_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.blance_comm_set.restype = C.c_int
+    lib.blance_comm_set.argtypes = [C.c_void_p, C.POINTER(abi.Comm)]
     if lib.blance_abi_version() != abi.ABI_VERSION:
         raise ImportError("ABI version mismatch")
     _libs[path] = lib
@@ -99,6 +106,38 @@ class Planner:
             self.close()
         except Exception:
             pass
+
+    # ---- one plan on several ranks (include/blance_hip.h "one plan on several GPUs") ----
+    def comm_init_rccl(self, dist):
+        """Join the library's RCCL communicator: one process per GPU, `dist` an initialised
+        torch.distributed (any backend) that carries the 128-byte id from rank 0 to the others."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            self._check(self.lib.blance_comm_unique_id(buf))
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=0)
+        ident = C.create_string_buffer(box[0], 128)
+        self._check(self.lib.blance_comm_init_rccl(self._h, world, rank, ident))
+        return world
+
+    def comm_set_callback(self, rank, n_ranks, allreduce):
+        """A caller-provided collective: allreduce(address, count) sums `count` int32 values in place
+        over the ranks (device memory of this context; host memory under the SIMT emulator)."""
+        def _cb(_user, ptr, count):
+            try:
+                allreduce(ptr, count)
+                return 0
+            except Exception:                      # no exception may cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._comm_cb = abi.ALLREDUCE_FN(_cb)       # keep the trampoline alive
+        comm = abi.Comm(rank, n_ranks, self._comm_cb, None)
+        self._check(self.lib.blance_comm_set(self._h, C.byref(comm)))
+
+    def comm_clear(self):
+        self._check(self.lib.blance_comm_set(self._h, None))
 
     def validate(self, fp):
         return self.lib.blance_validate(C.byref(fp.as_struct()))

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define BLANCE_ABI_VERSION 1
+#define BLANCE_ABI_VERSION 2
 
 /* status codes */
 #define BLANCE_OK                0
@@ -52,7 +52,7 @@ extern "C" {
 #define BLANCE_ERR_CAPACITY     -3  /* caller's output buffers too small                */
 #define BLANCE_ERR_DEVICE       -4  /* HIP runtime failure (see blance_last_error)      */
 #define BLANCE_ERR_NO_DEVICE    -5  /* no gfx950 device visible                         */
-#define BLANCE_ERR_COMM         -6  /* RCCL failure                                     */
+#define BLANCE_ERR_COMM         -6  /* RCCL / caller collective failure                 */
 
 /* list kinds: Go distinguishes a missing map key, a nil slice and an empty
  * non-nil slice under reflect.DeepEqual (plan.go:38). */
@@ -256,6 +256,30 @@ typedef struct blance_plan_stats {
 } blance_plan_stats;
 
 int blance_plan_stats_get(blance_ctx* ctx, blance_plan_stats* stats);
+
+/* ---- one plan on several GPUs (BASELINE.json config 4) ------------------------------------
+ * The steps of a state pass that runs as region chains (one chain per hierarchy region)
+ * shard over the ranks by region: every rank holds the whole problem (upload the same problem on
+ * every rank), runs the chains of its slice of the regions, and the ranks exchange, once per such
+ * pass, the pass outputs and the change of the per-node load vector (stateNodeCounts, plan.go:94)
+ * by an int32 sum all-reduce -- pass boundaries are the only exact exchange points of
+ * plan.go:253-303.  Everything else (flat passes, ordering, convergence test) is computed by every
+ * rank identically, so all ranks return the same result, bit-identical to a single-rank plan.
+ * Collectives: the library's own RCCL communicator (blance_comm_init_rccl; one process per GPU,
+ * the 128-byte id of blance_comm_unique_id() made on rank 0 and handed to the others by the host),
+ * or a caller-provided all-reduce (blance_comm_set; used by the GPU-less tests over gloo).
+ * Every rank must make the same sequence of plan calls. */
+typedef struct blance_comm {
+    int32_t rank, n_ranks;
+    /* in-place sum over the ranks of `count` int32 values at `device_buf` (device memory of this
+     * context); called between kernels with the stream idle; 0 = ok */
+    int (*allreduce_sum_i32)(void* user, int32_t* device_buf, int64_t count);
+    void* user;
+} blance_comm;
+
+int blance_comm_unique_id(void* id_out_128 /* 128 bytes */);
+int blance_comm_init_rccl(blance_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id_128);
+int blance_comm_set(blance_ctx* ctx, const blance_comm* comm /* NULL: back to a single rank */);
 
 /* Validate a problem without touching a device (sizes, id ranges, supported
  * envelope).  Same status codes as blance_plan. */
