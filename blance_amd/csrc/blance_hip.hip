@@ -662,7 +662,8 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             int R = first_nonfresh - pos;
             // NumPartitions == 0: steps may each exclude one node (k_fresh_excl); one more element of the
             // exclusion-free sequence is needed then
-            const int RS = q.NP == 0 ? R + 1 : R;
+            const bool excl = q.NP == 0 && q.higher_mask != 0;      // the top priority state excludes nothing
+            const int RS = excl ? R + 1 : R;
             BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, RS, c->f_m.as<int32_t>(),
                           c->f_moff.as<int32_t>());
             BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
@@ -670,7 +671,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             int e = radix_sort_pairs(c, RS, launches);
             if (e) return e;
             const int32_t* picks = c->f_vals_a.as<int32_t>();
-            if (q.NP == 0) {
+            if (excl) {
                 int32_t bad = INT_MAX;
                 HIPTRY(hipMemcpyAsync(scal + 10, &bad, sizeof bad, hipMemcpyHostToDevice, sm));
                 BLANCE_LAUNCH(k_fresh_excl, 1, 1024, 2048 + 64, sm, fq, pos, R, c->f_vals_a.as<int32_t>(),

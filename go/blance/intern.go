@@ -1,0 +1,531 @@
+// Interning of one PlanNextMapEx() call into the int32 / uint8 struct of arrays of
+// include/blance_hip.h (pure Go, no cgo: unit-testable without a device).
+//
+// These files are ADDED to package blance of couchbase/blance (next to api.go, plan.go,
+// misc.go, moves.go); they use that package's own types and its sortStateNames().  Function
+// for function this is blance_amd/csrc/host/blance_api.cpp: build(), which the repository's
+// tests drive on the reference's 69 golden cases (tests/test_host_cpp.py); the Go text cannot
+// be compiled in the build image (no Go toolchain), tools/check_go_shim.py keeps its field list
+// in step with the header.
+
+package blance
+
+import (
+	"fmt"
+	"sort"
+	"strconv"
+)
+
+// list kinds, include/blance_hip.h BLANCE_LIST_*
+const (
+	listAbsent = 0
+	listNil    = 1
+	listSet    = 2
+)
+
+// errUnsupported: the input is outside the device envelope -- the caller runs plan.go instead.
+type errUnsupported struct{ why string }
+
+func (e *errUnsupported) Error() string { return "blance hip: unsupported: " + e.why }
+
+func unsupported(format string, a ...interface{}) error {
+	return &errUnsupported{why: fmt.Sprintf(format, a...)}
+}
+
+// flatProblem owns every array blance_problem points to.
+type flatProblem struct {
+	nNodes, nNodesExt, nStates, nParts, nPrev int
+	nVertices, vertexEmpty, topState          int
+	maxIterations, boosterKind                int
+	partitionWeightsNil, nodesToAddNil        bool
+	hierarchyRulesNil                         bool
+
+	statePriority, stateConstraints, stateStickiness []int32
+	stateHasStickiness                               []uint8
+
+	nodeRemoved, nodeAdded, nodeHasWeight []uint8
+	nodeWeight                            []int32
+
+	partOrder, partWeight                          []int32
+	partHasWeight, partInPrev, partPrevNeverEqual []uint8
+
+	assignOff, assignNodes []int32
+	assignKind             []uint8
+	prevOff, prevNodes     []int32
+	prevKind               []uint8
+
+	loadState, loadNode, loadWeight []int32
+	loadFirstSweepOnly              []uint8
+
+	ruleOff, ruleInc, ruleExc                  []int32
+	vertexParent, vertexLeafLo, vertexLeafHi []int32
+	nodeLeafPos                                []int32
+
+	nodeNames, stateNames, partNames []string
+}
+
+type interner struct {
+	ids   map[string]int32
+	names []string
+}
+
+func newInterner(hint int) *interner {
+	return &interner{ids: make(map[string]int32, hint), names: make([]string, 0, hint)}
+}
+
+func (t *interner) add(s string) int32 {
+	if id, ok := t.ids[s]; ok {
+		return id
+	}
+	id := int32(len(t.names))
+	t.ids[s] = id
+	t.names = append(t.names, s)
+	return id
+}
+
+func abs64(v int64) int64 {
+	if v < 0 {
+		return -v
+	}
+	return v
+}
+
+// stateLess is stateNameSorter.Less (plan.go:459-470) on names.
+func stateLess(model PartitionModel, a, b string) bool {
+	ma, mb := model[a], model[b]
+	if ma != nil && mb != nil && ma.Priority < mb.Priority {
+		return true
+	}
+	return a < b
+}
+
+// internProblem flattens the arguments of planNextMapEx (plan.go:23-31).
+func internProblem(
+	prevMap PartitionMap,
+	partitionsToAssign PartitionMap,
+	nodesAll []string,
+	nodesToRemove []string,
+	nodesToAdd []string,
+	model PartitionModel,
+	options PlanNextMapOptions,
+	boosterKind int) (*flatProblem, error) {
+	f := &flatProblem{maxIterations: MaxIterationsPerPlan, boosterKind: boosterKind}
+	if prevMap == nil && len(partitionsToAssign) > 0 {
+		return nil, unsupported("nil prevMap with partitions to assign (plan.go:50 panics)")
+	}
+
+	// ---- states in pass order: sortStateNames, plan.go:437-474 (refused where its comparator
+	// is not an order: the result would depend on sort.Sort's internals)
+	for name, ms := range model {
+		if ms == nil {
+			return nil, unsupported("nil *PartitionModelState for %q", name)
+		}
+	}
+	for a := range model {
+		for b := range model {
+			if a != b && stateLess(model, a, b) && stateLess(model, b, a) {
+				return nil, unsupported("state priority order contradicts state name order")
+			}
+		}
+	}
+	states := sortStateNames(model)
+	M := len(states)
+	sid := make(map[string]int32, M)
+	for i, s := range states {
+		sid[s] = int32(i)
+	}
+	anyPass := false
+	for _, s := range states {
+		k := model[s].Constraints
+		if options.ModelStateConstraints != nil { // plan.go:314-319
+			if v, ok := options.ModelStateConstraints[s]; ok {
+				k = v
+			}
+		}
+		f.statePriority = append(f.statePriority, int32(model[s].Priority))
+		f.stateConstraints = append(f.stateConstraints, int32(k))
+		if k > 0 {
+			anyPass = true
+		}
+	}
+	if M > 0 {
+		mn := f.statePriority[0]
+		for _, p := range f.statePriority {
+			if p < mn {
+				mn = p
+			}
+		}
+		nTop := 0
+		for i := M - 1; i >= 0; i-- {
+			if f.statePriority[i] == mn {
+				f.topState = i
+				nTop++
+			}
+		}
+		if nTop > 1 && anyPass { // plan.go:126-132 walks a Go map: the choice would be random
+			return nil, unsupported("several states share the top priority")
+		}
+	}
+
+	// ---- nodes: ids 0..N-1 are positions in nodesAll (plan.go:72-75)
+	nodes := newInterner(len(nodesAll) + 16)
+	for _, n := range nodesAll {
+		if _, dup := nodes.ids[n]; dup {
+			return nil, unsupported("duplicate node name %q in nodesAll", n)
+		}
+		nodes.add(n)
+	}
+	N := len(nodes.names)
+
+	// ---- partitions
+	weightsNil := options.PartitionWeights == nil
+	pnames := make([]string, 0, len(partitionsToAssign))
+	for key, p := range partitionsToAssign {
+		if p == nil {
+			return nil, unsupported("nil *Partition in partitionsToAssign")
+		}
+		if p.Name != key {
+			return nil, unsupported("partition key %q != Partition.Name %q", key, p.Name)
+		}
+		pnames = append(pnames, key)
+	}
+	sort.Strings(pnames)
+	P := len(pnames)
+	f.partWeight = make([]int32, P)
+	f.partHasWeight = make([]uint8, P)
+	f.partInPrev = make([]uint8, P)
+	f.partPrevNeverEqual = make([]uint8, P)
+	for i, name := range pnames {
+		f.partWeight[i] = 1
+		if !weightsNil {
+			if w, ok := options.PartitionWeights[name]; ok {
+				if int64(w) > 2147483647 || int64(w) < -2147483648 {
+					return nil, unsupported("partition weight outside int32")
+				}
+				f.partWeight[i] = int32(w)
+				f.partHasWeight[i] = 1
+			}
+		}
+	}
+	removed := StringsToMap(nodesToRemove)
+	f.assignOff = append(f.assignOff, 0)
+	f.prevOff = append(f.prevOff, 0)
+	var absLoad int64
+	for i, name := range pnames {
+		pa := partitionsToAssign[name]
+		for st := range pa.NodesByState {
+			if _, ok := sid[st]; !ok {
+				return nil, unsupported("partition %q carries state %q that is not in the model", name, st)
+			}
+		}
+		for _, s := range states {
+			lst, ok := pa.NodesByState[s]
+			switch {
+			case !ok:
+				f.assignKind = append(f.assignKind, listAbsent)
+			case lst == nil:
+				f.assignKind = append(f.assignKind, listNil)
+			default:
+				f.assignKind = append(f.assignKind, listSet)
+				seen := make(map[string]bool, len(lst))
+				for _, x := range lst {
+					if seen[x] {
+						return nil, unsupported("duplicate node inside a state list of %q", name)
+					}
+					seen[x] = true
+					f.assignNodes = append(f.assignNodes, nodes.add(x))
+				}
+			}
+			f.assignOff = append(f.assignOff, int32(len(f.assignNodes)))
+		}
+		w := int64(f.partWeight[i])
+		pp, inPrev := prevMap[name]
+		if !inPrev {
+			if len(removed) > 0 && anyPass {
+				return nil, unsupported("nodesToRemove non-empty but %q is missing from prevMap (plan.go:545 panics)", name)
+			}
+			for m := 0; m < M; m++ {
+				f.prevKind = append(f.prevKind, listAbsent)
+				f.prevOff = append(f.prevOff, int32(len(f.prevNodes)))
+			}
+			continue
+		}
+		if pp == nil {
+			return nil, unsupported("nil *Partition in prevMap")
+		}
+		f.partInPrev[i] = 1
+		if pp.NodesByState == nil || pp.Name != name { // reflect.DeepEqual (plan.go:38) can never hold
+			f.partPrevNeverEqual[i] = 1
+		}
+		for _, s := range states {
+			lst, ok := pp.NodesByState[s]
+			switch {
+			case !ok:
+				f.prevKind = append(f.prevKind, listAbsent)
+			case lst == nil:
+				f.prevKind = append(f.prevKind, listNil)
+			default:
+				f.prevKind = append(f.prevKind, listSet)
+				for _, x := range lst {
+					f.prevNodes = append(f.prevNodes, nodes.add(x))
+					absLoad += abs64(w)
+				}
+			}
+			f.prevOff = append(f.prevOff, int32(len(f.prevNodes)))
+		}
+		for st, lst := range pp.NodesByState { // states outside the model only feed nodePartitionCounts
+			if _, ok := sid[st]; ok {
+				continue
+			}
+			f.partPrevNeverEqual[i] = 1
+			for _, x := range lst {
+				f.loadState = append(f.loadState, int32(M))
+				f.loadNode = append(f.loadNode, nodes.add(x))
+				f.loadWeight = append(f.loadWeight, int32(w))
+				f.loadFirstSweepOnly = append(f.loadFirstSweepOnly, 1)
+				absLoad += abs64(w)
+			}
+		}
+	}
+	for name, pp := range prevMap { // partitions that are only in prevMap (countStateNodes, plan.go:374-399)
+		if _, ok := partitionsToAssign[name]; ok {
+			continue
+		}
+		if pp == nil {
+			return nil, unsupported("nil *Partition in prevMap")
+		}
+		w := int64(1)
+		if !weightsNil {
+			if v, ok := options.PartitionWeights[name]; ok {
+				w = int64(v)
+			}
+		}
+		for st, lst := range pp.NodesByState {
+			state := int32(M)
+			if id, ok := sid[st]; ok {
+				state = id
+			}
+			for _, x := range lst {
+				f.loadState = append(f.loadState, state)
+				f.loadNode = append(f.loadNode, nodes.add(x))
+				f.loadWeight = append(f.loadWeight, int32(w))
+				f.loadFirstSweepOnly = append(f.loadFirstSweepOnly, 0)
+				absLoad += abs64(w)
+			}
+		}
+	}
+	{ // the device's load tables are int32
+		var sumw, maxw, ksum int64
+		for _, w := range f.partWeight {
+			sumw += abs64(int64(w))
+			if abs64(int64(w)) > maxw {
+				maxw = abs64(int64(w))
+			}
+		}
+		for _, k := range f.stateConstraints {
+			if k > 0 {
+				ksum += int64(k)
+			}
+		}
+		if ksum < 1 {
+			ksum = 1
+		}
+		absLoad += sumw * ksum * 2
+		if absLoad > 2147483647 {
+			return nil, unsupported("partition weights overflow the device's int32 load tables")
+		}
+	}
+
+	// ---- node attributes (names that are not in nodesAll get ids >= N: counted, never candidates)
+	for _, x := range nodesToRemove {
+		nodes.add(x)
+	}
+	for _, x := range nodesToAdd {
+		nodes.add(x)
+	}
+	for x := range options.NodeWeights {
+		nodes.add(x)
+	}
+	NX := len(nodes.names)
+	f.nodeRemoved = make([]uint8, NX)
+	f.nodeAdded = make([]uint8, NX)
+	f.nodeWeight = make([]int32, NX)
+	f.nodeHasWeight = make([]uint8, NX)
+	for _, x := range nodesToRemove {
+		f.nodeRemoved[nodes.ids[x]] = 1
+	}
+	for _, x := range nodesToAdd {
+		f.nodeAdded[nodes.ids[x]] = 1
+	}
+	for x, w := range options.NodeWeights {
+		if int64(w) > 2147483647 || int64(w) < -2147483648 {
+			return nil, unsupported("node weight outside int32")
+		}
+		f.nodeWeight[nodes.ids[x]] = int32(w)
+		f.nodeHasWeight[nodes.ids[x]] = 1
+	}
+	f.stateStickiness = make([]int32, M)
+	f.stateHasStickiness = make([]uint8, M)
+	for st, v := range options.StateStickiness {
+		if id, ok := sid[st]; ok {
+			if int64(v) > 2147483647 || int64(v) < -2147483648 {
+				return nil, unsupported("state stickiness outside int32")
+			}
+			f.stateStickiness[id] = int32(v)
+			f.stateHasStickiness[id] = 1
+		}
+	}
+
+	// ---- hierarchy rules, and the tree as DFS leaf intervals (plan.go:703-774)
+	rulesNil := options.HierarchyRules == nil
+	f.ruleOff = append(f.ruleOff, 0)
+	f.nodeLeafPos = make([]int32, NX)
+	for i := range f.nodeLeafPos {
+		f.nodeLeafPos[i] = -1
+	}
+	if rulesNil {
+		for m := 0; m < M; m++ {
+			f.ruleOff = append(f.ruleOff, 0)
+		}
+	} else {
+		for m, s := range states {
+			for _, r := range options.HierarchyRules[s] {
+				if r == nil {
+					return nil, unsupported("nil *HierarchyRule")
+				}
+				inc, exc := r.IncludeLevel, r.ExcludeLevel // findAncestor loops `for level > 0`
+				if inc < 0 {
+					inc = 0
+				}
+				if exc < 0 {
+					exc = 0
+				}
+				f.ruleInc = append(f.ruleInc, int32(inc))
+				f.ruleExc = append(f.ruleExc, int32(exc))
+			}
+			f.ruleOff = append(f.ruleOff, int32(len(f.ruleInc)))
+			k := int(f.stateConstraints[m])
+			if k > 0 && int(f.ruleOff[m+1]-f.ruleOff[m])*k > 64 {
+				return nil, unsupported("more than 64 hierarchy picks for a state")
+			}
+		}
+		if _, ok := nodes.ids[""]; ok {
+			return nil, unsupported("\"\" used as a node name")
+		}
+		v := &interner{ids: make(map[string]int32, NX+len(options.NodeHierarchy)), names: append([]string(nil), nodes.names...)}
+		for name, id := range nodes.ids {
+			v.ids[name] = id
+		}
+		childNames := make([]string, 0, len(options.NodeHierarchy))
+		for c, p := range options.NodeHierarchy {
+			v.add(c)
+			v.add(p)
+			childNames = append(childNames, c)
+		}
+		sort.Strings(childNames) // children in name order, plan.go:705-715
+		vEmpty := v.add("")
+		VX := len(v.names)
+		f.vertexEmpty = int(vEmpty)
+		f.nVertices = VX
+		f.vertexParent = make([]int32, VX)
+		for i := range f.vertexParent {
+			f.vertexParent[i] = vEmpty // findAncestor: a missing parent is ""
+		}
+		children := make([][]int32, VX)
+		hasParent := make([]bool, VX)
+		for _, c := range childNames {
+			ci, pi := v.ids[c], v.ids[options.NodeHierarchy[c]]
+			f.vertexParent[ci] = pi
+			children[pi] = append(children[pi], ci)
+			hasParent[ci] = true
+		}
+		f.vertexLeafLo = make([]int32, VX)
+		f.vertexLeafHi = make([]int32, VX)
+		for i := range f.vertexLeafLo {
+			f.vertexLeafLo[i], f.vertexLeafHi[i] = -1, -1
+		}
+		type frame struct {
+			u  int32
+			ci int
+		}
+		pos := int32(0)
+		for root := 0; root < VX; root++ {
+			if hasParent[root] {
+				continue
+			}
+			stack := []frame{{int32(root), 0}}
+			for len(stack) > 0 {
+				fr := stack[len(stack)-1]
+				stack = stack[:len(stack)-1]
+				if fr.ci == 0 {
+					f.vertexLeafLo[fr.u] = pos
+					if len(children[fr.u]) == 0 { // a childless vertex is its own leaf
+						pos++
+						f.vertexLeafHi[fr.u] = pos
+						continue
+					}
+				}
+				if fr.ci < len(children[fr.u]) {
+					stack = append(stack, frame{fr.u, fr.ci + 1}, frame{children[fr.u][fr.ci], 0})
+				} else {
+					f.vertexLeafHi[fr.u] = pos
+				}
+			}
+		}
+		for u := 0; u < VX; u++ {
+			if f.vertexLeafLo[u] < 0 || f.vertexLeafHi[u] < 0 {
+				return nil, unsupported("cycle in NodeHierarchy")
+			}
+		}
+		for n := 0; n < NX; n++ {
+			if len(children[n]) == 0 {
+				f.nodeLeafPos[n] = f.vertexLeafLo[n]
+			}
+		}
+	}
+
+	// ---- the static part of partitionSorter's key (plan.go:519-540), compared as the reference's strings
+	{
+		type key struct {
+			w, n, name string
+			i          int32
+		}
+		keys := make([]key, P)
+		for i, name := range pnames {
+			nkey := name
+			if v, err := strconv.Atoi(name); err == nil && v >= 0 {
+				nkey = fmt.Sprintf("%10d", v)
+			}
+			w := 1
+			if !weightsNil {
+				if pw, ok := options.PartitionWeights[name]; ok {
+					w = pw
+				}
+			}
+			keys[i] = key{fmt.Sprintf("%10d", 999999999-w), nkey, name, int32(i)}
+		}
+		sort.Slice(keys, func(a, b int) bool {
+			if keys[a].w != keys[b].w {
+				return keys[a].w < keys[b].w
+			}
+			if keys[a].n != keys[b].n {
+				return keys[a].n < keys[b].n
+			}
+			return keys[a].name < keys[b].name
+		})
+		f.partOrder = make([]int32, P)
+		for r, k := range keys {
+			f.partOrder[r] = k.i
+		}
+	}
+	if P*M == 0 {
+		f.assignOff, f.prevOff = []int32{0}, []int32{0}
+	}
+
+	f.nNodes, f.nNodesExt, f.nStates, f.nParts, f.nPrev = N, NX, M, P, len(prevMap)
+	f.partitionWeightsNil = weightsNil
+	f.nodesToAddNil = nodesToAdd == nil
+	f.hierarchyRulesNil = rulesNil
+	f.nodeNames, f.stateNames, f.partNames = nodes.names, states, pnames
+	return f, nil
+}
