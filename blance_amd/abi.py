@@ -104,10 +104,14 @@ class FlatProblem:
         self._struct = None
 
     def set(self, name, arr):
-        if name in I32_FIELDS:
-            a = np.ascontiguousarray(arr, dtype=np.int32)
-        elif name in U8_FIELDS:
-            a = np.ascontiguousarray(arr, dtype=np.uint8)
+        if name in I32_FIELDS or name in U8_FIELDS:
+            dt = np.int32 if name in I32_FIELDS else np.uint8
+            src = np.asarray(arr)
+            if src.size and src.dtype != dt:       # never wrap silently (a stickiness of 2**31, say)
+                info = np.iinfo(dt)
+                if src.min() < info.min or src.max() > info.max:
+                    raise OverflowError("%s: value outside %s" % (name, np.dtype(dt).name))
+            a = np.ascontiguousarray(src, dtype=dt)
         else:
             raise KeyError(name)
         if a.size == 0:          # keep a valid pointer for empty arrays

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <new>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -141,6 +142,17 @@ struct blance_ctx {
 };
 
 static void comm_release(blance_ctx* c);
+// no exception crosses the C boundary (std::bad_alloc from a staging vector, say)
+template <class F>
+static int guarded(F f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(BLANCE_ERR_DEVICE, "out of host memory");
+    } catch (...) {
+        return fail(BLANCE_ERR_DEVICE, "unexpected exception");
+    }
+}
 extern "C" int blance_abi_version(void) { return BLANCE_ABI_VERSION; }
 extern "C" const char* blance_last_error(void) { return g_last_error.c_str(); }
 
@@ -157,6 +169,7 @@ extern "C" int64_t blance_result_capacity(const blance_problem* pb) {
 }
 
 extern "C" int blance_validate(const blance_problem* pb) {
+    return guarded([&]() -> int {
     if (!pb) return fail(BLANCE_ERR_BAD_ARG, "null problem");
     const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
     if (N < 0 || NX < N || M < 0 || P < 0 || pb->n_prev < 0 || pb->n_loads < 0 || pb->n_rules < 0 ||
@@ -197,6 +210,7 @@ extern "C" int blance_validate(const blance_problem* pb) {
     for (int i = 0; i < pb->n_loads; i++)
         if (pb->load_state[i] < 0 || pb->load_state[i] > M || pb->load_node[i] < 0 || pb->load_node[i] >= NX)
             return fail(BLANCE_ERR_BAD_ARG, "load entry out of range");
+    if (pb->rule_off[0] != 0) return fail(BLANCE_ERR_BAD_ARG, "rule_off must start at 0");
     for (int m = 0; m < M; m++) {
         int k = pb->state_constraints[m];
         if (k > kMaxK) return fail(BLANCE_ERR_UNSUPPORTED, "constraints > 8 for a state");
@@ -212,9 +226,11 @@ extern "C" int blance_validate(const blance_problem* pb) {
         if (pb->vertex_empty < 0 || pb->vertex_empty >= VX) return fail(BLANCE_ERR_BAD_ARG, "vertex_empty out of range");
         for (int v = 0; v < VX; v++) {
             if (pb->vertex_parent[v] < 0 || pb->vertex_parent[v] >= VX) return fail(BLANCE_ERR_BAD_ARG, "vertex_parent out of range");
-            if (pb->vertex_leaf_lo[v] < 0 || pb->vertex_leaf_hi[v] <= pb->vertex_leaf_lo[v])
-                return fail(BLANCE_ERR_BAD_ARG, "vertex leaf interval empty");
+            if (pb->vertex_leaf_lo[v] < 0 || pb->vertex_leaf_hi[v] <= pb->vertex_leaf_lo[v] || pb->vertex_leaf_hi[v] > VX)
+                return fail(BLANCE_ERR_BAD_ARG, "vertex leaf interval empty or beyond the number of vertices");
         }
+        for (int n = 0; n < NX; n++)
+            if (pb->node_leaf_pos[n] < -1 || pb->node_leaf_pos[n] >= VX) return fail(BLANCE_ERR_BAD_ARG, "node_leaf_pos out of range");
         for (int r = 0; r < pb->n_rules; r++)
             if (pb->rule_inc[r] < 0 || pb->rule_exc[r] < 0 || pb->rule_inc[r] > 64 || pb->rule_exc[r] > 64)
                 return fail(BLANCE_ERR_UNSUPPORTED, "hierarchy rule level outside 0..64");
@@ -230,8 +246,22 @@ extern "C" int blance_validate(const blance_problem* pb) {
         if (b > L) L = b;
     }
     if (kRecHead + M * (1 + L) > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
+    {   // the load tables are int32: bound every sum a plan can form (a shim doing its own interning gets the check too)
+        long long abs_load = 0, sumw = 0, ksum = 0;
+        auto la = [](long long v) { return v < 0 ? -v : v; };
+        for (int p = 0; p < P; p++) {
+            const long long w = (!pb->partition_weights_nil && pb->part_has_weight[p]) ? la(pb->part_weight[p]) : 1;
+            sumw += w;
+            if (pb->part_in_prev[p]) abs_load += w * (pb->prev_off[(int64_t)(p + 1) * M] - pb->prev_off[(int64_t)p * M]);
+        }
+        for (int i = 0; i < pb->n_loads; i++) abs_load += la(pb->load_weight[i]);
+        for (int m = 0; m < M; m++) ksum += pb->state_constraints[m] > 0 ? pb->state_constraints[m] : 0;
+        abs_load += sumw * (ksum > 1 ? ksum : 1) * 2;
+        if (abs_load > 2147483647LL) return fail(BLANCE_ERR_UNSUPPORTED, "partition weights overflow the int32 load tables");
+    }
     if ((int64_t)(NX + 1) * (N > 0 ? N : 1) * 4 > (int64_t)64 << 30) return fail(BLANCE_ERR_UNSUPPORTED, "nodeToNodeCounts matrix > 64 GiB");
     return BLANCE_OK;
+    });
 }
 
 extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
@@ -286,7 +316,16 @@ static int put(blance_ctx* c, DevBuf& b, const T* src, size_t n) {
 
 static inline int cdiv(int64_t a, int b) { return (int)((a + b - 1) / b); }
 
+static int upload_inner(blance_ctx* c, const blance_problem* pb);
+// hipMemcpyAsync may still be reading the caller's arrays (and this function's staging tables) when an
+// error cuts the upload short: never return with copies in flight
 static int upload_locked(blance_ctx* c, const blance_problem* pb) {
+    int st = upload_inner(c, pb);
+    if (st && c->stream) (void)hipStreamSynchronize(c->stream);
+    return st;
+}
+
+static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     int st = blance_validate(pb);
     if (st) return st;
     HIPTRY(hipSetDevice(c->device));
@@ -309,7 +348,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     int fresh = 0;
     for (int p = 0; p < P; p++) if (!pb->part_in_prev[p]) fresh++;
     c->np_later = pb->n_prev + fresh;                      // plan.go:50
-    std::vector<uint8_t> alive((size_t)NX + 1, 0);
+    std::vector<uint8_t> alive((size_t)NX + 1, 0);   // lives to the hipStreamSynchronize at the end of this function
     c->n_alive = 0;
     c->any_removed = 0;
     for (int n = 0; n < NX; n++) {
@@ -440,7 +479,9 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
                 if (put(c, rr.leaf_cls, leaf_cls.data(), leaf_cls.size())) return BLANCE_ERR_DEVICE;
                 if (put(c, rr.cls_size, cls_size.data(), cls_size.size())) return BLANCE_ERR_DEVICE;
             }
+            HIPTRY(hipStreamSynchronize(c->stream));      // this rule's staging vectors go out of scope
         }
+        HIPTRY(hipStreamSynchronize(c->stream));          // ... and the anchor / leaf tables
     }
     const int RW = kRecHead + M * (1 + L);       // header + per-state lists
     int kmax = 1;
@@ -494,6 +535,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
             PUT(fl_one, one.data(), one.size());
             PUT(fl_reglo, &lo0, 1);
             PUT(fl_reghi, &hi0, 1);
+            HIPTRY(hipStreamSynchronize(c->stream));      // iota / zero / one / lo0 / hi0 are locals
         }
         RESERVE(f_tot, sizeof(int32_t) * ((size_t)NX + 1));
         RESERVE(f_g, sizeof(double) * ((size_t)NX + 1));
@@ -788,6 +830,7 @@ extern "C" int blance_comm_unique_id(void* id_out_128) {
 }
 
 extern "C" int blance_comm_init_rccl(blance_ctx* c, int32_t n_ranks, int32_t rank, const void* id_128) {
+    return guarded([&]() -> int {
 #ifndef BLANCE_SIMT_EMU
     if (!c || !id_128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(BLANCE_ERR_BAD_ARG, "bad communicator arguments");
     std::lock_guard<std::mutex> g(c->mu);
@@ -807,9 +850,11 @@ extern "C" int blance_comm_init_rccl(blance_ctx* c, int32_t n_ranks, int32_t ran
     (void)c; (void)n_ranks; (void)rank; (void)id_128;
     return fail(BLANCE_ERR_COMM, "no RCCL in the emulator build");
 #endif
+    });
 }
 
 extern "C" int blance_comm_set(blance_ctx* c, const blance_comm* comm) {
+    return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
     if (!comm) { c->comm = blance_comm{0, 1, nullptr, nullptr}; return BLANCE_OK; }
@@ -817,6 +862,7 @@ extern "C" int blance_comm_set(blance_ctx* c, const blance_comm* comm) {
         return fail(BLANCE_ERR_BAD_ARG, "bad communicator");
     c->comm = *comm;
     return BLANCE_OK;
+    });
 }
 
 static void comm_release(blance_ctx* c) {
@@ -1286,6 +1332,7 @@ static int download_locked(blance_ctx* c, blance_result* res) {
 }
 
 extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, blance_moves_result* res) {
+    return guarded([&]() -> int {
     if (!c || !pb || !res) return fail(BLANCE_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> g(c->mu);
     const int P = pb->n_parts, M = pb->n_states;
@@ -1346,21 +1393,27 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
     }
     res->op_off[P] = (int32_t)off;
     return BLANCE_OK;
+    });
 }
 
 extern "C" int blance_upload(blance_ctx* c, const blance_problem* pb) {
+    return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
     return upload_locked(c, pb);
+    });
 }
 
 extern "C" int blance_plan_resident(blance_ctx* c, blance_result* res) {
+    return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
     return plan_locked(c, res);
+    });
 }
 
 extern "C" int blance_plan_stats_get(blance_ctx* c, blance_plan_stats* st) {
+    return guarded([&]() -> int {
     if (!c || !st) return fail(BLANCE_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->planned) return fail(BLANCE_ERR_BAD_ARG, "nothing planned yet");
@@ -1403,15 +1456,19 @@ extern "C" int blance_plan_stats_get(blance_ctx* c, blance_plan_stats* st) {
         st->unmet_slots[m] = c->iterations > 0 ? hun[(size_t)m] : 0;
     }
     return BLANCE_OK;
+    });
 }
 
 extern "C" int blance_download(blance_ctx* c, blance_result* res) {
+    return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
     return download_locked(c, res);
+    });
 }
 
 extern "C" int blance_plan(blance_ctx* c, const blance_problem* pb, blance_result* res) {
+    return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     if (!res) return fail(BLANCE_ERR_BAD_ARG, "null result");
     std::lock_guard<std::mutex> g(c->mu);
@@ -1433,5 +1490,6 @@ extern "C" int blance_plan(blance_ctx* c, const blance_problem* pb, blance_resul
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     return st;
+    });
 }
 

@@ -596,7 +596,7 @@ void put_string(std::string& o, const char* s, size_t n) {     // encodeState.st
     o.push_back('"');
 }
 
-struct View {                                  // bounds-checked access to a caller's view
+struct View {                                  // string i of a blob (blance_wire_encode checks the offsets first)
     const blance_wire_view* v;
     const char* str(const char* bytes, const int64_t* off, int64_t i, size_t* n) const {
         *n = (size_t)(off[i + 1] - off[i]);
@@ -680,6 +680,24 @@ int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_l
         o = "null";
     } else {
         const int64_t P = v->n_parts;
+        // the view is the caller's: sizes, pointers and offset arrays are checked before anything is read through them
+        if (P < 0 || v->n_states < 0 || v->n_nodes < 0 || v->n_entries < 0 || v->n_node_refs < 0)
+            return fail(BLANCE_WIRE_ERR_ARG, "negative size");
+        if (!v->key_off || !v->name_off || !v->part_off || !v->state_off || !v->node_off || !v->entry_off ||
+            (P > 0 && (!v->key_bytes || !v->name_bytes || !v->part_kind)) ||
+            (v->n_entries > 0 && (!v->entry_state || !v->entry_kind)) || (v->n_node_refs > 0 && !v->entry_nodes) ||
+            (v->n_states > 0 && !v->state_bytes) || (v->n_nodes > 0 && !v->node_bytes))
+            return fail(BLANCE_WIRE_ERR_ARG, "null array in the view");
+        auto monotone = [](const int64_t* off, int64_t n) {
+            if (off[0] != 0) return false;
+            for (int64_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
+            return true;
+        };
+        if (!monotone(v->key_off, P) || !monotone(v->name_off, P) || !monotone(v->part_off, P) ||
+            !monotone(v->state_off, v->n_states) || !monotone(v->node_off, v->n_nodes) || !monotone(v->entry_off, v->n_entries))
+            return fail(BLANCE_WIRE_ERR_ARG, "offsets do not start at 0 or are not monotone");
+        if (v->part_off[P] > v->n_entries || v->entry_off[v->n_entries] > v->n_node_refs)
+            return fail(BLANCE_WIRE_ERR_ARG, "offsets run past the arrays they index");
         for (int64_t e = 0; e < v->n_entries; e++)
             if (v->entry_state[e] < 0 || v->entry_state[e] >= v->n_states) return fail(BLANCE_WIRE_ERR_ARG, "state id out of range");
         for (int64_t r = 0; r < v->n_node_refs; r++)

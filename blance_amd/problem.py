@@ -20,7 +20,7 @@ class Unsupported(Exception):
     """Input outside the supported envelope."""
 
 
-_ATOI_RE = re.compile(r"^[+-]?[0-9]+$")
+_ATOI_RE = re.compile(r"\A[+-]?[0-9]+\Z")      # strconv.Atoi: no trailing newline either
 INT32_MAX = (1 << 31) - 1
 
 
