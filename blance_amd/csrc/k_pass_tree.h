@@ -198,27 +198,34 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         int ownv[KM], ntn_own[KM], hv[KH], ov[KO];
         unsigned oKh[KM], oKl[KM];
 #pragma unroll
-        for (int j = 0; j < KM; j++) { ownv[j] = 0; ntn_own[j] = 0; oKh[j] = kKeyNoneV; oKl[j] = kKeyNoneV; }
+        for (int j = 0; j < KM; j++) { ownv[j] = -1; ntn_own[j] = 0; oKh[j] = kKeyNoneV; oKl[j] = kKeyNoneV; }
 #pragma unroll
         for (int j = 0; j < KH; j++) hv[j] = -1;
 #pragma unroll
         for (int j = 0; j < KO; j++) ov[j] = -1;
-        bool pok = act;                              // own list complete and inside nodesAll: ntn_own is loaded
+        bool pok = act;                              // own list of at most k nodes inside nodesAll: ntn_own is loaded
+        int nown = 0;                                // its length (k: the step may be a stay)
         const double vstick = __hiloint2double(rj[3], rj[2]);
         {
             const int hT = rj[kRecHead + q.top_state * SW];
             if ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) row = rj[kRecHead + q.top_state * SW + 1];   // plan.go:134-138
             const int hs = rj[kRecHead + s * SW];
-            if ((hs >> 16) == kListAbsent || (hs & 0xffff) != k) pok = false;
+            nown = (hs >> 16) == kListAbsent ? 0 : (hs & 0xffff);
+            if (nown > k) { pok = false; nown = 0; }
             if (pok) {
 #pragma unroll
                 for (int j = 0; j < KM; j++) {
-                    if (j < k) {
+                    if (j < nown) {
                         const int o = rj[kRecHead + s * SW + 1 + j];
                         ownv[j] = o;
                         if (o >= N) pok = false;
                     }
                 }
+            }
+            if (!pok) {
+                nown = 0;
+#pragma unroll
+                for (int j = 0; j < KM; j++) ownv[j] = -1;
             }
         }
         // simple: every own node is a candidate, held once, in no other list; few nodes in the other lists
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         if (simple) {
 #pragma unroll
             for (int j = 0; j < KM; j++) {
-                if (j < k) {
+                if (j < nown) {
                     if (!(flL[ownv[j]] & 1)) simple = false;
 #pragma unroll
                     for (int jj = 0; jj < KM; jj++) if (jj < j && ownv[jj] == ownv[j]) simple = false;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                 for (int jj = 0; jj < (h & 0xffff); jj++) {
                     const int x = rj[kRecHead + t * SW + 1 + jj];
 #pragma unroll
-                    for (int j = 0; j < KM; j++) if (j < k && ownv[j] == x) simple = false;   // excluded or demoted: not a plain stay
+                    for (int j = 0; j < KM; j++) if (ownv[j] == x) simple = false;   // excluded or demoted: not a plain stay
                     if (higher) {
                         if (n_h >= KH) simple = false;
 #pragma unroll
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         if (NP > 0) {
 #pragma unroll
             for (int j = 0; j < KM; j++)
-                if (pok && j < k) ntn_own[j] = BLANCE_LD_COHERENT(q.ntn + (size_t)row * N + ownv[j]);
+                if (pok && j < nown) ntn_own[j] = BLANCE_LD_COHERENT(q.ntn + (size_t)row * N + ownv[j]);
             for (int i = 0; i < B - 1; i++) {
                 const int ri = __builtin_amdgcn_readlane(row, i);
                 if (lane > i && row == ri) dirty = true;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         PH(2);
         u64 lastB = 0;
         int lastN = -1;
-        bool sfail = !simple;
+        bool sfail = !simple || nown != k;           // fewer nodes than constraints: never a stay
         bool stale = false;                          // an earlier general step of the batch touched my own nodes
         int sortv[KM];                               // the own nodes in (score, position) order: what a stay emits
 #pragma unroll
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             for (int j = 0; j < KM; j++) sK[j] = ~0ull;
 #pragma unroll
             for (int j = 0; j < KM; j++) {
-                if (j < k) {
+                if (j < nown) {
                     const int o = ownv[j];
                     const u64 b = sortable_bits(tree_score(cntL[o], ntn_own[j], totL[o], (flL[o] >> 1) & 1, wL[o], NP,
                                                            vstick, q.booster_kind, lpT, ffT));
@@ -401,10 +408,10 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
 #pragma unroll
                 for (int j = 0; j < KM; j++) {
                     if (j < k) {
-                        qown[j] = __builtin_amdgcn_readlane(ownv[j], f);
+                        qown[j] = __builtin_amdgcn_readlane(ownv[j], f);     // -1 beyond the list's length
                         const unsigned bh = (unsigned)__builtin_amdgcn_readlane((int)oKh[j], f);
                         const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)oKl[j], f);
-                        insert(((u64)bh << 32) | bl, qown[j]);
+                        if (qown[j] >= 0) insert(((u64)bh << 32) | bl, qown[j]);
                     }
                 }
 #pragma unroll
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             int n_oth = 0;
             if (quick) {
 #pragma unroll
-                for (int j = 0; j < KM; j++) if (j < k && lane == j) { hx = qown[j]; h_own = true; }
+                for (int j = 0; j < KM; j++) if (j < k && lane == j && qown[j] >= 0) { hx = qown[j]; h_own = true; }
 #pragma unroll
                 for (int j = 0; j < KM; j++) {
                     if (j < n_out) {

@@ -299,3 +299,33 @@ def test_unsupported_is_refused(planner):
     with pytest.raises(hip.BlanceError) as e:
         planner.plan(fp)
     assert e.value.status == -2
+
+
+def test_widest_clusters_8192_nodes(planner):
+    """The register-resident workgroup pass at its widest (k_pass_seq<1024, 8>: 8,192 node names): hierarchy
+    states it has to walk itself (two rules for the state, or the sequential engine), and a flat weighted
+    rebalance beyond k_pass_tree's 4,096 names."""
+    from blance_amd import abi
+    c = synth.config_case(3, P=1200, N=8192)
+    fp = synth.case_to_flat(c)
+    _same(planner.plan(fp), _oracle(fp), "config 3 shape at 8192 nodes")
+    seq = hip.Planner(device_id=0, engine=abi.ENGINE_SEQUENTIAL)
+    _same(seq.plan(fp), _oracle(fp), "sequential engine at 8192 nodes")
+    seq.close()
+    c["hierarchyRules"] = {"replica": [{"includeLevel": 2, "excludeLevel": 1}, {"includeLevel": 3, "excludeLevel": 2}]}
+    fp2 = synth.case_to_flat(c)
+    _same(planner.plan(fp2), _oracle(fp2), "two rules for the state at 8192 nodes")
+    _rebalance(planner, P=2500, N=8192, hierarchy=False)
+
+
+def test_region_chain_envelope_edges(planner):
+    """Passes just outside the region chains' envelope fall back to the exact workgroup pass: k = 5 copies,
+    regions of more than 512 leaves."""
+    c = synth.config_case(3, P=2500, N=1024)
+    c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": 5}}
+    fp = synth.case_to_flat(c)
+    _same(planner.plan(fp), _oracle(fp), "k = 5")
+    c = synth.config_case(3, P=2500, N=1400)
+    c["nodeHierarchy"] = synth.hierarchy_names(1400, rack=16, racks_per_zone=40, zones_per_dc=2)   # zones of 640 leaves
+    fp = synth.case_to_flat(c)
+    _same(planner.plan(fp), _oracle(fp), "regions of 640 leaves")
