@@ -37,6 +37,7 @@ namespace blance {
 // ============================================================================
 constexpr int kTreeMaxNodes = 4096;      // LDS budget: 25 bytes per node + tables
 constexpr int kWalkCap = 24;
+constexpr int kMvW = 17;                 // words per mover record in LDS (14 used; odd stride: no bank conflicts)
 
 #ifndef BLANCE_SIMT_EMU
 // nodeToNodeCounts is read and bumped (atomics, at L2) by this wave all along the pass: its loads bypass L1
@@ -115,7 +116,9 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
     u64* stkB = (u64*)(ffT + kFfTab);                // [kWalkCap] leaves taken out of the tree during a walk
     int* stkN = (int*)(stkB + kWalkCap);             // [kWalkCap]
     int* ntL = stkN + kWalkCap;                      // [NXp] folded mode: the shared row of nodeToNodeCounts
-    unsigned char* flL = (unsigned char*)(ntL + NXp);   // [NXp] 1: in nodesNext, 2: has a weight
+    int* mvL = ntL + NXp;                            // [64][kMvW] what lane j learnt about step j (the lean general step reads it)
+    int* outS = mvL + 64 * kMvW;                     // [64][OW] the batch's outputs: written out, and their rows bumped, per batch
+    unsigned char* flL = (unsigned char*)(outS + 64 * (KM + 1));   // [NXp] 1: in nodesNext, 2: has a weight
 
     for (int i = lane; i < kLpTab; i += 64) lpT[i] = NP > 0 ? (double)i / (double)NP : 0.0;
     for (int i = lane; i < kFfTab; i += 64) ffT[i] = NP > 0 ? (0.001 * (double)i) / (double)NP : 0.0;
@@ -160,9 +163,29 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
         }
     };
     rebuild_tree();
+    // the two smallest leaves (root = the smallest), recomputed after every change of the tree
     bool root_valid = false;
-    u64 rootB = ~0ull;
-    int root_n = INT_MAX;
+    u64 rootB = ~0ull, t2B = ~0ull;
+    int root_n = INT_MAX, t2n = INT_MAX;
+    auto compute_top2 = [&]() {
+        const TreeMin m = wave_min_u64_lane(gm_hi, gm_lo);
+        rootB = ((u64)m.hi << 32) | m.lo;
+        root_n = __builtin_amdgcn_readlane(gm_n, m.lane);
+        t2B = ~0ull; t2n = INT_MAX;
+        if (root_n != INT_MAX) {                     // the runner-up: another group's minimum, or the rest of the root's group
+            u64 v = gB[m.lane * 64 + lane];
+            if (lane == (root_n & 63)) v = ~0ull;
+            const TreeMin s2 = wave_min_u64_lane((unsigned)(v >> 32), (unsigned)v);
+            unsigned wh = gm_hi, wl = gm_lo;
+            if (lane == m.lane) { wh = s2.hi; wl = s2.lo; }
+            const TreeMin m2 = wave_min_u64_lane(wh, wl);
+            if ((m2.hi & m2.lo) != kKeyNoneV) {
+                t2B = ((u64)m2.hi << 32) | m2.lo;
+                t2n = m2.lane == m.lane ? m.lane * 64 + s2.lane : __builtin_amdgcn_readlane(gm_n, m2.lane);
+            }
+        }
+        root_valid = true;
+    };
 
     // which word of the record's state lists this lane looks at when a general step decodes its record
     const int slot_t = lane / SW, slot_ix = lane - slot_t * SW;
@@ -170,9 +193,10 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
     const bool slot_higher = slot_ok && ((q.higher_mask >> slot_t) & 1);
 
     long long n_bulk = 0;
+    int pf_v = 0, pf_n = -1, pf_f = -1;              // lanes 2, 3: the nodeToNodeCounts entries of the two smallest leaves, fetched for step pf_f
     PH_DECL;
 #ifdef BLANCE_PHASE_PROF
-    long long pc_general = 0, pc_taken = 0, pc_miss = 0, pc_batches = 0, pc_scans = 0, pc_short = 0, pc_stay = 0, pc_reorder = 0, pc_half = 0;
+    long long pc_general = 0, pc_taken = 0, pc_miss = 0, pc_batches = 0, pc_scans = 0, pc_short = 0, pc_stay = 0, pc_reorder = 0, pc_half = 0, pc_lean = 0, pc_lean_try = 0, pc_hit1 = 0, pc_hit2 = 0, pc_need2 = 0;
 #define PC(x) (x)++
 #else
 #define PC(x)
@@ -330,53 +354,189 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
 #pragma unroll
             for (int j = 0; j < KM; j++) if (j == k - 1) { lastB = sK[j]; lastN = sortv[j]; }
         }
+        if constexpr (KM == 2) {
+            int* mv = mvL + lane * kMvW;
+            mv[0] = wj; mv[1] = row;
+            mv[2] = ownv[0]; mv[3] = ownv[1];
+            mv[4] = (int)oKh[0]; mv[5] = (int)oKl[0]; mv[6] = (int)oKh[1]; mv[7] = (int)oKl[1];
+            mv[8] = hv[0]; mv[9] = hv[1];
+#pragma unroll
+            for (int e = 0; e < KO; e++) mv[10 + e] = ov[e];
+        }
         BLANCE_WAVE_SYNC();
 
         PH(3);
         // ---- the batch in order: validated runs at once, the other steps one by one
+        pf_f = -1;                                   // prefetched entries are tagged with a lane of THIS batch
+        // Inside a batch the steps only write LDS: their outputs are staged in outS, and the bumps of nodeToNodeCounts
+        // (plan.go:238-245) wait there too -- no step reads an entry an earlier step of the batch bumps, except the
+        // "dirty" ones (same row as an earlier lane), which get the pending bumps flushed first.  So the only global
+        // memory operations between two steps are the prefetches, and waiting for one never waits for a store.
+        int bumped_upto = 0;                         // steps [0, bumped_upto) of the batch have their rows bumped
+        const int OWs = q.OW;
+        auto flush_bumps = [&](int upto) {
+            if (NP > 0 && lane >= bumped_upto && lane < upto) {
+                const int n = outS[lane * OWs] & 0xffff;
+                for (int j = 0; j < n; j++) {
+                    const int x = outS[lane * OWs + 1 + j];
+                    if (x >= 0 && x < N) atomicAdd(q.ntn + (size_t)row * N + x, 1);
+                }
+            }
+            bumped_upto = upto > bumped_upto ? upto : bumped_upto;
+        };
         int cur = 0;
         while (cur < B) {
             PH(11);
-            if (!root_valid) {
-                const TreeMin m = wave_min_u64_lane(gm_hi, gm_lo);
-                rootB = ((u64)m.hi << 32) | m.lo;
-                root_n = __builtin_amdgcn_readlane(gm_n, m.lane);
-                root_valid = true;
-            }
+            if (!root_valid) compute_top2();
             const bool fail = sfail || dirty || fold >= 0 || !key_less(lastB, lastN, rootB, root_n);
             const u64 fm = __ballot(act && fail) & (~0ull << cur);
             const int f = fm ? __ffsll((long long)fm) - 1 : B;
             if (lane >= cur && lane < f) {          // certain stays: plan.go:299-301 leaves everything as it is
-                int* o = q.out + (size_t)(oi + lane) * q.OW;
+                int* o = outS + lane * OWs;
                 o[0] = k;
 #pragma unroll
-                for (int j = 0; j < KM; j++) {
-                    if (j < k) {
-                        o[1 + j] = sortv[j];
-                        if (NP > 0) atomicAdd(q.ntn + (size_t)row * N + ownv[j], 1);   // plan.go:238-245
-                    }
-                }
+                for (int j = 0; j < KM; j++) if (j < k) o[1 + j] = sortv[j];
             }
             n_bulk += f - cur;
             PH(4);
             if (f >= B) break;
             PC(pc_general);
+            const int rowf = __builtin_amdgcn_readlane(row, f);
+            // nodeToNodeCounts entries of the two smallest leaves.  Lanes 4 and 5 fetched, a step ago, the entries
+            // of the lane that was expected to fail next for the runner-up and the root of then -- one of them is
+            // the root of now unless a lowered node got in front; what is missing is fetched now (lanes 2, 3), and
+            // the same is started for the lane after this one.
+            int nt1 = 0, nt2 = 0;                     // root's / runner-up's entry when hit1 / hit2
+            bool hit1 = false, hit2 = false;
+            if (NP > 0 && fold < 0) {
+                const int e4n = __builtin_amdgcn_readlane(pf_n, 4), e4f = __builtin_amdgcn_readlane(pf_f, 4);
+                const int e5n = __builtin_amdgcn_readlane(pf_n, 5), e5f = __builtin_amdgcn_readlane(pf_f, 5);
+                const int e4v = __builtin_amdgcn_readlane(pf_v, 4), e5v = __builtin_amdgcn_readlane(pf_v, 5);
+                if (e4f == f && e4n == root_n) { hit1 = true; nt1 = e4v; }
+                else if (e5f == f && e5n == root_n) { hit1 = true; nt1 = e5v; }
+                if (e4f == f && e4n == t2n) { hit2 = true; nt2 = e4v; }
+                else if (e5f == f && e5n == t2n) { hit2 = true; nt2 = e5v; }
+                const u64 fm2 = fm & (fm - 1);                         // the lane expected to fail after this one
+                const int f2 = fm2 ? __ffsll((long long)fm2) - 1 : -1;
+                const int rowf2 = __builtin_amdgcn_readlane(row, f2 < 0 ? 0 : f2);
+                int my_node = -1, my_row = 0, my_f = -1;
+                if (lane == 2 && !hit1) { my_node = root_n; my_row = rowf; my_f = f; }
+                if (lane == 3 && !hit2) { my_node = t2n; my_row = rowf; my_f = f; }
+                if (lane == 4 && f2 >= 0) { my_node = t2n; my_row = rowf2; my_f = f2; }
+                if (lane == 5 && f2 >= 0) { my_node = root_n; my_row = rowf2; my_f = f2; }
+                if (my_node >= 0 && my_node < N) {
+                    pf_v = BLANCE_LD_COHERENT(q.ntn + (size_t)my_row * N + my_node);
+                    pf_n = my_node; pf_f = my_f;
+                }
+            }
 
             // ================= general step for lane f's record =================
             const int* rf = recS + f * RW;
-            const int rowf = __builtin_amdgcn_readlane(row, f);
             const int w = __builtin_amdgcn_readlane(wj, f);
             const bool dirty_f = __builtin_amdgcn_readlane(dirty ? 1 : 0, f) != 0;
+            if (dirty_f && fold < 0 && NP > 0) {   // this step reads a row an earlier step of the batch bumps
+                flush_bumps(f);
+                BLANCE_AGENT_FENCE();
+            }
             const bool quick = !no_short && !dirty_f && __builtin_amdgcn_readlane((simple && !stale) ? 1 : 0, f) != 0;
             // the first candidate's nodeToNodeCounts entry: in flight while the step is decoded
-            const bool pre_ok = NP > 0 && fold < 0 && !dirty_f && root_n < N;
-            int pre_nt = 0;
-            if (pre_ok) pre_nt = BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + root_n);
+            const bool pre_ok = NP > 0 && fold < 0 && !dirty_f && root_n < N;   // the root's entry: fetched above
             const int pre_n = root_n;
 
+            // what either form of the general step leaves behind: the chosen nodes, and per lane a node whose counters changed
+            int bN[KM];
+#pragma unroll
+            for (int j = 0; j < KM; j++) bN[j] = INT_MAX;
+            int n_out = 0;
+            int hx = -1;
+            bool changed = false;
+            bool lean_done = false;
+            if constexpr (KM == 2) {
+                // ---- the lean general step (k <= 2, a "short" step): the four contenders -- the partition's own nodes with
+                // the exact keys of its validating lane, and the two smallest leaves -- sit in lanes 0..3, are sorted by a
+                // three-stage compare-exchange network inside the quad, and commit lane-parallel.  Nothing unexamined can
+                // get in as long as the k-th taken is not after the runner-up in (g, position) order; otherwise, and for
+                // promotions / demotions, the general code below takes the step.
+                if (quick && fold < 0) {
+                    PC(pc_lean_try);
+                    const int* mv = mvL + f * kMvW;
+                    const int own0 = mv[2], own1 = mv[3], h0 = mv[8], h1 = mv[9];
+                    int s_n = INT_MAX, s_org = lane & 3;
+                    u64 s_b = ~0ull;
+                    if (lane < 2) {
+                        const int n = mv[2 + lane];
+                        if (n >= 0) { s_n = n; s_b = ((u64)(unsigned)mv[4 + 2 * lane] << 32) | (unsigned)mv[5 + 2 * lane]; }
+                    } else if (lane < 4) {
+                        const int c = lane == 2 ? root_n : t2n;
+                        const u64 cB = lane == 2 ? rootB : t2B;
+                        if (c != INT_MAX && c != own0 && c != own1 && c != h0 && c != h1) {     // plan.go:142-156
+                            // the root with its exact score; the runner-up with its lower bound g for now: its entry
+                            // is only waited for if that gets it taken
+                            int nt = 0;
+                            if (NP > 0 && lane == 2) nt = hit1 ? nt1 : pf_v;
+                            if (NP > 0 && lane == 3 && hit2) nt = nt2;
+                            s_n = c;
+                            s_b = nt ? sortable_bits(tree_score(cntL[c], nt, totL[c], (flL[c] >> 1) & 1, wL[c], NP, 0.0,
+                                                                q.booster_kind, lpT, ffT)) : cB;
+                        }
+                    }
+#define BLANCE_CEX(CTRL, LOWER)                                                                                  \
+                    {                                                                                            \
+                        const unsigned ph_ = (unsigned)dpp_mov<CTRL>((int)(unsigned)(s_b >> 32));                \
+                        const unsigned pl_ = (unsigned)dpp_mov<CTRL>((int)(unsigned)s_b);                        \
+                        const int pn_ = dpp_mov<CTRL>(s_n), po_ = dpp_mov<CTRL>(s_org);                          \
+                        const u64 pb_ = ((u64)ph_ << 32) | pl_;                                                  \
+                        const bool mine_ = key_less(s_b, s_n, pb_, pn_), theirs_ = key_less(pb_, pn_, s_b, s_n); \
+                        if ((LOWER) ? theirs_ : mine_) { s_b = pb_; s_n = pn_; s_org = po_; }                    \
+                    }
+#ifdef BLANCE_PHASE_PROF
+                    if (hit1) pc_hit1++;
+                    if (hit2) pc_hit2++;
+#endif
+                    BLANCE_CEX(0xB1, !(lane & 1))     // (0,1) (2,3): the lower lane keeps the smaller
+                    BLANCE_CEX(0x4E, !(lane & 2))     // (0,2) (1,3)
+                    BLANCE_CEX(0xD8, lane == 1)       // (1,2)
+#undef BLANCE_CEX
+                    const bool taken = lane < k && s_n != INT_MAX;
+                    bool ok = __popcll(__ballot(taken)) == k;
+                    const u64 kB = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(s_b >> 32), k - 1) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)s_b, k - 1);
+                    const int kn = __builtin_amdgcn_readlane(s_n, k - 1);
+                    if (t2n != INT_MAX && key_less(t2B, t2n, kB, kn)) ok = false;      // a leaf after the runner-up could get in
+                    // taken from the tree but held by the partition in another state: promoted / demoted
+                    bool prom = false;
+#pragma unroll
+                    for (int e = 0; e < KO; e++) prom = prom || (taken && s_org >= 2 && (mv[10 + e] & 0xffff) == s_n);
+                    if (__ballot(prom)) ok = false;
+#ifdef BLANCE_PHASE_PROF
+                    if (__ballot(taken && s_org == 3)) pc_need2++;
+#endif
+                    if (ok && NP > 0 && !hit2 && __ballot(taken && s_org == 3)) {
+                        // the runner-up was taken on its lower bound: exact only if its entry is 0 (else the general code)
+                        if (__builtin_amdgcn_readlane(pf_v, 3) != 0) ok = false;
+                    }
+                    if (ok) {
+                        PC(pc_lean);
+                        const bool valid = lane < 4 && s_n != INT_MAX;
+                        const bool enter = valid && lane < k && s_org >= 2, leave = valid && lane >= k && s_org < 2;
+                        changed = enter || leave;
+                        if (changed) {               // plan.go:290-301
+                            const int ds = enter ? w : -w;
+                            hx = s_n;
+                            cntL[s_n] += ds;
+                            totL[s_n] += ds;
+                            gB[s_n] = leaf_key(s_n);
+                        }
+#pragma unroll
+                        for (int j = 0; j < KM; j++) if (j < k) bN[j] = __builtin_amdgcn_readlane(s_n, j);
+                        n_out = k;
+                        lean_done = true;
+                    }
+                }
+            }
+            if (!lean_done) {
             // the k best (score, position) so far; wave uniform, ascending
             u64 bB[KM];
-            int bN[KM];
 #pragma unroll
             for (int j = 0; j < KM; j++) { bB[j] = ~0ull; bN[j] = INT_MAX; }
             auto insert = [&](u64 b, int n) {
@@ -493,7 +653,8 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                     int nt = 0;
                     if (NP > 0 && fold < 0) {                                  // folded: the leaf is the exact score
                         const bool pref = pre_ok && pre_n == c;
-                        nt = pref ? uni(pre_nt) : uni(BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + c));
+                        nt = pref ? (hit1 ? nt1 : __builtin_amdgcn_readlane(pf_v, 2))
+                                  : uni(BLANCE_LD_COHERENT(q.ntn + (size_t)rowf * N + c));
 #ifdef BLANCE_PHASE_PROF
                         if (!pref) pc_miss++;
 #endif
@@ -567,7 +728,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                     for (int j = 0; j < KM; j++) if (j == pick) { bB[j] = ((u64)mh << 32) | ml; bN[j] = (int)mn; }
                 }
             }
-            int n_out = 0;
+            n_out = 0;
 #pragma unroll
             for (int j = 0; j < KM; j++) if (j < k && bN[j] != INT_MAX) n_out++;
             PH(8);
@@ -592,7 +753,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             // partition that holds it.  Own nodes are settled by lanes of their own (quick: lanes
             // 0..k-1, else the lanes that hold them), newly chosen ones by lanes 60..63 (never list
             // words: records are at most 64 words).
-            int hx = -1;                             // the node this lane settles
+            hx = -1;                                 // the node this lane settles
             bool h_own = false, h_chosen = false;
             int n_oth = 0;
             if (quick) {
@@ -639,19 +800,14 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             }
             const int ds = (h_chosen ? w : 0) - (h_own ? w : 0);
             const bool bumped = fold >= 0 && h_chosen;      // folded: the chosen node's row entry is part of its leaf
-            const bool changed = hx >= 0 && (ds != 0 || n_oth > 0 || bumped);
+            changed = hx >= 0 && (ds != 0 || n_oth > 0 || bumped);
             if (changed) {
                 cntL[hx] += ds;
                 totL[hx] += ds - w * n_oth;
                 if (bumped) ntL[hx] += 1;
                 gB[hx] = leaf_key(hx);
             }
-            if (NP > 0 && lane < n_out) {
-                int cn = INT_MAX;
-#pragma unroll
-                for (int j = 0; j < KM; j++) if (j == lane) cn = bN[j];
-                if (cn < N) atomicAdd(q.ntn + (size_t)rowf * N + cn, 1);         // plan.go:238-245
-            }
+            }   // !lean_done
             BLANCE_WAVE_SYNC();
             PH(9);
             // the tree: a smaller leaf replaces its group's minimum in place, a grown minimum needs a scan
@@ -686,7 +842,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
                         if (((q.higher_mask >> t) & 1) && (rf[kRecHead + t * SW] >> 16) != kListAbsent) any_higher_key = true;
                     is_nil = !any_higher_key;
                 }
-                int* o = q.out + (size_t)(oi + f) * q.OW;
+                int* o = outS + f * OWs;             // (its row is bumped with the batch's, plan.go:238-245)
                 o[0] = n_out | (is_nil << 16);
 #pragma unroll
                 for (int j = 0; j < KM; j++) if (j < k) o[1 + j] = j < n_out ? bN[j] : -1;
@@ -700,11 +856,16 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
             cur = f + 1;
             PH(10);
         }
+        // ---- the batch's outputs, and the bumps still pending
+        BLANCE_WAVE_SYNC();
+        flush_bumps(B);
+        for (int idx = lane; idx < B * OWs; idx += 64) q.out[(size_t)oi * OWs + idx] = outS[idx];
+        BLANCE_WAVE_SYNC();
     }
 #ifdef BLANCE_PHASE_PROF
     if (lane == 0) {
-        printf("[tree] k %d steps %d batches %lld general %lld (short %lld: stays %lld reorders %lld one-kept %lld) walked %lld prefetch-miss %lld commit-scans %lld\n",
-               k, q.end - q.beg, pc_batches, pc_general, pc_short, pc_stay, pc_reorder, pc_half, pc_taken, pc_miss, pc_scans);
+        printf("[tree] k %d steps %d batches %lld general %lld (lean %lld of %lld tried, root hit %lld, runner-up hit %lld needed %lld; short %lld: stays %lld reorders %lld one-kept %lld) walked %lld prefetch-miss %lld commit-scans %lld\n",
+               k, q.end - q.beg, pc_batches, pc_general, pc_lean, pc_lean_try, pc_hit1, pc_hit2, pc_need2, pc_short, pc_stay, pc_reorder, pc_half, pc_taken, pc_miss, pc_scans);
         for (int i_ = 0; i_ < 12; i_++) printf("[tree phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
     }
 #endif
@@ -720,7 +881,7 @@ __global__ __launch_bounds__(64) void k_pass_tree(PassParams q) {
 static inline size_t tree_lds_bytes(int NX, int RW) {
     const size_t NXp = (size_t)((NX + 63) / 64) * 64;
     return NXp * (8 + 4 + 4 + 4 + 4 + 1) + sizeof(int32_t) * (size_t)(64 * RW) +
-           sizeof(double) * (kLpTab + kFfTab) + (size_t)kWalkCap * 12 + 64;
+           sizeof(double) * (kLpTab + kFfTab) + (size_t)kWalkCap * 12 + sizeof(int32_t) * 64 * (kMvW + 5) + 64;
 }
 
 }  // namespace blance

@@ -329,3 +329,25 @@ def test_region_chain_envelope_edges(planner):
     c["nodeHierarchy"] = synth.hierarchy_names(1400, rack=16, racks_per_zone=40, zones_per_dc=2)   # zones of 640 leaves
     fp = synth.case_to_flat(c)
     _same(planner.plan(fp), _oracle(fp), "regions of 640 leaves")
+
+
+def test_rccl_communicator_of_one_rank(planner):
+    """blance_comm_unique_id / blance_comm_init_rccl on the device (librccl.so bound at run time): a communicator of one
+    rank, after which plans run as before (the multi-rank exchange is covered on gloo by tests/test_dist.py)."""
+    class OneRank:
+        @staticmethod
+        def get_rank():
+            return 0
+
+        @staticmethod
+        def get_world_size():
+            return 1
+
+        @staticmethod
+        def broadcast_object_list(box, src=0):
+            return None
+    pl = hip.Planner(device_id=0)
+    assert pl.comm_init_rccl(OneRank) == 1
+    fp = synth.config_flat(3, P=4096, N=512)
+    _same(pl.plan(fp), _oracle(fp), "after comm_init_rccl")
+    pl.close()
