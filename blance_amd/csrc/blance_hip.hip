@@ -544,11 +544,11 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
         RESERVE(f_row_count, sizeof(int32_t) * ((size_t)NX + 2));
         RESERVE(f_m, sizeof(int32_t) * ((size_t)N + 2));
         RESERVE(f_moff, sizeof(int32_t) * ((size_t)N + 2));
-        RESERVE(f_keys_a, sizeof(unsigned long long) * ((size_t)P + 1));
-        RESERVE(f_keys_b, sizeof(unsigned long long) * ((size_t)P + 1));
-        RESERVE(f_vals_a, sizeof(int32_t) * ((size_t)P + 1));
-        RESERVE(f_vals_b, sizeof(int32_t) * ((size_t)P + 1));
-        RESERVE(f_hist, sizeof(int32_t) * 256 * ((size_t)cdiv(P, kSortTile) + 1));
+        RESERVE(f_keys_a, sizeof(unsigned long long) * (2 * (size_t)P + 4));      // fresh runs: up to 2 picks per step, + 1
+        RESERVE(f_keys_b, sizeof(unsigned long long) * (2 * (size_t)P + 4));
+        RESERVE(f_vals_a, sizeof(int32_t) * (2 * (size_t)P + 4));
+        RESERVE(f_vals_b, sizeof(int32_t) * (2 * (size_t)P + 4));
+        RESERVE(f_hist, sizeof(int32_t) * 256 * ((size_t)cdiv(2 * (int64_t)P + 4, kSortTile) + 1));
     }
     HIPTRY(hipStreamSynchronize(c->stream));
     // the caller's arrays are not retained: drop the host pointers
@@ -704,8 +704,10 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             int R = first_nonfresh - pos;
             // NumPartitions == 0: steps may each exclude one node (k_fresh_excl); one more element of the
             // exclusion-free sequence is needed then
-            const bool excl = q.NP == 0 && q.higher_mask != 0;      // the top priority state excludes nothing
-            const int RS = excl ? R + 1 : R;
+            // NumPartitions == 0: steps may exclude one node each and take two (k_fresh_excl); the exclusion-free
+            // sequence then needs k elements per step and one more
+            const bool excl = q.NP == 0 && (q.higher_mask != 0 || q.k == 2);
+            const int RS = excl ? q.k * R + q.k : R;
             BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, RS, c->f_m.as<int32_t>(),
                           c->f_moff.as<int32_t>());
             BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
@@ -724,7 +726,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
                 if (bad < R) R = bad;               // a pending node came up again: the run ends before that step
                 picks = c->f_vals_b.as<int32_t>();
                 HIPTRY(hipMemsetAsync(c->f_m.p, 0, sizeof(int32_t) * ((size_t)q.N + 1), sm));
-                if (R > 0) BLANCE_LAUNCH_NOSYNC(k_fresh_hist, cdiv(R, 256), 256, 0, sm, R, picks, c->f_m.as<int32_t>());
+                if (R > 0) BLANCE_LAUNCH_NOSYNC(k_fresh_hist, cdiv((int64_t)q.k * R, 256), 256, 0, sm, q.k * R, picks, c->f_m.as<int32_t>());
             }
             if (R > 0) {
                 BLANCE_LAUNCH_NOSYNC(k_fresh_commit_steps, cdiv(R, 256), 256, 0, sm, fq, pos, R, picks);
@@ -1188,7 +1190,9 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
             int e;
             c->pass_kind.resize(n_pass + 1);
-            if (c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && k == 1 && P >= c->chain_min_parts) {
+            // the flat bulk driver: k = 1, and the first sweep of a fresh plan (NumPartitions == 0) with k = 2
+            if (c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && (k == 1 || (k == 2 && NP == 0)) &&
+                P >= c->chain_min_parts) {
                 c->pass_kind[n_pass] = 1;
                 e = run_flat_pass(c, q, scal, &launches, &batched, flat_chain);
             } else if (flat_chain) {

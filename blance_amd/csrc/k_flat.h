@@ -113,8 +113,8 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
         // NumPartitions == 0 no score term depends on the partition (plan.go:638,:647), so one node
         // in a higher priority state -- just not a candidate, plan.go:146-154 -- is allowed too
         // (k_fresh_excl), and the top priority node does not matter.
-        bool fresh = q.k == 1 && w > 0 && w == r0[1] &&
-                     (q.NP == 0 ? (all_len == high_len && high_len <= 1) : (all_len == 0 && top < 0));
+        bool fresh = w > 0 && w == r0[1] &&
+                     (q.NP == 0 ? (q.k <= 2 && all_len == high_len && high_len <= 1) : (q.k == 1 && all_len == 0 && top < 0));
         scan_note_first(in_range && !fresh, oi, &q.scan[1]);
     }
     // ---- certain stay?
@@ -311,12 +311,12 @@ __global__ void k_fresh_emit(FlatParams q, int beg, int R, const int32_t* m_off,
     vals[e] = n;
 }
 
-__global__ void k_fresh_commit_steps(FlatParams q, int beg, int R, const int32_t* sorted_nodes) {
+__global__ void k_fresh_commit_steps(FlatParams q, int beg, int R, const int32_t* picks /* [k R], k per step */) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R) return;
     int* out = q.out + (size_t)(beg + j) * q.OW;
-    out[0] = 1;
-    out[1] = sorted_nodes[j];
+    out[0] = q.k;
+    for (int c = 0; c < q.k; c++) out[1 + c] = picks[(size_t)j * q.k + c];
 }
 
 __global__ void k_fresh_commit_nodes(FlatParams q, int beg, const int32_t* m, int32_t* cnt) {
@@ -351,20 +351,36 @@ __device__ __forceinline__ int fresh_excluded(const FlatParams& q, int oi) {
     return -1;
 }
 
-__global__ __launch_bounds__(1024) void k_fresh_excl(FlatParams q, int beg, int R, const int32_t* S /* [R + 1] */,
-                                                     int32_t* picks /* [R] */, int32_t* first_bad) {
+// k = 1 or 2 picks per step.  With two, a step takes the two smallest of the CURRENT scores (plan.go:171-172, :228-229:
+// no commit between its picks), which are the next two elements of S as long as those are two different nodes; a
+// pending node x goes first (its score is the smallest there is), then the rest from S.  Step function, with
+// B_t = (e_t among the k elements the step would take from S), C_t = (e_t among the k - 1 it would take after x):
+//   b' = b ? (A_t ? 1 : C_t) : B_t.
+struct FreshStep { unsigned A, B, C; };
+__device__ __forceinline__ FreshStep fresh_step(int k, const int32_t* S, int t, int e, int eprev) {
+    FreshStep r;
+    const int base = k * t;
+    r.A = (e >= 0 && e == eprev) ? 1u : 0u;
+    r.B = (e >= 0 && (S[base] == e || (k == 2 && S[base + 1] == e))) ? 1u : 0u;
+    r.C = (e >= 0 && k == 2 && S[base + 1] == e) ? 1u : 0u;
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_fresh_excl(FlatParams q, int beg, int R, const int32_t* S /* [k R + k] */,
+                                                     int32_t* picks /* [k R] */, int32_t* first_bad) {
     BLANCE_DYN_LDS(lds);
     unsigned char* comp = (unsigned char*)lds;       // [1024] composite step function of a thread's slice: bit x = f(x)
     unsigned char* tmp = comp + 1024;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, k = q.k;
     const int per = (R + 1023) / 1024;
     const int t0 = tid * per < R ? tid * per : R, t1 = t0 + per < R ? t0 + per : R;
     unsigned f = 2;                                  // identity: f(0) = 0, f(1) = 1
     int eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
     for (int t = t0; t < t1; t++) {
         const int e = fresh_excluded(q, beg + t);
-        const unsigned A = (e >= 0 && e == eprev) ? 1u : 0u, B = (e >= 0 && S[t] == e) ? 1u : 0u;
-        const unsigned f0 = (f & 1) ? A : B, f1 = (f & 2) ? A : B;
+        const FreshStep st = fresh_step(k, S, t, e, eprev);
+        const unsigned g0 = st.B, g1 = st.A ? 1u : st.C;                 // the step's function: g(0), g(1)
+        const unsigned f0 = (f & 1) ? g1 : g0, f1 = (f & 2) ? g1 : g0;
         f = f0 | (f1 << 1);
         eprev = e;
     }
@@ -386,10 +402,29 @@ __global__ __launch_bounds__(1024) void k_fresh_excl(FlatParams q, int beg, int 
     eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
     for (int t = t0; t < t1; t++) {
         const int e = fresh_excluded(q, beg + t);
-        const unsigned A = (e >= 0 && e == eprev) ? 1u : 0u, B = (e >= 0 && S[t] == e) ? 1u : 0u;
-        const unsigned nb = b ? A : B;               // pending after this step: then it is e
-        picks[t] = b ? (A ? S[t + 1] : eprev) : (B ? S[t + 1] : S[t]);
-        if (nb && S[t + 1] == e) atomicMin(first_bad, t);
+        const FreshStep st = fresh_step(k, S, t, e, eprev);
+        const int base = k * t;
+        int p0, p1 = -1;
+        if (!b) {                                    // the next k elements of S, skipping e
+            int i = base;
+            if (S[i] == e && e >= 0) i++;
+            p0 = S[i++];
+            if (k == 2) { if (S[i] == e && e >= 0) i++; p1 = S[i]; }
+        } else if (!st.A) {                          // the pending node, then k - 1 elements of S, skipping e
+            p0 = eprev;
+            if (k == 2) { int i = base + 1; if (S[i] == e && e >= 0) i++; p1 = S[i]; }
+        } else {                                     // still excluded: k elements of S behind it
+            p0 = S[base + 1];
+            if (k == 2) p1 = S[base + 2];
+        }
+        const unsigned nb = b ? (st.A ? 1u : st.C) : st.B;               // e pending after this step
+        picks[base] = p0;
+        if (k == 2) picks[base + 1] = p1;
+        // not what the reference does if the pending node comes up again, or a node would be taken twice in a step
+        bool bad = e >= 0 && (p0 == e || p1 == e);
+        if (k == 2 && p0 == p1) bad = true;
+        if (nb && S[base + k] == e) bad = true;
+        if (bad) atomicMin(first_bad, t);
         b = nb;
         eprev = e;
     }

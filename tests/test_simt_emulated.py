@@ -276,3 +276,38 @@ def test_fresh_runs_with_excluded_node(emu_lib):
         bulk += got.struct.steps_batched > 0
     assert bulk > 20
     pl.close()
+
+
+def test_fresh_runs_two_picks(emu_lib):
+    """k_fresh_excl with two picks per step: a fresh plan's pass for a state with two copies (NumPartitions == 0),
+    with and without an excluded node per step; few nodes force cuts (a node would be taken twice in a step, the
+    pending node comes up again)."""
+    import random
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=1)
+    bulk = 0
+    for seed in range(36):
+        rnd = random.Random(1000 + seed)
+        n = rnd.choice([2, 3, 4, 7, 30, 70])
+        nodes = ["n%02d" % i for i in range(n)]
+        if seed % 2:
+            model = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": 2}}
+        else:
+            model = {"primary": {"priority": 0, "constraints": 2}}
+        hot = nodes[: rnd.choice([1, 2, n])]
+        parts = {}
+        for i in range(rnd.choice([30, 200, 600])):
+            nbs = {}
+            if seed % 4 == 1:
+                nbs = {"primary": [rnd.choice(hot) if rnd.random() < 0.7 else rnd.choice(nodes)]}
+            parts[str(i)] = {"name": str(i), "nodesByState": nbs}
+        kw = {}
+        if seed % 3 == 0:
+            kw["node_weights"] = {x: rnd.choice([1, 2, 3]) for x in nodes}
+        fp = problem.build_problem({}, parts, nodes, [], nodes, model, max_iterations=rnd.choice([1, 10]), **kw)
+        got, want = pl.plan(fp), _oracle(fp)
+        assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
+        bulk += got.struct.steps_batched > 0
+    assert bulk > 20
+    for fp in (synth.config5_initial(400, 60), synth.config5_initial(900, 30)):
+        assert pl.plan(fp).digest() == _oracle(fp).digest()
+    pl.close()
