@@ -92,7 +92,7 @@ def test_region_chains(emu_lib):
     verified-stay speculation) and its escape to the sequential pass."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     chains = 0
-    for seed in range(0, 130):               # the GPU suite walks 800 of these (tests/test_hip_parity.py)
+    for seed in range(0, 100):               # the GPU suite walks 800 of these (tests/test_hip_parity.py)
         try:
             fp = build_from_case(random_regular_case(seed))
         except problem.Unsupported:
@@ -100,7 +100,7 @@ def test_region_chains(emu_lib):
         got = pl.plan(fp)
         assert got.digest() == _oracle(fp).digest(), seed
         chains += got.struct.steps_batched > 0
-    assert chains >= 60
+    assert chains >= 45
     fp = synth.config_flat(3, P=160, N=200)
     got = pl.plan(fp)
     assert got.digest() == _oracle(fp).digest() and got.struct.steps_batched > 0
@@ -110,7 +110,7 @@ def test_region_chains(emu_lib):
 def test_random_instances_bulk_engines(emu_lib):
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     n = bulk = 0
-    for seed in range(600, 860):             # the GPU suite walks 1,000 of these
+    for seed in range(600, 780):             # the GPU suite walks 1,000 of these
         try:
             fp = build_from_case(random_case(seed))
         except problem.Unsupported:
@@ -119,7 +119,7 @@ def test_random_instances_bulk_engines(emu_lib):
         assert got.digest() == _oracle(fp).digest(), seed
         n += 1
         bulk += got.struct.steps_batched > 0
-    assert n > 170 and bulk > 40
+    assert n > 115 and bulk > 25
     pl.close()
 
 
@@ -295,7 +295,7 @@ def test_fresh_runs_two_picks(emu_lib):
             model = {"primary": {"priority": 0, "constraints": 2}}
         hot = nodes[: rnd.choice([1, 2, n])]
         parts = {}
-        for i in range(rnd.choice([30, 200, 600])):
+        for i in range(rnd.choice([30, 200, 400])):
             nbs = {}
             if seed % 4 == 1:
                 nbs = {"primary": [rnd.choice(hot) if rnd.random() < 0.7 else rnd.choice(nodes)]}

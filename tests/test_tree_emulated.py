@@ -50,7 +50,7 @@ def test_random_instances_tree(emu_lib):
 def test_random_instances_tree_dense_and_bulk(emu_lib):
     pd = hip.Planner(lib_path=emu_lib, tree="dense")
     pb = hip.Planner(lib_path=emu_lib, tree="long", chain_min_parts=1)
-    for seed in range(500, 760):
+    for seed in range(500, 640):             # (the GPU suite walks 300 of these in dense mode)
         try:
             fp = build_from_case(random_case(seed))
         except problem.Unsupported:
@@ -99,8 +99,9 @@ def test_folded_row_tree(emu_lib):
     unfolds when a mixed batch comes."""
     for mode in ("on", "dense", "long"):
         pl = hip.Planner(lib_path=emu_lib, tree=mode)
-        _rebalance(pl, 500, 40, remove_frac=0.5, add_frac=0.3)
-        _rebalance(pl, 260, 130, remove_frac=0.6, add_frac=0.1)
+        _rebalance(pl, 400, 40, remove_frac=0.5, add_frac=0.3)
+        if mode == "on":
+            _rebalance(pl, 260, 130, remove_frac=0.6, add_frac=0.1)
         pl.close()
 
 
