@@ -72,6 +72,8 @@ struct blance_ctx {
     blance_comm comm{0, 1, nullptr, nullptr};
     void* rccl_comm = nullptr;      // ncclComm_t of blance_comm_init_rccl
     DevBuf cnt_base, cnt_delta;
+    DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
+    DevBuf mv[11];                  // blance_calc_moves: inputs, per-partition slices, offsets, compacted outputs (kept between calls)
     int64_t comm_calls = 0, comm_bytes = 0;
 
     // host copy of the small parts of the problem
@@ -132,6 +134,8 @@ struct blance_ctx {
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
         rule_regions.clear();
         cnt_base.release(); cnt_delta.release();
+        dl_off.release(); dl_nodes.release();
+        for (DevBuf& b : mv) b.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &n_ev, &chain_oi,
                           &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
                           &fl_one, &fl_reglo, &fl_reghi, &f_tot, &f_g,
@@ -1289,8 +1293,6 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     const int M = h.n_states, P = h.n_parts, L = c->L;
     const size_t PM = (size_t)P * M;
     if (c->n_warnings > res->warn_capacity) return fail(BLANCE_ERR_CAPACITY, "warn_capacity too small");
-    std::vector<int32_t> live(PM * L + 1), len(PM + 1);
-    std::vector<uint8_t> kind(PM + 1);
     if (c->iterations == 0) {
         // MaxIterationsPerPlan <= 0: planNextMapEx returns (nil, nil) -- nothing to report (plan.go:32-58)
         for (size_t i = 0; i <= PM; i++) res->out_off[i] = 0;
@@ -1300,26 +1302,29 @@ static int download_locked(blance_ctx* c, blance_result* res) {
         res->converged = 0;
         return BLANCE_OK;
     }
+    res->out_off[0] = 0;
     if (PM) {
-        HIPTRY(hipMemcpyAsync(live.data(), c->live.p, sizeof(int32_t) * PM * L, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipMemcpyAsync(len.data(), c->live_len.p, sizeof(int32_t) * PM, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipMemcpyAsync(kind.data(), c->live_kind.p, PM, hipMemcpyDeviceToHost, c->stream));
+        // the CSR is made on the device (lengths -> exclusive scan -> gather) and lands in the caller's arrays directly
+        DevProblem d = dev_problem(c);
+        RESERVE(dl_off, sizeof(int32_t) * (PM + 2));
+        BLANCE_LAUNCH_NOSYNC(k_result_len, cdiv((int64_t)PM + 1, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>());
+        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, (int)PM + 1, c->dl_off.as<int32_t>());
+        int32_t total = 0;
+        HIPTRY(hipMemcpyAsync(&total, c->dl_off.as<int32_t>() + PM, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipStreamSynchronize(c->stream));
+        if (total > res->out_capacity) return fail(BLANCE_ERR_CAPACITY, "out_capacity too small");
+        RESERVE(dl_nodes, sizeof(int32_t) * ((size_t)total + 1));
+        BLANCE_LAUNCH_NOSYNC(k_result_gather, cdiv((int64_t)PM, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>(),
+                             c->dl_nodes.as<int32_t>());
+        HIPTRY(hipMemcpyAsync(res->out_off, c->dl_off.p, sizeof(int32_t) * (PM + 1), hipMemcpyDeviceToHost, c->stream));
+        if (total) HIPTRY(hipMemcpyAsync(res->out_nodes, c->dl_nodes.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipMemcpyAsync(res->out_kind, c->live_kind.p, PM, hipMemcpyDeviceToHost, c->stream));
     }
     if (c->n_warnings) {
         HIPTRY(hipMemcpyAsync(res->warn_part, c->warn_part.p, sizeof(int32_t) * (size_t)c->n_warnings, hipMemcpyDeviceToHost, c->stream));
         HIPTRY(hipMemcpyAsync(res->warn_state, c->warn_state.p, sizeof(int32_t) * (size_t)c->n_warnings, hipMemcpyDeviceToHost, c->stream));
     }
     HIPTRY(hipStreamSynchronize(c->stream));
-    int64_t off = 0;
-    for (size_t idx = 0; idx < PM; idx++) {
-        res->out_off[idx] = (int32_t)off;
-        res->out_kind[idx] = kind[idx];
-        int n = kind[idx] == BLANCE_LIST_ABSENT ? 0 : len[idx];
-        if (off + n > res->out_capacity) return fail(BLANCE_ERR_CAPACITY, "out_capacity too small");
-        for (int i = 0; i < n; i++) res->out_nodes[off + i] = live[idx * L + i];
-        off += n;
-    }
-    res->out_off[PM] = (int32_t)off;
     res->n_warnings = c->n_warnings;
     res->iterations = c->iterations;
     res->converged = c->converged;
@@ -1352,8 +1357,8 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
     if (cap > res->capacity) return fail(BLANCE_ERR_CAPACITY, "moves capacity too small");
     if (cap > (int64_t)INT32_MAX) return fail(BLANCE_ERR_UNSUPPORTED, "more than 2^31 list entries");
     HIPTRY(hipSetDevice(c->device));
-    DevBuf boff, bnod, eoff, enod, onode, ostate, okind, nmov;
-    struct Free { DevBuf* b[8]; ~Free() { for (DevBuf* x : b) x->release(); } } fr{{&boff, &bnod, &eoff, &enod, &onode, &ostate, &okind, &nmov}};
+    DevBuf &boff = c->mv[0], &bnod = c->mv[1], &eoff = c->mv[2], &enod = c->mv[3], &onode = c->mv[4], &ostate = c->mv[5],
+           &okind = c->mv[6], &nmov = c->mv[7], &cnode = c->mv[8], &cstate = c->mv[9], &ckind = c->mv[10];
     auto up = [&](DevBuf& b, const int32_t* src, size_t n) -> int {
         if (b.reserve(sizeof(int32_t) * (n + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
         if (n) HIPTRY(hipMemcpyAsync(b.p, src, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
@@ -1361,11 +1366,17 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
     };
     int e;
     if ((e = up(boff, pb->beg_off, PS + 1)) || (e = up(bnod, pb->beg_nodes, (size_t)nb)) ||
-        (e = up(eoff, pb->end_off, PS + 1)) || (e = up(enod, pb->end_nodes, (size_t)ne)))
+        (e = up(eoff, pb->end_off, PS + 1)) || (e = up(enod, pb->end_nodes, (size_t)ne))) {
+        (void)hipStreamSynchronize(c->stream);
         return e;
+    }
     if (onode.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || ostate.reserve(sizeof(int32_t) * ((size_t)cap + 1)) ||
-        okind.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || nmov.reserve(sizeof(int32_t) * ((size_t)P + 1)))
+        okind.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || nmov.reserve(sizeof(int32_t) * ((size_t)P + 2)) ||
+        cnode.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || cstate.reserve(sizeof(int32_t) * ((size_t)cap + 1)) ||
+        ckind.reserve(sizeof(int32_t) * ((size_t)cap + 1))) {
+        (void)hipStreamSynchronize(c->stream);
         return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    }
     MovesParams q;
     q.P = P; q.M = M; q.favor_min_nodes = pb->favor_min_nodes;
     q.beg_off = boff.as<int32_t>(); q.beg_nodes = bnod.as<int32_t>();
@@ -1373,29 +1384,30 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
     q.op_node = onode.as<int32_t>(); q.op_state = ostate.as<int32_t>(); q.op_kind = okind.as<int32_t>();
     q.n_moves = nmov.as<int32_t>();
     HIPTRY(hipEventRecord(c->ev0, c->stream));
-    if (P > 0) BLANCE_LAUNCH_NOSYNC(k_calc_moves, cdiv(P, 256), 256, 0, c->stream, q);
+    res->op_off[0] = 0;
+    if (P > 0) {
+        // per-partition slices -> offsets (exclusive scan of the move counts) -> packed on the device
+        HIPTRY(hipMemsetAsync(nmov.as<int32_t>() + P, 0, sizeof(int32_t), c->stream));
+        BLANCE_LAUNCH_NOSYNC(k_calc_moves, cdiv(P, 256), 256, 0, c->stream, q);
+        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, P + 1, nmov.as<int32_t>());
+        BLANCE_LAUNCH_NOSYNC(k_moves_compact, cdiv(P, 256), 256, 0, c->stream, q, nmov.as<int32_t>(), cnode.as<int32_t>(),
+                             cstate.as<int32_t>(), ckind.as<int32_t>());
+    }
     HIPTRY(hipEventRecord(c->ev1, c->stream));
-    std::vector<int32_t> hn((size_t)P + 1), hnode((size_t)cap + 1), hstate((size_t)cap + 1), hkind((size_t)cap + 1);
-    if (P > 0) HIPTRY(hipMemcpyAsync(hn.data(), nmov.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
-    if (cap > 0) {
-        HIPTRY(hipMemcpyAsync(hnode.data(), onode.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipMemcpyAsync(hstate.data(), ostate.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipMemcpyAsync(hkind.data(), okind.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, c->stream));
+    if (P > 0) {
+        HIPTRY(hipMemcpyAsync(res->op_off, nmov.p, sizeof(int32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipStreamSynchronize(c->stream));
+        const int64_t total = res->op_off[P];
+        if (total > 0) {
+            HIPTRY(hipMemcpyAsync(res->op_node, cnode.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, c->stream));
+            HIPTRY(hipMemcpyAsync(res->op_state, cstate.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, c->stream));
+            HIPTRY(hipMemcpyAsync(res->op_kind, ckind.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, c->stream));
+        }
     }
     HIPTRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     res->device_ms = ms;
-    int64_t off = 0;
-    for (int p = 0; p < P; p++) {                       // compact the per-partition slices
-        res->op_off[p] = (int32_t)off;
-        const int64_t src = (int64_t)pb->beg_off[(size_t)p * (M + 1)] + pb->end_off[(size_t)p * (M + 1)];
-        for (int i = 0; i < hn[p]; i++) {
-            res->op_node[off] = hnode[src + i]; res->op_state[off] = hstate[src + i]; res->op_kind[off] = hkind[src + i];
-            off++;
-        }
-    }
-    res->op_off[P] = (int32_t)off;
     return BLANCE_OK;
     });
 }

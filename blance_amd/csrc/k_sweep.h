@@ -344,6 +344,20 @@ __global__ void k_vec_add(int n, const int32_t* a, const int32_t* b, int32_t* ou
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// ---- result as CSR on the device (blance_download): list lengths -> exclusive scan -> gather
+__global__ void k_result_len(DevProblem d, int32_t* len_out /* [P*M + 1] */) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int PM = d.P * d.M;
+    if (idx > PM) return;
+    len_out[idx] = (idx < PM && d.live_kind[idx] != kListAbsent) ? d.live_len[idx] : 0;
+}
+__global__ void k_result_gather(DevProblem d, const int32_t* off, int32_t* nodes_out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    const int n = off[idx + 1] - off[idx];
+    for (int i = 0; i < n; i++) nodes_out[off[idx] + i] = d.live[(size_t)idx * d.L + i];
+}
+
 // Step records in pass order: what findBestNodes needs to know about its partition.
 __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
                          const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
@@ -497,6 +511,16 @@ __global__ void k_calc_moves(MovesParams q) {
         }
     }
     q.n_moves[p] = n;
+}
+
+// the moves of every partition packed back to back (op_off = exclusive scan of n_moves)
+__global__ void k_moves_compact(MovesParams q, const int32_t* op_off, int32_t* node_out, int32_t* state_out, int32_t* kind_out) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= q.P) return;
+    const int src = q.beg_off[p * (q.M + 1)] + q.end_off[p * (q.M + 1)], dst = op_off[p], n = op_off[p + 1] - dst;
+    for (int i = 0; i < n; i++) {
+        node_out[dst + i] = q.op_node[src + i]; state_out[dst + i] = q.op_state[src + i]; kind_out[dst + i] = q.op_kind[src + i];
+    }
 }
 
 // ---- plan quality (blance_plan_stats_get): countStateNodes (plan.go:374-399) over the RESULT map
