@@ -13,7 +13,7 @@ def test_go_shim_matches_header():
 
 
 def test_go_files_are_balanced():
-    for name in ("intern.go", "plan_hip.go", "moves_hip.go", "hip_test.go"):
+    for name in ("intern.go", "plan_hip.go", "moves_hip.go", "hip_test.go", "orchestrate_index.go"):
         text = open(os.path.join(ROOT, "go", "blance", name)).read()
         assert text.count("{") == text.count("}"), name
         assert text.count("(") == text.count(")"), name
