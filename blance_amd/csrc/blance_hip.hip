@@ -88,7 +88,6 @@ struct blance_ctx {
     bool tree_dense = false;        // test knob (& 4): k_pass_tree scores every node in every general step
     bool tree_always = false;       // test knob (& 8): k_pass_tree even when a k_pass_seq workgroup size is forced
     bool tree_long = false;         // test knob (& 16): k_pass_tree decodes the record in every general step
-    bool no_win = false;            // test knob (& 32): never k_pass_win (the lean form of k_pass_tree)
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -288,7 +287,6 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->tree_dense = opt && (opt->reserved[2] & 4);
     c->tree_always = opt && (opt->reserved[2] & 8);
     c->tree_long = opt && (opt->reserved[2] & 16);
-    c->no_win = opt && (opt->reserved[2] & 32);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -570,35 +568,6 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
 // of a step does not grow with the cluster; everything else: the workgroup pass k_pass_seq.
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     const bool tree = !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always);
-    if (tree && !c->no_win && !c->tree_dense && !c->tree_long && q.k <= 2 && q.NP > 0 && q.rule_begin == q.rule_end &&
-        q.NX >= 1 && q.NX <= 4096) {
-        // The lean kernel walks until a step needs the general code; that batch goes to k_pass_tree and the lean
-        // kernel takes over again behind it.  A pass that keeps stopping is finished by k_pass_tree.
-        int32_t* stop_dev = c->scalars.as<int32_t>() + 11;
-        int pos = q.beg, stops = 0;
-        bool lean = true;
-        while (pos < q.end && lean) {
-            PassParams w = q;
-            w.beg = pos; w.stop_at = stop_dev;
-            if (!launch_pass_win(c->stream, w)) { lean = false; break; }
-            int32_t stop = 0;
-            HIPTRY(hipMemcpyAsync(&stop, stop_dev, sizeof stop, hipMemcpyDeviceToHost, c->stream));
-            HIPTRY(hipStreamSynchronize(c->stream));
-            if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_win state %d steps [%d, %d) stopped at %d\n", q.s, pos, q.end, stop);
-            if (stop >= q.end) return 0;
-            PassParams g = q;
-            g.beg = stop; g.end = stop + 64 < q.end ? stop + 64 : q.end;
-            if (!launch_pass_tree(c->stream, g, 0)) return fail(BLANCE_ERR_DEVICE, "k_pass_tree refused a pass k_pass_win took");
-            pos = g.end;
-            stops++;
-            if (stops >= 32 && (pos - q.beg) / stops < 256) lean = false;      // too few steps per stop to pay for the round trips
-        }
-        if (pos >= q.end) return 0;
-        PassParams rest = q;
-        rest.beg = pos;
-        if (launch_pass_tree(c->stream, rest, 0)) return 0;
-        return fail(BLANCE_ERR_DEVICE, "k_pass_tree refused a pass");
-    }
     if (tree && launch_pass_tree(c->stream, q, (c->tree_dense ? 1 : 0) | (c->tree_long ? 2 : 0))) {
         if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
         return 0;

@@ -31,9 +31,6 @@ namespace blance {
 int launch_pass_seq(hipStream_t stream, PassParams q, int force_threads, bool allow_spec);
 // k_pass_tree (tu_tree.hip): false when the pass is outside its envelope (nothing launched)
 bool launch_pass_tree(hipStream_t stream, PassParams q, int knobs);
-// k_pass_win (tu_tree.hip): the lean form for k <= 2, NumPartitions > 0; runs until a step needs the general code
-// (*q.stop_at = that step, or q.end); false when the pass is outside its envelope (nothing launched)
-bool launch_pass_win(hipStream_t stream, PassParams q);
 // k_pass_chain (tu_chain.hip): one wave64 per region; false when the shape has no variant
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
 // k_pass_chain_blank (tu_chain.hip): the lean first-sweep kernel

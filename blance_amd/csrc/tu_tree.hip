@@ -1,7 +1,6 @@
 // Translation unit of k_pass_tree: flat passes on one wave64 with bound-ordered candidates.
 #include "dev_prelude.h"
 #include "k_pass_tree.h"
-#include "k_pass_win.h"
 
 namespace blance {
 
@@ -12,16 +11,6 @@ bool launch_pass_tree(hipStream_t stream, PassParams q, int knobs) {
     q.spec = ((knobs & 1) ? 2 : 0) | ((knobs & 2) ? 4 : 0);   // test knobs: dense general steps, no short general steps
     if (q.k <= 2) { auto kern = k_pass_tree<2>; BLANCE_LAUNCH(kern, 1, 64, lds, stream, q); }
     else { auto kern = k_pass_tree<4>; BLANCE_LAUNCH(kern, 1, 64, lds, stream, q); }
-    return true;
-}
-
-// k_pass_win: flat passes with k <= 2 and NumPartitions > 0; stops where a step needs the general code
-bool launch_pass_win(hipStream_t stream, PassParams q) {
-    if (q.rule_begin < q.rule_end || q.NX > kTreeMaxNodes || q.NX < 1 || q.k < 1 || q.k > 2 || q.NP <= 0 || !q.stop_at) return false;
-    const size_t lds = win_lds_bytes(q.NX, q.RW);
-    if (lds > 160 * 1024) return false;
-    auto kern = k_pass_win<2>;
-    BLANCE_LAUNCH(kern, 1, 64, lds, stream, q);
     return true;
 }
 

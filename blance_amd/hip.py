@@ -86,9 +86,8 @@ class Planner:
         # test knobs: 1 = k_pass_seq without verified stays; k_pass_tree (flat passes): 2 = never,
         # 4 = every general step scores all nodes, 8 = also when a k_pass_seq workgroup size is forced,
         # 16 = every general step decodes its record (none served from the validating lane's registers)
-        # 32 = never k_pass_win (the lean form of k_pass_tree for k <= 2, NumPartitions > 0)
         opt.reserved[2] = (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
-                                                          "dense-long": 4 | 8 | 16, "nowin": 8 | 32}[tree]
+                                                          "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))
         self._h = h
