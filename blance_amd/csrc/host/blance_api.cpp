@@ -21,6 +21,7 @@ namespace blance {
 
 int MaxIterationsPerPlan = 10;                 // plan.go:21
 Booster NodeScoreBooster = Booster::None;      // plan.go:693
+bool CustomNodeSorterIsDefault = true;         // plan.go:580
 
 namespace {
 
@@ -436,6 +437,9 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
                           const StringList& nodesToAdd, const PartitionModel& model,
                           const PlanNextMapOptions& options) {
     PlanOutcome out;
+    // callbacks of the caller's language cannot run on the device: the shim leaves such calls to plan.go
+    if (!CustomNodeSorterIsDefault) { out.why = "CustomNodeSorter is not the default sorter (plan.go:580)"; return out; }
+    if (NodeScoreBooster == Booster::Other) { out.why = "NodeScoreBooster is an arbitrary callback (plan.go:693)"; return out; }
     Flat f;
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) {

@@ -46,8 +46,9 @@ struct PlanNextMapOptions {                                           // api.go:
 
 // package-level knobs of the reference (plan.go:21, :693)
 extern int MaxIterationsPerPlan;
-enum class Booster { None = 0, Cbgt = 1 };   // control_test.go:19-26 is the only booster known in the wild
-extern Booster NodeScoreBooster;
+enum class Booster { None = 0, Cbgt = 1, Other = 2 };   // control_test.go:19-26 is the only booster known in the wild;
+extern Booster NodeScoreBooster;                        // Other: some callback of the caller's -- not handled (plan.go:693)
+extern bool CustomNodeSorterIsDefault;                  // plan.go:580; false: a caller's sorter -- not handled
 
 using Warnings = std::map<std::string, std::vector<std::string>>;
 

@@ -239,7 +239,11 @@ int main(int argc, char** argv) {
                 }
             }
         }
-        NodeScoreBooster = line() == "cbgt" ? Booster::Cbgt : Booster::None;
+        {
+            const std::string b = line();      // "", "cbgt", "other" (an arbitrary callback), "sorter" (a custom node sorter)
+            NodeScoreBooster = b == "cbgt" ? Booster::Cbgt : (b == "other" ? Booster::Other : Booster::None);
+            CustomNodeSorterIsDefault = b != "sorter";
+        }
         PlanOutcome r = PlanNextMapEx(lib, &prev, assign, nodesAll, rm, add, model, o);
         std::cout << (ci ? "," : "") << "{\"handled\":" << (r.handled ? "true" : "false") << ",\"why\":" << q(r.why)
                   << ",\"iterations\":" << r.iterations << ",\"converged\":" << (r.converged ? "true" : "false")

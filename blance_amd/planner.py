@@ -10,6 +10,11 @@ planner there).
 from . import hip, problem
 
 MaxIterationsPerPlan = 10            # plan.go:21
+# plan.go:580: the hook that replaces the node sorter.  Anything but None (the default sorter) is a
+# callback of the caller's language and cannot run on the device: PlanNextMapEx refuses (the Go shim
+# runs plan.go then).  plan.go:693 NodeScoreBooster: only the cbgt booster (control_test.go:19-26) is
+# built in -- pass booster="cbgt"; any other callable is refused the same way.
+CustomNodeSorter = None
 
 
 class Partition:
@@ -73,6 +78,10 @@ def PlanNextMapEx(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToA
     """api.go:147-157.  Returns (nextMap, warnings); mutates prevMap and
     partitionsToAssign the way planNextMapEx does (plan.go:49-52)."""
     options = options or PlanNextMapOptions()
+    if CustomNodeSorter is not None:
+        raise problem.Unsupported("CustomNodeSorter is not the default sorter (plan.go:580)")
+    if booster is not None and booster != "cbgt":
+        raise problem.Unsupported("NodeScoreBooster is an arbitrary callback (plan.go:693)")
     fp = problem.build_problem(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model,
                                options.ModelStateConstraints, options.PartitionWeights,
                                options.StateStickiness, options.NodeWeights, options.NodeHierarchy,

@@ -134,7 +134,9 @@ def test_cpp_mirror_refuses_what_python_refuses():
     bad = [dict(base, nodesAll=["a", "a"]),
            dict(base, partitionsToAssign={"0": {"name": "0", "nodesByState": {"dead": ["a"]}}}),
            dict(base, model={"a": {"priority": 1, "constraints": 1}, "b": {"priority": 0, "constraints": 1}}),
-           dict(base, partitionsToAssign={"0": {"name": "zero", "nodesByState": {}}})]
+           dict(base, partitionsToAssign={"0": {"name": "zero", "nodesByState": {}}}),
+           dict(base, booster="other"),          # a NodeScoreBooster that is not the cbgt one (plan.go:693)
+           dict(base, booster="sorter")]         # a CustomNodeSorter (plan.go:580)
     for got in run_cli(build_emu(), bad):
         assert not got["handled"] and got["why"]
 

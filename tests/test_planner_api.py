@@ -73,3 +73,15 @@ def test_unsupported_inputs_raise():
     with pytest.raises(problem.Unsupported):
         problem.build_problem({}, {"0": {"name": "0", "nodesByState": {}}}, ["a", "a"], [], [],
                               {"primary": {"priority": 0, "constraints": 1}})
+
+
+def test_callbacks_of_the_caller_are_refused(monkeypatch):
+    """plan.go:580 CustomNodeSorter and plan.go:693 NodeScoreBooster are hooks in the caller's language:
+    the device path refuses them before touching the library (the Go shim runs plan.go for such calls)."""
+    args = ({}, {"0": {"name": "0", "nodesByState": {}}}, ["a", "b"], [], [],
+            {"primary": {"priority": 0, "constraints": 1}})
+    with pytest.raises(problem.Unsupported):
+        planner.PlanNextMapEx(*args, booster=lambda w, s: s)
+    monkeypatch.setattr(planner, "CustomNodeSorter", lambda *a: None)
+    with pytest.raises(problem.Unsupported):
+        planner.PlanNextMapEx(*args)
