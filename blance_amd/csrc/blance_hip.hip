@@ -19,8 +19,6 @@
 #ifdef BLANCE_SIMT_EMU          /* the emulator build is one translation unit */
 #include "tu_seq.hip"
 #include "tu_tree.hip"
-#include "tu_par.hip"
-#include "tu_pool.hip"
 #include "tu_chain.hip"
 #endif
 
@@ -90,8 +88,6 @@ struct blance_ctx {
     bool tree_dense = false;        // test knob (& 4): k_pass_tree scores every node in every general step
     bool tree_always = false;       // test knob (& 8): k_pass_tree even when a k_pass_seq workgroup size is forced
     bool tree_long = false;         // test knob (& 16): k_pass_tree decodes the record in every general step
-    bool no_par = false;            // test knob (& 32): never k_pass_par (the steps of a batch resolved in parallel)
-    bool no_pool = false;           // test knob (& 64): never k_pass_pool (the pool of the smallest nodes in one wave's lanes)
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -291,8 +287,6 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->tree_dense = opt && (opt->reserved[2] & 4);
     c->tree_always = opt && (opt->reserved[2] & 8);
     c->tree_long = opt && (opt->reserved[2] & 16);
-    c->no_par = opt && (opt->reserved[2] & 32);
-    c->no_pool = opt && (opt->reserved[2] & 64);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -574,38 +568,6 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
 // of a step does not grow with the cluster; everything else: the workgroup pass k_pass_seq.
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     const bool tree = !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always);
-    if (tree && !(c->no_par && c->no_pool) && !c->tree_dense && !c->tree_long && q.k <= 2 && q.rule_begin == q.rule_end &&
-        q.NX >= 1 && q.NX <= 4096) {
-        // k_pass_par resolves the steps of a batch in parallel; where the steps depend on each other too much for that
-        // it hands the rest of the pass to k_pass_pool (the pool of the smallest nodes in the lanes of one wave, a
-        // general step a few wave minima).  Either stops where a step needs the general code: that batch goes to
-        // k_pass_tree and the kernel takes over again behind it.  A pass that keeps stopping is finished by k_pass_tree.
-        int32_t* stop_dev = c->scalars.as<int32_t>() + 3;
-        int pos = q.beg, stops = 0;
-        bool par = !c->no_par;
-        while (pos < q.end) {
-            PassParams w = q;
-            w.beg = pos; w.stop_at = stop_dev;
-            if (par ? !launch_pass_par(c->stream, w) : (c->no_pool || !launch_pass_pool(c->stream, w))) break;
-            int32_t stop = 0;
-            HIPTRY(hipMemcpyAsync(&stop, stop_dev, sizeof stop, hipMemcpyDeviceToHost, c->stream));
-            HIPTRY(hipStreamSynchronize(c->stream));
-            if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] %s state %d steps [%d, %d) stopped at %d\n", par ? "k_pass_par" : "k_pass_pool", q.s, pos, q.end, stop);
-            if (stop >= q.end) return 0;
-            if (stop < 0) { pos = -1 - stop; par = false; continue; }      // the steps depend on each other too much
-            PassParams g = q;
-            g.beg = stop; g.end = stop + 64 < q.end ? stop + 64 : q.end;
-            if (!launch_pass_tree(c->stream, g, 0)) return fail(BLANCE_ERR_DEVICE, "k_pass_tree refused a pass another kernel took");
-            pos = g.end;
-            stops++;
-            if (stops >= 32 && (pos - q.beg) / stops < 256) break;         // too few steps per stop to pay for the round trips
-        }
-        if (pos >= q.end) return 0;
-        PassParams rest = q;
-        rest.beg = pos;
-        if (launch_pass_tree(c->stream, rest, 0)) return 0;
-        return fail(BLANCE_ERR_DEVICE, "k_pass_tree refused a pass");
-    }
     if (tree && launch_pass_tree(c->stream, q, (c->tree_dense ? 1 : 0) | (c->tree_long ? 2 : 0))) {
         if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
         return 0;

@@ -46,7 +46,6 @@ struct PassParams {
     int32_t* warn_state;
     int32_t* warn_count;
     int32_t* err;                  // device error word (interval overflow ...)
-    int32_t* stop_at;              // k_pass_par: first step it did not do (that step needs the general code), or end
     int32_t spec;                  // try verified-stay speculation (flat passes; LDS mirrors sized by the host)
     long long* spec_count;         // steps committed as verified stays (statistics, may be null)
 };

@@ -31,11 +31,6 @@ namespace blance {
 int launch_pass_seq(hipStream_t stream, PassParams q, int force_threads, bool allow_spec);
 // k_pass_tree (tu_tree.hip): false when the pass is outside its envelope (nothing launched)
 bool launch_pass_tree(hipStream_t stream, PassParams q, int knobs);
-// k_pass_par (tu_par.hip): flat passes with k <= 2, the steps of a batch resolved in parallel; runs until a step needs
-// the general code (*q.stop_at = that step, or q.end); false when the pass is outside its envelope (nothing launched)
-bool launch_pass_par(hipStream_t stream, PassParams q);
-// k_pass_pool (tu_pool.hip): flat passes with k <= 2, the pool of the smallest nodes in the lanes of one wave64; same contract
-bool launch_pass_pool(hipStream_t stream, PassParams q);
 // k_pass_chain (tu_chain.hip): one wave64 per region; false when the shape has no variant
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
 // k_pass_chain_blank (tu_chain.hip): the lean first-sweep kernel

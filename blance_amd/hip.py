@@ -85,11 +85,9 @@ class Planner:
         opt.reserved[1] = chain_min_parts    # smallest pass run as region chains (0 = default)
         # test knobs: 1 = k_pass_seq without verified stays; k_pass_tree (flat passes): 2 = never,
         # 4 = every general step scores all nodes, 8 = also when a k_pass_seq workgroup size is forced,
-        # 16 = every general step decodes its record (none served from the validating lane's registers),
-        # 32 = never k_pass_par (flat passes with k <= 2: the steps of a batch resolved in parallel),
-        # 64 = never k_pass_pool (flat passes with k <= 2: the pool of the smallest nodes in one wave's lanes)
+        # 16 = every general step decodes its record (none served from the validating lane's registers)
         opt.reserved[2] = (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
-                                                          "dense-long": 4 | 8 | 16, "nopar": 8 | 32, "nopool": 8 | 64, "tree": 8 | 32 | 64}[tree]
+                                                          "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))
         self._h = h

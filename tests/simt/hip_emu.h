@@ -246,12 +246,6 @@ inline int atomicMin(int* p, int v) {
     return old;
 }
 
-inline unsigned atomicMax(unsigned* p, unsigned v) {
-    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-    return old;
-}
-
 // ---- host runtime: device memory is host memory -----------------------------
 typedef int hipError_t;
 typedef void* hipStream_t;

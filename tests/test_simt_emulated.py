@@ -17,8 +17,8 @@ EMU_SRC = os.path.join(HERE, "simt", "emu_lib.cpp")
 EMU_SO = os.path.join(HERE, "simt", "_build", "libblance_emu.so")
 DEPS = [EMU_SRC, os.path.join(HERE, "simt", "hip_emu.h"), os.path.join(HERE, "..", "include", "blance_hip.h")] + [
     os.path.join(HERE, "..", "blance_amd", "csrc", f) for f in
-    ("blance_hip.hip", "tu_seq.hip", "tu_tree.hip", "tu_par.hip", "tu_pool.hip", "tu_chain.hip", "dev_prelude.h", "blance_kernels.h", "dev_common.h",
-     "k_pass_seq.h", "k_pass_tree.h", "k_pass_par.h", "k_pass_pool.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h")]
+    ("blance_hip.hip", "tu_seq.hip", "tu_tree.hip", "tu_chain.hip", "dev_prelude.h", "blance_kernels.h", "dev_common.h",
+     "k_pass_seq.h", "k_pass_tree.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h")]
 
 
 def build_emu():

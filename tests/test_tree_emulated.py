@@ -19,7 +19,7 @@ def _oracle(fp):
     return loader.plan(fp)
 
 
-@pytest.mark.parametrize("mode", ["on", "nopar", "nopool", "tree", "dense", "long"])
+@pytest.mark.parametrize("mode", ["on", "dense", "long"])
 def test_golden_cases_tree(emu_lib, golden_cases, mode):
     for eager in (0, 1):                         # 1: the flat bulk driver hands sub-ranges to the tree kernel
         pl = hip.Planner(lib_path=emu_lib, tree=mode, chain_min_parts=eager)
@@ -87,7 +87,7 @@ def test_rebalance_tree(emu_lib):
     _rebalance(pl, 300, 100)
     _rebalance(pl, 300, 300, check_stays=True)
     pl.close()
-    for mode in ("nopar", "nopool", "tree", "dense", "long", "dense-long"):
+    for mode in ("dense", "long", "dense-long"):
         pl = hip.Planner(lib_path=emu_lib, tree=mode)
         _rebalance(pl, 120, 70)
         pl.close()
@@ -97,7 +97,7 @@ def test_folded_row_tree(emu_lib):
     """Half of the nodes removed: hundreds of consecutive steps have no top priority node and share the
     row "" of nodeToNodeCounts -- k_pass_tree folds that row into its leaves for whole batches, and
     unfolds when a mixed batch comes."""
-    for mode in ("on", "nopar", "nopool", "tree", "dense", "long"):
+    for mode in ("on", "dense", "long"):
         pl = hip.Planner(lib_path=emu_lib, tree=mode)
         _rebalance(pl, 400, 40, remove_frac=0.5, add_frac=0.3)
         if mode == "on":
@@ -115,7 +115,7 @@ def test_reduced_configs_tree(emu_lib):
 
 def test_edge_shapes_tree(emu_lib):
     cases = edge_cases()
-    for mode in ("on", "nopar", "nopool", "tree", "dense", "long"):
+    for mode in ("on", "dense", "long"):
         pl = hip.Planner(lib_path=emu_lib, tree=mode)
         for i, (a, k) in enumerate(cases):
             fp = problem.build_problem(*a, **k)

@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["blance_amd/csrc/k_pass_chain.h", "blance_amd/csrc/k_pass_tree.h", "blance_amd/csrc/k_pass_par.h", "blance_amd/csrc/k_pass_pool.h", "blance_amd/csrc/k_pass_seq.h",
+KERNEL_SOURCES = ["blance_amd/csrc/k_pass_chain.h", "blance_amd/csrc/k_pass_tree.h", "blance_amd/csrc/k_pass_seq.h",
                   "blance_amd/csrc/k_flat.h", "blance_amd/csrc/k_sweep.h", "blance_amd/csrc/dev_common.h",
                   "blance_amd/csrc/blance_hip.hip"]
 
