@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int kAbiVersion = 1;
+constexpr int kAbiVersion = 2;
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -673,9 +673,12 @@ int blance_wire_view_of(const blance_wire_map* m, blance_wire_view* v) {
 void blance_wire_free(blance_wire_map* m) { delete m; }
 void blance_wire_free_bytes(char* p) { free(p); }
 
-int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_len) {
-    if (!v || !out_json || !out_len) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
-    std::string o;
+}  // extern "C"
+
+namespace {
+
+// json.Marshal of the view into o (the view is checked first; nothing is read through a bad offset)
+int encode_to(const blance_wire_view* v, std::string& o) {
     if (v->map_is_nil) {
         o = "null";
     } else {
@@ -780,12 +783,79 @@ int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_l
         }
         o.push_back('}');
     }
+    return BLANCE_WIRE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_len) {
+    if (!v || !out_json || !out_len) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
+    std::string o;
+    const int st = encode_to(v, o);
+    if (st) return st;
     char* buf = (char*)malloc(o.size() + 1);
     if (!buf) return fail(BLANCE_WIRE_ERR_ARG, "out of memory");
     memcpy(buf, o.data(), o.size());
     buf[o.size()] = 0;
     *out_json = buf;
     *out_len = o.size();
+    return BLANCE_WIRE_OK;
+}
+
+int blance_wire_encode_into(const blance_wire_view* v, char* buf, size_t cap, size_t* need) {
+    if (!v || !need || (!buf && cap)) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
+    std::string o;
+    const int st = encode_to(v, o);
+    if (st) return st;
+    *need = o.size();
+    if (o.size() > cap) return fail(BLANCE_WIRE_ERR_SPACE, "the caller's buffer is too small (see *need)");
+    memcpy(buf, o.data(), o.size());
+    return BLANCE_WIRE_OK;
+}
+
+int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b, blance_wire_view* view) {
+    if (!b || !view) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
+    blance_wire_map* m = nullptr;
+    int st = blance_wire_decode(json, len, &m);
+    if (st) return st;
+    blance_wire_view v;
+    blance_wire_view_of(m, &v);
+    const int64_t kb = v.n_parts ? v.key_off[v.n_parts] : 0, nb = v.n_parts ? v.name_off[v.n_parts] : 0;
+    const int64_t sb = v.n_states ? v.state_off[v.n_states] : 0, db = v.n_nodes ? v.node_off[v.n_nodes] : 0;
+    const bool fits = b->cap_parts >= v.n_parts && b->cap_states >= v.n_states && b->cap_nodes >= v.n_nodes &&
+                      b->cap_entries >= v.n_entries && b->cap_node_refs >= v.n_node_refs && b->cap_key_bytes >= kb &&
+                      b->cap_name_bytes >= nb && b->cap_state_bytes >= sb && b->cap_node_bytes >= db;
+    const bool have = b->key_off && b->name_off && b->part_off && b->state_off && b->node_off && b->entry_off &&
+                      (!v.n_parts || (b->part_kind && (!kb || b->key_bytes) && (!nb || b->name_bytes))) &&
+                      (!sb || b->state_bytes) && (!db || b->node_bytes) &&
+                      (!v.n_entries || (b->entry_state && b->entry_kind)) && (!v.n_node_refs || b->entry_nodes);
+    // what the document needs, whether or not it fits
+    b->cap_parts = v.n_parts; b->cap_states = v.n_states; b->cap_nodes = v.n_nodes; b->cap_entries = v.n_entries;
+    b->cap_node_refs = v.n_node_refs; b->cap_key_bytes = kb; b->cap_name_bytes = nb; b->cap_state_bytes = sb; b->cap_node_bytes = db;
+    if (!fits) { blance_wire_free(m); return fail(BLANCE_WIRE_ERR_SPACE, "the caller's arrays are too small (sizes written to cap_*)"); }
+    if (!have) { blance_wire_free(m); return fail(BLANCE_WIRE_ERR_ARG, "null array in the buffers"); }
+    auto put = [](void* dst, const void* src, size_t n) { if (n) memcpy(dst, src, n); };
+    put(b->key_bytes, v.key_bytes, (size_t)kb);     put(b->key_off, v.key_off, sizeof(int64_t) * (size_t)(v.n_parts + 1));
+    put(b->name_bytes, v.name_bytes, (size_t)nb);   put(b->name_off, v.name_off, sizeof(int64_t) * (size_t)(v.n_parts + 1));
+    put(b->part_kind, v.part_kind, (size_t)v.n_parts);
+    put(b->part_off, v.part_off, sizeof(int64_t) * (size_t)(v.n_parts + 1));
+    put(b->state_bytes, v.state_bytes, (size_t)sb); put(b->state_off, v.state_off, sizeof(int64_t) * (size_t)(v.n_states + 1));
+    put(b->node_bytes, v.node_bytes, (size_t)db);   put(b->node_off, v.node_off, sizeof(int64_t) * (size_t)(v.n_nodes + 1));
+    put(b->entry_state, v.entry_state, sizeof(int32_t) * (size_t)v.n_entries);
+    put(b->entry_kind, v.entry_kind, (size_t)v.n_entries);
+    put(b->entry_off, v.entry_off, sizeof(int64_t) * (size_t)(v.n_entries + 1));
+    put(b->entry_nodes, v.entry_nodes, sizeof(int32_t) * (size_t)v.n_node_refs);
+    *view = v;
+    view->key_bytes = b->key_bytes;     view->key_off = b->key_off;
+    view->name_bytes = b->name_bytes;   view->name_off = b->name_off;
+    view->part_kind = b->part_kind;     view->part_off = b->part_off;
+    view->state_bytes = b->state_bytes; view->state_off = b->state_off;
+    view->node_bytes = b->node_bytes;   view->node_off = b->node_off;
+    view->entry_state = b->entry_state; view->entry_kind = b->entry_kind;
+    view->entry_off = b->entry_off;     view->entry_nodes = b->entry_nodes;
+    blance_wire_free(m);
     return BLANCE_WIRE_OK;
 }
 

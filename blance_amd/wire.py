@@ -13,7 +13,9 @@ import numpy as np
 ABSENT, NIL, LIST = 0, 1, 2
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libblance_wire.so")
 EXPORTS = ("blance_wire_decode", "blance_wire_view_of", "blance_wire_free", "blance_wire_encode",
-           "blance_wire_free_bytes", "blance_wire_last_error", "blance_wire_abi_version")
+           "blance_wire_free_bytes", "blance_wire_last_error", "blance_wire_abi_version",
+           "blance_wire_decode_into", "blance_wire_encode_into")
+ERR_SPACE = -4
 
 
 class View(C.Structure):
@@ -27,6 +29,14 @@ class View(C.Structure):
                 ("node_bytes", C.c_void_p), ("node_off", C.c_void_p),
                 ("entry_state", C.c_void_p), ("entry_kind", C.c_void_p),
                 ("entry_off", C.c_void_p), ("entry_nodes", C.c_void_p)]
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("cap_parts", "cap_states", "cap_nodes", "cap_entries", "cap_node_refs",
+                                          "cap_key_bytes", "cap_name_bytes", "cap_state_bytes", "cap_node_bytes")] + \
+               [(n, C.c_void_p) for n in ("key_bytes", "key_off", "name_bytes", "name_off", "part_kind", "part_off",
+                                          "state_bytes", "state_off", "node_bytes", "node_off",
+                                          "entry_state", "entry_kind", "entry_off", "entry_nodes")]
 
 
 class WireError(ValueError):
@@ -57,8 +67,12 @@ def load_library(path=None):
     lib.blance_wire_free_bytes.restype = None
     lib.blance_wire_free_bytes.argtypes = [C.c_void_p]
     lib.blance_wire_last_error.restype = C.c_char_p
+    lib.blance_wire_decode_into.restype = C.c_int
+    lib.blance_wire_decode_into.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Buffers), C.POINTER(View)]
+    lib.blance_wire_encode_into.restype = C.c_int
+    lib.blance_wire_encode_into.argtypes = [C.POINTER(View), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.blance_wire_abi_version.restype = C.c_int
-    if lib.blance_wire_abi_version() != 1:
+    if lib.blance_wire_abi_version() != 2:
         raise ImportError("blance_wire ABI version mismatch")
     _lib = lib
     return lib
@@ -148,6 +162,58 @@ class WireMap:
 
     def __del__(self):
         self.close()
+
+
+_BUF_FIELDS = (("key_bytes", "cap_key_bytes", np.uint8, 0), ("key_off", "cap_parts", np.int64, 1),
+               ("name_bytes", "cap_name_bytes", np.uint8, 0), ("name_off", "cap_parts", np.int64, 1),
+               ("part_kind", "cap_parts", np.uint8, 0), ("part_off", "cap_parts", np.int64, 1),
+               ("state_bytes", "cap_state_bytes", np.uint8, 0), ("state_off", "cap_states", np.int64, 1),
+               ("node_bytes", "cap_node_bytes", np.uint8, 0), ("node_off", "cap_nodes", np.int64, 1),
+               ("entry_state", "cap_entries", np.int32, 0), ("entry_kind", "cap_entries", np.uint8, 0),
+               ("entry_off", "cap_entries", np.int64, 1), ("entry_nodes", "cap_node_refs", np.int32, 0))
+
+
+def decode_into_numpy(data, caps=None, lib_path=None):
+    """The caller-owned form: numpy arrays of the caller (this function) are filled by blance_wire_decode_into.
+    caps: dict of capacities (default: small, so that the size report and the second call are exercised).
+    Returns (View, arrays, calls)."""
+    lib = load_library(lib_path)
+    if isinstance(data, str):
+        data = data.encode("utf-8")
+    b = Buffers()
+    for f, _ in Buffers._fields_[:9]:
+        setattr(b, f, (caps or {}).get(f, 0))
+    calls = 0
+    while True:
+        arrays = {}
+        for name, cap, dt, extra in _BUF_FIELDS:
+            arrays[name] = np.zeros(int(getattr(b, cap)) + extra, dtype=dt)
+            setattr(b, name, arrays[name].ctypes.data)
+        v = View()
+        st = lib.blance_wire_decode_into(data, len(data), C.byref(b), C.byref(v))
+        calls += 1
+        if st == ERR_SPACE and calls < 3:
+            continue                             # cap_* now hold what the document needs
+        if st:
+            raise WireError(st, lib.blance_wire_last_error().decode())
+        return v, arrays, calls
+
+
+def encode_into_numpy(view, cap=0, lib_path=None):
+    """The caller-owned form of encode: returns (bytes, calls)."""
+    lib = load_library(lib_path)
+    need = C.c_size_t()
+    calls = 0
+    while True:
+        buf = np.zeros(max(cap, 1), dtype=np.uint8)
+        st = lib.blance_wire_encode_into(C.byref(view), buf.ctypes.data, cap, C.byref(need))
+        calls += 1
+        if st == ERR_SPACE and calls < 3:
+            cap = need.value
+            continue
+        if st:
+            raise WireError(st, lib.blance_wire_last_error().decode())
+        return bytes(buf[:need.value]), calls
 
 
 def decode(data, lib_path=None):

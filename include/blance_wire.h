@@ -23,8 +23,12 @@
  * U+2028 / U+2029 as \u2028 / \u2029, control characters as \b \f \n \r \t or \u00XX,
  * invalid UTF-8 bytes as \ufffd.
  *
- * All arrays returned by the accessors are owned by the blance_wire_map and live until
- * blance_wire_free().  Lists are kept per (partition, state entry) in document order.
+ * Two forms of every direction.  Caller-owned (the planner ABI's rule, blance_hip.h): blance_wire_decode_into
+ * fills arrays the caller brought, blance_wire_encode_into a byte buffer of the caller's; a too small buffer is
+ * reported with the sizes needed and nothing of the library's crosses the boundary.  Handle-based (one pass, no
+ * size guess): blance_wire_decode returns a blance_wire_map whose arrays live until blance_wire_free(),
+ * blance_wire_encode bytes to release with blance_wire_free_bytes().  Lists are kept per (partition, state entry)
+ * in document order.
  */
 #ifndef BLANCE_WIRE_H
 #define BLANCE_WIRE_H
@@ -40,6 +44,7 @@ extern "C" {
 #define BLANCE_WIRE_ERR_SYNTAX (-1)   /* malformed JSON */
 #define BLANCE_WIRE_ERR_TYPE (-2)     /* a value of the wrong JSON type (UnmarshalTypeError) */
 #define BLANCE_WIRE_ERR_ARG (-3)
+#define BLANCE_WIRE_ERR_SPACE (-4)    /* a caller's buffer is too small; the sizes needed are reported */
 
 #define BLANCE_WIRE_ABSENT 0          /* same values as BLANCE_LIST_* of blance_hip.h */
 #define BLANCE_WIRE_NIL 1
@@ -76,6 +81,29 @@ void blance_wire_free(blance_wire_map* m);
  * blance_wire_free_bytes.  The view's arrays are the caller's. */
 int blance_wire_encode(const blance_wire_view* view, char** out_json, size_t* out_len);
 void blance_wire_free_bytes(char* p);
+
+/* Caller-owned storage for a decoded map: capacities (elements / bytes) in, the document's sizes out -- also when
+ * the call fails with BLANCE_WIRE_ERR_SPACE, so the second call fits.  Offset arrays hold one element more than
+ * their capacity says (n + 1 offsets).  A document of len bytes never needs more than len of anything. */
+typedef struct blance_wire_buffers {
+    int64_t cap_parts, cap_states, cap_nodes, cap_entries, cap_node_refs;
+    int64_t cap_key_bytes, cap_name_bytes, cap_state_bytes, cap_node_bytes;
+    char* key_bytes;   int64_t* key_off;
+    char* name_bytes;  int64_t* name_off;
+    uint8_t* part_kind;
+    int64_t* part_off;
+    char* state_bytes; int64_t* state_off;
+    char* node_bytes;  int64_t* node_off;
+    int32_t* entry_state;
+    uint8_t* entry_kind;
+    int64_t* entry_off;
+    int32_t* entry_nodes;
+} blance_wire_buffers;
+
+/* json.Unmarshal into the caller's arrays; *view then points into them. */
+int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* buffers, blance_wire_view* view);
+/* json.Marshal into the caller's buffer; *need = the document's length, also with BLANCE_WIRE_ERR_SPACE. */
+int blance_wire_encode_into(const blance_wire_view* view, char* buf, size_t cap, size_t* need);
 
 const char* blance_wire_last_error(void);   /* thread local, with the byte offset of a syntax error */
 int blance_wire_abi_version(void);

@@ -204,3 +204,31 @@ def test_large_map_round_trip():
     assert m.encode() == want
     assert json.loads(got) == pmap
     m.close()
+
+
+def test_caller_owned_forms_agree_with_the_handles(golden_cases):
+    """blance_wire_decode_into / blance_wire_encode_into (nothing of the library's crosses the boundary): same arrays
+    and same bytes as the handle-based calls; a too small buffer is answered with the sizes and the second call fits."""
+    docs = [b"null", b"{}", b'{"a":null}', b'{"0":{"name":"0","nodesByState":{"primary":["a","b"],"replica":null}}}']
+    for c in golden_cases[:40]:
+        for k in ("prevMap", "exp"):
+            if c.get(k) is not None:
+                docs.append(wire.encode(c[k]))
+    for doc in docs:
+        m = wire.decode(doc)
+        v, arrays, calls = wire.decode_into_numpy(doc)
+        assert calls <= 2
+        for f in ("map_is_nil", "n_parts", "n_states", "n_nodes", "n_entries", "n_node_refs"):
+            assert getattr(v, f) == getattr(m.view, f), f
+        assert list(arrays["part_kind"][:v.n_parts]) == list(m.part_kind)
+        assert list(arrays["entry_nodes"][:v.n_node_refs]) == list(m.entry_nodes)
+        assert list(arrays["entry_off"][:v.n_entries + 1]) == list(m.entry_off)
+        want = m.encode()
+        got, calls = wire.encode_into_numpy(v)                # from the caller's arrays into the caller's bytes
+        assert got == want and calls <= 2
+        got, calls = wire.encode_into_numpy(m.view, cap=len(want))
+        assert got == want and calls == 1
+        m.close()
+    with pytest.raises(wire.WireError) as e:
+        wire.decode_into_numpy(b'{"a":')
+    assert e.value.status == -1
