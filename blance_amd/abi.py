@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -218,8 +218,9 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class Comm(C.Structure):
-    """blance_comm: a caller-provided int32 sum all-reduce for a plan sharded over ranks."""
-    _fields_ = [("rank", C.c_int32), ("n_ranks", C.c_int32), ("allreduce_sum_i32", ALLREDUCE_FN), ("user", C.c_void_p)]
+    """blance_comm: an embedder's collectives (int32 sum all-reduce, all-gather) for a plan sharded over ranks."""
+    _fields_ = [("rank", C.c_int32), ("n_ranks", C.c_int32), ("allreduce_sum_i32", ALLREDUCE_FN), ("user", C.c_void_p),
+                ("allgather_i32", ALLREDUCE_FN)]
 
 
 class PlanStats(C.Structure):

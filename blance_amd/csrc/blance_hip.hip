@@ -69,9 +69,12 @@ struct blance_ctx {
     bool uploaded = false;
     bool planned = false;
     // one plan on several ranks (include/blance_hip.h "one plan on several GPUs")
-    blance_comm comm{0, 1, nullptr, nullptr};
+    blance_comm comm{0, 1, nullptr, nullptr, nullptr};
     void* rccl_comm = nullptr;      // ncclComm_t of blance_comm_init_rccl
-    DevBuf cnt_base, cnt_delta;
+    DevBuf scan_sums;               // tile totals of launch_scan_excl
+    DevBuf cnt_base, xbuf, gath;    // sharded pass: loads at pass start, [flags | load change], gathered output slices
+    std::vector<int32_t> h_reg_off; // host copy of the chain offsets (slice sizes of the all-gather)
+    bool trace = false;             // BLANCE_TRACE, read once at context creation
     DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
     DevBuf mv[11];                  // blance_calc_moves: inputs, per-partition slices, offsets, compacted outputs (kept between calls)
     int64_t comm_calls = 0, comm_bytes = 0;
@@ -88,6 +91,7 @@ struct blance_ctx {
     bool tree_dense = false;        // test knob (& 4): k_pass_tree scores every node in every general step
     bool tree_always = false;       // test knob (& 8): k_pass_tree even when a k_pass_seq workgroup size is forced
     bool tree_long = false;         // test knob (& 16): k_pass_tree decodes the record in every general step
+    bool no_planes = false;         // test knob (& 32): the all-blank chain pass on k_pass_chain_blank, not k_pass_chain_planes
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -133,7 +137,7 @@ struct blance_ctx {
         for (DevBuf* b : all) b->release();
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
         rule_regions.clear();
-        cnt_base.release(); cnt_delta.release();
+        cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release();
         dl_off.release(); dl_nodes.release();
         for (DevBuf& b : mv) b.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &n_ev, &chain_oi,
@@ -287,6 +291,8 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->tree_dense = opt && (opt->reserved[2] & 4);
     c->tree_always = opt && (opt->reserved[2] & 8);
     c->tree_long = opt && (opt->reserved[2] & 16);
+    c->no_planes = opt && (opt->reserved[2] & 32);
+    c->trace = getenv("BLANCE_TRACE") != nullptr;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -569,13 +575,29 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
 static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     const bool tree = !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always);
     if (tree && launch_pass_tree(c->stream, q, (c->tree_dense ? 1 : 0) | (c->tree_long ? 2 : 0))) {
-        if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
+        if (c->trace) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
         return 0;
     }
     if (launch_pass_seq(c->stream, q, c->force_threads, !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL))
         return fail(BLANCE_ERR_UNSUPPORTED, "too many nodes for the register-resident pass");
     return 0;
 }
+
+// exclusive scan of n ints on the planner's stream (k_sweep.h: one workgroup for short arrays, tile
+// totals + per-tile scans over the whole chip for long ones)
+static int launch_scan_excl(blance_ctx* c, int n, int32_t* data) {
+    if (n <= 4 * kScanTile) {
+        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, n, data);
+        return 0;
+    }
+    const int tiles = cdiv(n, kScanTile);
+    if (c->scan_sums.reserve(sizeof(int32_t) * ((size_t)tiles + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    BLANCE_LAUNCH(k_scan_tile_sums, tiles, 1024, 256, c->stream, n, data, c->scan_sums.as<int32_t>());
+    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, tiles, c->scan_sums.as<int32_t>());
+    BLANCE_LAUNCH(k_scan_apply, tiles, 1024, 256, c->stream, n, data, c->scan_sums.as<int32_t>());
+    return 0;
+}
+#define SCANTRY(n, data) do { int e__ = launch_scan_excl(c, (n), (data)); if (e__) return e__; } while (0)
 
 // stable LSD radix sort of n (key, value) pairs; result ends in the *_a buffers
 static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
@@ -596,7 +618,7 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
     for (int shift = 0; shift < 64; shift += 8) {
         if (((varying >> shift) & 0xff) == 0) continue;
         BLANCE_LAUNCH(k_sort_hist, n_tiles, 64, 1024 + 64, c->stream, n, shift, ka, n_tiles, c->f_hist.as<int32_t>());
-        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, 256 * n_tiles, c->f_hist.as<int32_t>());
+        SCANTRY(256 * n_tiles, c->f_hist.as<int32_t>());
         BLANCE_LAUNCH(k_sort_scatter, n_tiles, 64, 1024 + 64, c->stream, n, shift, ka, va, kb, vb, n_tiles,
                       c->f_hist.as<int32_t>());
         std::swap(ka, kb);
@@ -790,13 +812,18 @@ static int dump_pass(blance_ctx* c, int sweep, int state, int P, int OW, const i
 #include <dlfcn.h>
 struct Id128 { char b[128]; };                  // ncclUniqueId, passed by value
 namespace {
-// RCCL is bound at run time (dlopen): a single-GPU caller never loads it
+// RCCL is bound at run time (dlopen): a single-GPU caller never loads it.  The two enum values
+// this file passes are part of NCCL's stable ABI (nccl.h: ncclDataType_t, ncclRedOp_t).
+constexpr int kNcclInt32 = 2;                   // ncclInt32 == ncclInt
+constexpr int kNcclSum = 0;                     // ncclSum
 struct Rccl {
     void* lib = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 }
@@ -812,14 +839,24 @@ static int rccl_load() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(lib, "ncclCommAbort");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return fail(BLANCE_ERR_COMM, "librccl.so lacks an entry point");
     g_rccl.lib = lib;
     return 0;
 }
 #endif
+
+extern "C" int blance_is_emulated(void) {
+#ifdef BLANCE_SIMT_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int blance_comm_unique_id(void* id_out_128) {
 #ifndef BLANCE_SIMT_EMU
@@ -850,7 +887,7 @@ extern "C" int blance_comm_init_rccl(blance_ctx* c, int32_t n_ranks, int32_t ran
     int e = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
     if (e) return fail(BLANCE_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
     c->rccl_comm = comm;
-    c->comm = blance_comm{rank, n_ranks, nullptr, nullptr};
+    c->comm = blance_comm{rank, n_ranks, nullptr, nullptr, nullptr};
     return BLANCE_OK;
 #else
     (void)c; (void)n_ranks; (void)rank; (void)id_128;
@@ -863,7 +900,7 @@ extern "C" int blance_comm_set(blance_ctx* c, const blance_comm* comm) {
     return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
-    if (!comm) { c->comm = blance_comm{0, 1, nullptr, nullptr}; return BLANCE_OK; }
+    if (!comm) { c->comm = blance_comm{0, 1, nullptr, nullptr, nullptr}; return BLANCE_OK; }
     if (comm->n_ranks < 1 || comm->rank < 0 || comm->rank >= comm->n_ranks || (comm->n_ranks > 1 && !comm->allreduce_sum_i32))
         return fail(BLANCE_ERR_BAD_ARG, "bad communicator");
     c->comm = *comm;
@@ -871,11 +908,28 @@ extern "C" int blance_comm_set(blance_ctx* c, const blance_comm* comm) {
     });
 }
 
+extern "C" int blance_comm_stats(blance_ctx* c, int64_t* calls, int64_t* words) {
+    if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (calls) *calls = c->comm_calls;
+    if (words) *words = c->comm_bytes / 4;
+    return BLANCE_OK;
+}
+
 static void comm_release(blance_ctx* c) {
 #ifndef BLANCE_SIMT_EMU
     if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
 #endif
     c->rccl_comm = nullptr;
+}
+
+// a sharded call failed on this rank after the others may have entered a collective: RCCL
+// communicators are aborted so that no rank waits forever (the communicator is invalid afterwards)
+static void comm_abort(blance_ctx* c) {
+#ifndef BLANCE_SIMT_EMU
+    if (c->rccl_comm && g_rccl.CommAbort) { g_rccl.CommAbort(c->rccl_comm); c->rccl_comm = nullptr; }
+#endif
+    (void)c;
 }
 
 // in-place int32 sum over the ranks, ordered with the kernels of the planner's stream
@@ -890,8 +944,29 @@ static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
     }
 #ifndef BLANCE_SIMT_EMU
     if (!c->rccl_comm) return fail(BLANCE_ERR_COMM, "no communicator");
-    int e = g_rccl.AllReduce(buf, buf, (size_t)n, /* ncclInt32 */ 2, /* ncclSum */ 0, c->rccl_comm, c->stream);
+    int e = g_rccl.AllReduce(buf, buf, (size_t)n, kNcclInt32, kNcclSum, c->rccl_comm, c->stream);
     if (e) return fail(BLANCE_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return 0;
+#else
+    return fail(BLANCE_ERR_COMM, "no communicator");
+#endif
+}
+
+// in-place all-gather of n_ranks blocks of `per_rank` int32 values (this rank's block filled in)
+static int comm_allgather(blance_ctx* c, int32_t* buf, int64_t per_rank) {
+    if (c->comm.n_ranks <= 1 || per_rank <= 0) return 0;
+    c->comm_calls++;
+    c->comm_bytes += per_rank * 4 * c->comm.n_ranks;
+    if (c->comm.allreduce_sum_i32) {
+        HIPTRY(hipStreamSynchronize(c->stream));
+        if (!c->comm.allgather_i32) return fail(BLANCE_ERR_COMM, "no all-gather hook");
+        if (c->comm.allgather_i32(c->comm.user, buf, per_rank)) return fail(BLANCE_ERR_COMM, "the caller's all-gather failed");
+        return 0;
+    }
+#ifndef BLANCE_SIMT_EMU
+    if (!c->rccl_comm) return fail(BLANCE_ERR_COMM, "no communicator");
+    int e = g_rccl.AllGather(buf + (size_t)c->comm.rank * per_rank, buf, (size_t)per_rank, kNcclInt32, c->rccl_comm, c->stream);
+    if (e) return fail(BLANCE_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
     return 0;
 #else
     return fail(BLANCE_ERR_COMM, "no communicator");
@@ -912,6 +987,230 @@ static DevProblem dev_problem(blance_ctx* c) {
     d.prv = c->prv.as<int32_t>(); d.prv_len = c->prv_len.as<int32_t>(); d.prv_kind = c->prv_kind.as<uint8_t>();
     d.in_prev = c->in_prev.as<uint8_t>(); d.never_equal = c->never_equal.as<uint8_t>();
     return d;
+}
+
+// ---- one state pass as region chains ----------------------------------------
+// Header of the buffer the ranks of a sharded plan sum up after such a pass (collective A):
+// [0..7] the chain kernels' flags, [8] poison (a rank failed), then the load-vector change.
+constexpr int kXHead = 16;
+struct ChainPassArgs {
+    DevProblem d;
+    int m, k, NP, OW, RW, higher_mask, r0, it;
+};
+
+// this rank failed before collective A of a sharded chain pass: take part in it with the poison word set
+static void comm_poison(blance_ctx* c) {
+    const blance_problem& h = c->h;
+    const size_t n = kXHead + (size_t)(h.n_states + 1) * h.n_nodes_ext;
+    if (c->xbuf.reserve(sizeof(int32_t) * (n + 1))) return;
+    if (hipMemsetAsync(c->xbuf.p, 0, sizeof(int32_t) * n, c->stream) != hipSuccess) return;
+    const int32_t one = 1;
+    if (hipMemcpyAsync(c->xbuf.as<int32_t>() + 8, &one, sizeof one, hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+    (void)comm_allreduce(c, c->xbuf.as<int32_t>(), (int64_t)n);
+    (void)hipStreamSynchronize(c->stream);
+}
+
+// 0 = ok (*done tells whether the pass was made; if not, the counters are as before and the caller
+// runs the pass in order), < 0 = error
+static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launches_io, int64_t* batched_io, int* n_pass_io,
+                          bool* done, bool* a_done) {
+    const blance_problem& h = c->h;
+    const DevProblem& d = a.d;
+    const int N = h.n_nodes, NX = h.n_nodes_ext, M = h.n_states, P = h.n_parts, L = c->L;
+    const int m = a.m, k = a.k, NP = a.NP, OW = a.OW;
+    hipStream_t sm = c->stream;
+    int32_t* scal = c->scalars.as<int32_t>();
+    int64_t launches = 0;
+    int& n_pass = *n_pass_io;
+    blance_ctx::RuleRegions& rr = c->rule_regions[a.r0];
+    const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
+    const int G = c->comm.n_ranks, rank = c->comm.rank;
+    const bool sharded = G > 1 && B >= G;
+    HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+    BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P + 1, 256), 256, 0, sm, d, m, h.top_state,
+                         c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
+                         c->n_ev.as<int32_t>(), scal + 4);
+    int nbits = 1;
+    while ((1 << nbits) < B) nbits++;
+    BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
+                  (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, B, c->bucket_counts.as<int32_t>());
+    SCANTRY(B * nbc, c->bucket_counts.as<int32_t>());
+    BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nbc, P,
+                         c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
+    BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
+                  (const uint8_t*)nullptr, (const int32_t*)nullptr, c->order.as<int32_t>(), nbc, B, nbits,
+                  c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>());
+    // events: how many?  (also: is every step region-local at all, are there orphan nodes); a sharded
+    // plan reads the chain offsets in the same round trip (the slice sizes of collective B)
+    int32_t n_events = 0, cfl[8] = {0};
+    HIPTRY(hipMemcpyAsync(cfl, scal + 4, sizeof cfl, hipMemcpyDeviceToHost, sm));
+    if (sharded) {
+        c->h_reg_off.resize((size_t)B + 1);
+        HIPTRY(hipMemcpyAsync(c->h_reg_off.data(), c->reg_off.p, sizeof(int32_t) * ((size_t)B + 1), hipMemcpyDeviceToHost, sm));
+    }
+    HIPTRY(hipStreamSynchronize(sm));
+    if (!cfl[0] && cfl[7]) {                            // rare: nodes outside their partition's region
+        SCANTRY(P + 1, c->n_ev.as<int32_t>());   // -> event slots
+        HIPTRY(hipMemcpyAsync(&n_events, c->n_ev.as<int32_t>() + P, sizeof n_events, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipStreamSynchronize(sm));
+    }
+    if (c->trace)
+        fprintf(stderr, "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
+    HIPTRY(hipMemsetAsync(c->ev_off.p, 0, sizeof(int32_t) * ((size_t)B + 1), sm));
+    if (!cfl[0] && n_events > 0) {
+        const int nec = cdiv(n_events, kPartChunk);
+        BLANCE_LAUNCH_NOSYNC(k_chain_ev_fill, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+                             rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), c->node_leaf_pos.as<int32_t>(),
+                             c->regid.as<int32_t>(), c->n_ev.as<int32_t>(), c->ev_key.as<int32_t>(),
+                             c->ev_oi.as<int32_t>(), c->ev_leaf.as<int32_t>(), c->ev_w.as<int32_t>());
+        BLANCE_LAUNCH(k_part_count, nec, 64, sizeof(int32_t) * B + 64, sm, n_events, c->ev_key.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, nec, B, c->ev_counts.as<int32_t>());
+        SCANTRY(B * nec, c->ev_counts.as<int32_t>());
+        BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nec, n_events,
+                             c->ev_counts.as<int32_t>(), c->ev_off.as<int32_t>());
+        BLANCE_LAUNCH(k_part_scatter, nec, 64, sizeof(int32_t) * B + 64, sm, n_events, c->ev_key.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, nec, B, nbits,
+                      c->ev_counts.as<int32_t>(), c->ev_perm.as<int32_t>(), (int32_t*)nullptr);
+        launches += 5;
+    }
+    BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, a.higher_mask,
+                         c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>(), c->state_stick.as<int32_t>(),
+                         c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
+                         rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
+                         rr.cls_size.as<int32_t>(), 0,
+                         c->crec.as<int32_t>(), scal + 4);
+    const size_t cnt_words = (size_t)(M + 1) * NX;
+    HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+    ChainParams cq;
+    memset(&cq, 0, sizeof cq);
+    cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
+    cq.NP = NP; cq.OW = OW; cq.booster_kind = h.booster_kind;
+    cq.n_regions = B;
+    // a sharded plan: this rank walks the chains of its slice of the regions
+    auto slice_lo = [&](int r) { return (int)((int64_t)B * r / G); };
+    cq.region_base = sharded ? slice_lo(rank) : 0;
+    cq.n_launch = sharded ? slice_lo(rank + 1) - cq.region_base : B;
+    cq.reg_lo = rr.reg_lo.as<int32_t>(); cq.reg_hi = rr.reg_hi.as<int32_t>();
+    cq.reg_off = c->reg_off.as<int32_t>();
+    cq.leaf_node = c->leaf_node.as<int32_t>();
+    cq.leaf_cls = rr.leaf_cls.as<int32_t>();
+    cq.cls_size = rr.cls_size.as<int32_t>();
+    cq.alive = c->alive.as<uint8_t>();
+    cq.node_weight = c->node_weight.as<int32_t>();
+    cq.node_has_weight = c->node_has_weight.as<uint8_t>();
+    cq.cnt = c->cnt.as<int32_t>(); cq.ntn = c->ntn.as<int32_t>();
+    cq.crec = c->crec.as<int32_t>(); cq.out = c->out.as<int32_t>();
+    cq.flags = scal + 4;
+    cq.ev_off = c->ev_off.as<int32_t>(); cq.ev_perm = c->ev_perm.as<int32_t>();
+    cq.ev_oi = c->ev_oi.as<int32_t>(); cq.ev_leaf = c->ev_leaf.as<int32_t>(); cq.ev_w = c->ev_w.as<int32_t>();
+    if (cfl[6])                                        // nodes of this state that lie in no region
+        BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+                             rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
+    cq.cnt_out = cq.cnt;
+    const bool gather_out = sharded && (c->comm.allgather_i32 || !c->comm.allreduce_sum_i32);
+    if (sharded) {                                     // the loads every rank starts this pass from (orphans included)
+        RESERVE(cnt_base, sizeof(int32_t) * (cnt_words + 1));
+        RESERVE(xbuf, sizeof(int32_t) * (kXHead + cnt_words + 1));
+        HIPTRY(hipMemcpyAsync(c->cnt_base.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+        if (!gather_out) HIPTRY(hipMemsetAsync(c->out.p, 0, sizeof(int32_t) * (size_t)P * OW, sm));
+    }
+    HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
+    // a fresh plan's first sweep: every step blank -> the lean kernel; it either does this rank's
+    // whole slice or changes nothing that is not restored below (a rank-local decision: the full
+    // kernel makes the same choices)
+    bool lean = false;
+    if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4 && !cfl[0]) {
+        if (c->no_planes || !launch_chain_planes(sm, cq, rr.max_size)) launch_chain_blank(sm, cq, rr.max_size);
+        int32_t fl[2] = {0, 0};
+        HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipStreamSynchronize(sm));
+        launches++;
+        if (c->trace) fprintf(stderr, "[blance] chain pass state %d: all-blank kernel (%s) %s\n", m, c->no_planes ? "lanes" : "planes",
+                              !fl[0] && !fl[1] ? "did the pass" : "escaped");
+        if (!fl[0] && !fl[1]) {
+            lean = true;
+        } else if (!fl[0]) {                            // not all blank: the full kernel, from the same state
+            HIPTRY(hipMemcpyAsync(c->cnt.p, sharded ? c->cnt_base.p : c->cnt_save.p, sizeof(int32_t) * cnt_words,
+                                  hipMemcpyDeviceToDevice, sm));
+            if (cfl[6] && !sharded)
+                BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state,
+                                     c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
+            HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
+        }
+    }
+    if (!lean && !dispatch_chain(c, cq, rr.max_size)) return fail(BLANCE_ERR_UNSUPPORTED, "region chain shape");
+    HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
+    launches += 8;
+    c->pass_kind.resize(n_pass + 1);
+    c->pass_kind[n_pass] = 0;
+    n_pass++;
+    int32_t fl[kXHead] = {0};
+    if (sharded) {
+        // collective A: [flags | this rank's change of the load vector]
+        int32_t* xb = c->xbuf.as<int32_t>();
+        HIPTRY(hipMemsetAsync(xb, 0, sizeof(int32_t) * kXHead, sm));
+        HIPTRY(hipMemcpyAsync(xb, scal + 4, 32, hipMemcpyDeviceToDevice, sm));
+        BLANCE_LAUNCH_NOSYNC(k_vec_sub, cdiv((int64_t)cnt_words, 256), 256, 0, sm, (int)cnt_words, c->cnt.as<int32_t>(),
+                             c->cnt_base.as<int32_t>(), xb + kXHead);
+        *a_done = true;
+        COMMTRY(comm_allreduce(c, xb, (int64_t)(kXHead + cnt_words)));
+        HIPTRY(hipMemcpyAsync(fl, xb, sizeof fl, hipMemcpyDeviceToHost, sm));
+        launches++;
+    } else {
+        HIPTRY(hipMemcpyAsync(fl, scal + 4, 32, hipMemcpyDeviceToHost, sm));
+    }
+    HIPTRY(hipStreamSynchronize(sm));
+    if (fl[8]) return fail(BLANCE_ERR_COMM, "another rank of the sharded plan failed");
+    if (c->trace)
+        fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
+                m, fl[2], P, fl[3]);
+    if (!fl[0] && !fl[1]) {
+        if (sharded) {
+            // every rank's chains wrote their own regions' loads and their own steps' outputs
+            int32_t* xb = c->xbuf.as<int32_t>();
+            BLANCE_LAUNCH_NOSYNC(k_vec_add, cdiv((int64_t)cnt_words, 256), 256, 0, sm, (int)cnt_words, c->cnt_base.as<int32_t>(),
+                                 xb + kXHead, c->cnt.as<int32_t>());
+            launches++;
+            if (gather_out) {
+                // collective B: a rank's steps are contiguous in chain order
+                const int32_t* ro = c->h_reg_off.data();
+                int64_t per = 0;
+                for (int r = 0; r < G; r++) {
+                    const int64_t len = (int64_t)(ro[slice_lo(r + 1)] - ro[slice_lo(r)]) * OW;
+                    if (len > per) per = len;
+                }
+                if (per > 0) {
+                    RESERVE(gath, sizeof(int32_t) * ((size_t)per * G + 1));
+                    int32_t* gb = c->gath.as<int32_t>();
+                    const int64_t mine = (int64_t)(ro[slice_lo(rank + 1)] - ro[slice_lo(rank)]) * OW;
+                    if (mine > 0)
+                        HIPTRY(hipMemcpyAsync(gb + (size_t)rank * per, c->out.as<int32_t>() + (size_t)ro[slice_lo(rank)] * OW,
+                                              sizeof(int32_t) * (size_t)mine, hipMemcpyDeviceToDevice, sm));
+                    COMMTRY(comm_allgather(c, gb, per));
+                    for (int r = 0; r < G; r++) {
+                        const int64_t len = (int64_t)(ro[slice_lo(r + 1)] - ro[slice_lo(r)]) * OW;
+                        if (r != rank && len > 0)
+                            HIPTRY(hipMemcpyAsync(c->out.as<int32_t>() + (size_t)ro[slice_lo(r)] * OW, gb + (size_t)r * per,
+                                                  sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToDevice, sm));
+                    }
+                }
+            } else {
+                COMMTRY(comm_allreduce(c, c->out.as<int32_t>(), (int64_t)P * OW));
+            }
+        }
+        if (dump_pass(c, a.it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
+        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, OW, c->chain_order.as<int32_t>(), c->out.as<int32_t>());
+        launches++;
+        *batched_io += P;
+        *done = true;
+    } else {                                        // not region-local after all: redo in order
+        if (NP > 0)                                 // chains of big regions keep their rows in global memory
+            HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
+        HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+    }
+    *launches_io += launches;
+    return 0;
 }
 
 static int plan_locked(blance_ctx* c, blance_result* res) {
@@ -971,7 +1270,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             BLANCE_LAUNCH_NOSYNC(k_category, cdiv(P, 256), 256, 0, sm, d, m, any_removed, add_nil, c->cat.as<uint8_t>());
             BLANCE_LAUNCH(k_part_count, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
                           c->part_order.as<int32_t>(), n_chunks, 3, c->chunk_counts.as<int32_t>());
-            BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, 3 * n_chunks, c->chunk_counts.as<int32_t>());
+            SCANTRY(3 * n_chunks, c->chunk_counts.as<int32_t>());
             BLANCE_LAUNCH(k_part_scatter, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
                           c->part_order.as<int32_t>(), c->part_order.as<int32_t>(), n_chunks, 3, 2,
                           c->chunk_counts.as<int32_t>(), c->order.as<int32_t>(), (int32_t*)nullptr);
@@ -992,156 +1291,14 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             bool done = false;
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
                 c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
-                blance_ctx::RuleRegions& rr = c->rule_regions[r0];
-                const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
-                HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
-                BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P + 1, 256), 256, 0, sm, d, m, h.top_state,
-                                     c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
-                                     c->n_ev.as<int32_t>(), scal + 4);
-                int nbits = 1;
-                while ((1 << nbits) < B) nbits++;
-                BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
-                              (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, B, c->bucket_counts.as<int32_t>());
-                BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, B * nbc, c->bucket_counts.as<int32_t>());
-                BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nbc, P,
-                                     c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
-                BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
-                              (const uint8_t*)nullptr, (const int32_t*)nullptr, c->order.as<int32_t>(), nbc, B, nbits,
-                              c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>());
-                // events: how many?  (also: is every step region-local at all, are there orphan nodes)
-                int32_t n_events = 0, cfl[8] = {0};
-                HIPTRY(hipMemcpyAsync(cfl, scal + 4, sizeof cfl, hipMemcpyDeviceToHost, sm));
-                HIPTRY(hipStreamSynchronize(sm));
-                if (!cfl[0] && cfl[7]) {                            // rare: nodes outside their partition's region
-                    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, P + 1, c->n_ev.as<int32_t>());   // -> event slots
-                    HIPTRY(hipMemcpyAsync(&n_events, c->n_ev.as<int32_t>() + P, sizeof n_events, hipMemcpyDeviceToHost, sm));
-                    HIPTRY(hipStreamSynchronize(sm));
-                }
-                if (getenv("BLANCE_TRACE"))
-                    fprintf(stderr, "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
-                HIPTRY(hipMemsetAsync(c->ev_off.p, 0, sizeof(int32_t) * ((size_t)B + 1), sm));
-                if (!cfl[0] && n_events > 0) {
-                    const int nec = cdiv(n_events, kPartChunk);
-                    BLANCE_LAUNCH_NOSYNC(k_chain_ev_fill, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
-                                         rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), c->node_leaf_pos.as<int32_t>(),
-                                         c->regid.as<int32_t>(), c->n_ev.as<int32_t>(), c->ev_key.as<int32_t>(),
-                                         c->ev_oi.as<int32_t>(), c->ev_leaf.as<int32_t>(), c->ev_w.as<int32_t>());
-                    BLANCE_LAUNCH(k_part_count, nec, 64, sizeof(int32_t) * B + 64, sm, n_events, c->ev_key.as<int32_t>(),
-                                  (const uint8_t*)nullptr, (const int32_t*)nullptr, nec, B, c->ev_counts.as<int32_t>());
-                    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, sm, B * nec, c->ev_counts.as<int32_t>());
-                    BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nec, n_events,
-                                         c->ev_counts.as<int32_t>(), c->ev_off.as<int32_t>());
-                    BLANCE_LAUNCH(k_part_scatter, nec, 64, sizeof(int32_t) * B + 64, sm, n_events, c->ev_key.as<int32_t>(),
-                                  (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, nec, B, nbits,
-                                  c->ev_counts.as<int32_t>(), c->ev_perm.as<int32_t>(), (int32_t*)nullptr);
-                    launches += 5;
-                }
-                BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->chain_order.as<int32_t>(),
-                                     c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
-                BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
-                                     c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>(), c->state_stick.as<int32_t>(),
-                                     c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
-                                     rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
-                                     rr.cls_size.as<int32_t>(), 0,
-                                     c->crec.as<int32_t>(), scal + 4);
-                HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
-                                      hipMemcpyDeviceToDevice, sm));
-                ChainParams cq;
-                memset(&cq, 0, sizeof cq);
-                cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
-                cq.NP = NP; cq.OW = OW; cq.booster_kind = h.booster_kind;
-                cq.n_regions = B;
-                // a sharded plan: this rank walks the chains of its slice of the regions
-                const bool sharded = c->comm.n_ranks > 1 && B >= c->comm.n_ranks;
-                cq.region_base = sharded ? (int)((int64_t)B * c->comm.rank / c->comm.n_ranks) : 0;
-                cq.n_launch = sharded ? (int)((int64_t)B * (c->comm.rank + 1) / c->comm.n_ranks) - cq.region_base : B;
-                cq.reg_lo = rr.reg_lo.as<int32_t>(); cq.reg_hi = rr.reg_hi.as<int32_t>();
-                cq.reg_off = c->reg_off.as<int32_t>();
-                cq.leaf_node = c->leaf_node.as<int32_t>();
-                cq.leaf_cls = rr.leaf_cls.as<int32_t>();
-                cq.cls_size = rr.cls_size.as<int32_t>();
-                cq.alive = c->alive.as<uint8_t>();
-                cq.node_weight = c->node_weight.as<int32_t>();
-                cq.node_has_weight = c->node_has_weight.as<uint8_t>();
-                cq.cnt = c->cnt.as<int32_t>(); cq.ntn = c->ntn.as<int32_t>();
-                cq.crec = c->crec.as<int32_t>(); cq.out = c->out.as<int32_t>();
-                cq.flags = scal + 4;
-                cq.ev_off = c->ev_off.as<int32_t>(); cq.ev_perm = c->ev_perm.as<int32_t>();
-                cq.ev_oi = c->ev_oi.as<int32_t>(); cq.ev_leaf = c->ev_leaf.as<int32_t>(); cq.ev_w = c->ev_w.as<int32_t>();
-                if (cfl[6])                                        // nodes of this state that lie in no region
-                    BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
-                                         rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
-                cq.cnt_out = cq.cnt;
-                const size_t cnt_words = (size_t)(M + 1) * NX;
-                if (sharded) {                                     // what the ranks will sum up: outputs, load changes
-                    RESERVE(cnt_base, sizeof(int32_t) * (cnt_words + 1));
-                    RESERVE(cnt_delta, sizeof(int32_t) * (cnt_words + 1));
-                    HIPTRY(hipMemcpyAsync(c->cnt_base.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
-                    HIPTRY(hipMemsetAsync(c->out.p, 0, sizeof(int32_t) * (size_t)P * OW, sm));
-                }
-                HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
-                // a fresh plan's first sweep: every step blank -> the lean kernel; it either
-                // does the whole pass or changes nothing that is not restored below
-                bool lean = false;
-                if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4) {
-                    launch_chain_blank(sm, cq, rr.max_size);
-                    if (sharded) COMMTRY(comm_allreduce(c, scal + 4, 8));       // did every rank's chains make it?
-                    int32_t fl[2] = {0, 0};
-                    HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
-                    HIPTRY(hipStreamSynchronize(sm));
-                    launches++;
-                    if (!fl[0] && !fl[1]) {
-                        lean = true;
-                    } else if (!fl[0]) {                            // not all blank: the full kernel, from the same state
-                        HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
-                                              hipMemcpyDeviceToDevice, sm));
-                        if (cfl[6])
-                            BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state,
-                                                 c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
-                        HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
-                        if (sharded) HIPTRY(hipMemsetAsync(c->out.p, 0, sizeof(int32_t) * (size_t)P * OW, sm));
-                    }
-                }
-                bool launched = lean;
-                if (!lean) {
-                    launched = dispatch_chain(c, cq, rr.max_size);
-                    if (launched && sharded) COMMTRY(comm_allreduce(c, scal + 4, 8));
-                }
-                HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
-                launches += 8;
-                if (launched) {
-                    c->pass_kind.resize(n_pass + 1);
-                    c->pass_kind[n_pass] = 0;
-                    n_pass++;
-                    int32_t fl[4] = {0, 0, 0, 0};
-                    HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
-                    HIPTRY(hipStreamSynchronize(sm));
-                    if (getenv("BLANCE_TRACE"))
-                        fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
-                                m, fl[2], P, fl[3]);
-                    if (!fl[0] && !fl[1]) {
-                        if (sharded) {
-                            // every rank's chains wrote their own steps' outputs and their own regions' loads
-                            BLANCE_LAUNCH_NOSYNC(k_vec_sub, cdiv((int64_t)cnt_words, 256), 256, 0, sm, (int)cnt_words, c->cnt.as<int32_t>(),
-                                                 c->cnt_base.as<int32_t>(), c->cnt_delta.as<int32_t>());
-                            COMMTRY(comm_allreduce(c, c->cnt_delta.as<int32_t>(), (int64_t)cnt_words));
-                            BLANCE_LAUNCH_NOSYNC(k_vec_add, cdiv((int64_t)cnt_words, 256), 256, 0, sm, (int)cnt_words, c->cnt_base.as<int32_t>(),
-                                                 c->cnt_delta.as<int32_t>(), c->cnt.as<int32_t>());
-                            COMMTRY(comm_allreduce(c, c->out.as<int32_t>(), (int64_t)P * OW));
-                            launches += 2;
-                        }
-                        if (dump_pass(c, it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
-                        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, OW, c->chain_order.as<int32_t>(),
-                                             c->rec.as<int32_t>(), c->out.as<int32_t>());
-                        launches++;
-                        batched += P;
-                        done = true;
-                    } else {                                        // not region-local after all: redo in order
-                        if (NP > 0)                                 // chains of big regions keep their rows in global memory
-                            HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
-                        HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX,
-                                              hipMemcpyDeviceToDevice, sm));
-                    }
+                ChainPassArgs ca{d, m, k, NP, OW, RW, higher_mask, r0, it};
+                bool a_done = false;
+                const int e = run_chain_pass(c, ca, &launches, &batched, &n_pass, &done, &a_done);
+                if (e) {
+                    const bool sharded = c->comm.n_ranks > 1 && c->rule_regions[r0].n_regions >= c->comm.n_ranks;
+                    if (sharded && !a_done) comm_poison(c);       // the other ranks are (or will be) in collective A
+                    if (sharded) comm_abort(c);
+                    return e;
                 }
             }
             if (!done) {
@@ -1179,7 +1336,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             c->no_fast_keys = false;
             if (flat_chain) {
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
-                BLANCE_LAUNCH_NOSYNC(k_gather_chain, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, higher_mask,
+                BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, higher_mask,
                                      c->order.as<int32_t>(), (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
@@ -1213,8 +1370,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
             n_pass++;
             if (dump_pass(c, it, m, P, q.OW, nullptr)) return BLANCE_ERR_DEVICE;
-            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, RW, q.OW, c->order.as<int32_t>(),
-                                 c->rec.as<int32_t>(), c->out.as<int32_t>());
+            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, c->order.as<int32_t>(), c->out.as<int32_t>());
             }
             launches += 7;
             steps += P;
@@ -1222,7 +1378,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         iterations++;
         // convergence (plan.go:36-45) + write-back (plan.go:49-52)
         if (P > 0) {
-            BLANCE_LAUNCH_NOSYNC(k_converge, cdiv(P, 256), 256, 0, sm, d, scal + 1);
+            BLANCE_LAUNCH(k_converge, cdiv(P, 256), 256, 0, sm, d, scal + 1);          // (uses a wave ballot)
             launches++;
         }
         int32_t hs[4] = {0, 0, 0, 0};
@@ -1241,7 +1397,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         HIPTRY(hipStreamSynchronize(sm));
         batched += spec;
         if (batched > steps) batched = steps;     // the flat chain counts its whole pass already
-        if (getenv("BLANCE_TRACE")) fprintf(stderr, "[blance] sequential passes: %lld verified stays\n", spec);
+        if (c->trace) fprintf(stderr, "[blance] sequential passes: %lld verified stays\n", spec);
     }
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -1251,7 +1407,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         float pm = 0.f;
         HIPTRY(hipEventElapsedTime(&pm, c->pass_events[2 * i], c->pass_events[2 * i + 1]));
         if (c->pass_kind[i] == 0) { pass_ms += pm; n_kernel_pass++; } else { flat_ms += pm; n_flat++; }
-        if (getenv("BLANCE_TRACE"))
+        if (c->trace)
             fprintf(stderr, "[blance] pass %d (%s): %.3f ms\n", i, c->pass_kind[i] ? "flat bulk driver" : "pass kernel", pm);
     }
     c->pass_ms = pass_ms;
@@ -1308,7 +1464,7 @@ static int download_locked(blance_ctx* c, blance_result* res) {
         DevProblem d = dev_problem(c);
         RESERVE(dl_off, sizeof(int32_t) * (PM + 2));
         BLANCE_LAUNCH_NOSYNC(k_result_len, cdiv((int64_t)PM + 1, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>());
-        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, (int)PM + 1, c->dl_off.as<int32_t>());
+        SCANTRY((int)PM + 1, c->dl_off.as<int32_t>());
         int32_t total = 0;
         HIPTRY(hipMemcpyAsync(&total, c->dl_off.as<int32_t>() + PM, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIPTRY(hipStreamSynchronize(c->stream));
@@ -1389,7 +1545,7 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
         // per-partition slices -> offsets (exclusive scan of the move counts) -> packed on the device
         HIPTRY(hipMemsetAsync(nmov.as<int32_t>() + P, 0, sizeof(int32_t), c->stream));
         BLANCE_LAUNCH_NOSYNC(k_calc_moves, cdiv(P, 256), 256, 0, c->stream, q);
-        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, P + 1, nmov.as<int32_t>());
+        SCANTRY(P + 1, nmov.as<int32_t>());
         BLANCE_LAUNCH_NOSYNC(k_moves_compact, cdiv(P, 256), 256, 0, c->stream, q, nmov.as<int32_t>(), cnode.as<int32_t>(),
                              cstate.as<int32_t>(), ckind.as<int32_t>());
     }

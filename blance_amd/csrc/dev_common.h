@@ -59,6 +59,17 @@ struct RedSlot { unsigned hi, lo; int n; int pad; };
 
 constexpr unsigned kKeyNoneV = 0xffffffffu;
 
+// v_writelane_b32: lane `lane` of `old` takes the wave-uniform value v (both selectors come from the scalar unit)
+__device__ __forceinline__ int write_lane(int v, int lane, int old) {
+#ifndef BLANCE_SIMT_EMU
+    // gfx9 reads one SGPR per VALU instruction (constant bus): the lane select goes through M0
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(lane) : "m0");
+    return old;
+#else
+    return (int)(threadIdx.x & 63) == lane ? v : old;
+#endif
+}
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int v) {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);

@@ -35,4 +35,6 @@ bool launch_pass_tree(hipStream_t stream, PassParams q, int knobs);
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
 // k_pass_chain_blank (tu_chain.hip): the lean first-sweep kernel
 void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size);
+// k_pass_chain_planes (tu_chain.hip): the all-blank pass as a scalar bit-plane automaton; false: shape outside it
+bool launch_chain_planes(hipStream_t stream, const ChainParams& q, int max_size);
 }  // namespace blance

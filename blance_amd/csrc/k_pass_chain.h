@@ -913,4 +913,381 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
         if (nid[u] >= 0) q.cnt_out[q.s * q.NX + nid[u]] = cntv[u];
 }
 
+// ---------------------------------------------------------------------------
+// k_pass_chain_planes: the all-blank pass (see k_pass_chain_blank) as a SCALAR automaton.
+// With NumPartitions == 0 and no node weights a leaf's score is its count, and every pick adds the
+// same weight w0: the leaves of a region are kept as bit planes in SGPRs -- plane j holds the
+// live leaves whose count is base + j * w0, one bit per leaf in leaf order (= node id order,
+// the tie-break of plan.go:617-628).  A pick is: first plane with a bit outside the exclude mask
+// (s_andn2_b64 / s_or_b64), first such bit (s_ff1_i32_b64), move the bit one plane up.  No
+// cross-lane reduction, no VALU on the dependent chain except the lane reads of the step's and
+// the pick's exclude masks (v_readlane_b32).  The exclude masks of 64 steps are prepared lane
+// parallel (lane r: step r), the records of the next 64 steps are fetched while this batch is walked.
+// Envelope: <= 64 W leaves, every live leaf has an exclude class, counts within kPlanes levels of
+// each other at any time, one partition weight for the whole chain.  Outside it: flags[1], nothing
+// published (as k_pass_chain_blank).
+// ---------------------------------------------------------------------------
+constexpr int kPlanes = 4;
+
+// One pick of the plane automaton: the lowest plane with a leaf outside E, its lowest such leaf, moved
+// one plane up; MORE: the leaf's exclude class joins E for the step's next pick (lm: the class mask
+// of every leaf, lane l of lm[u] = leaf 64 u + l).  Returns the leaf; negative: no candidate at
+// all (-1) or the leaf left the planes (-2).
+// planes_pick_from<J>: the general form, plane J upwards.
+template <int W, int J, bool MORE>
+__device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes][W], unsigned long long (&E)[W],
+                                             const unsigned (&lm)[W][2 * W]) {
+    typedef unsigned long long u64;
+    u64 m[W], any = 0;
+#pragma unroll
+    for (int u = 0; u < W; u++) { m[u] = P[J][u] & ~E[u]; any |= m[u]; }
+    if (any != 0) {
+#pragma unroll
+        for (int u = 0; u < W; u++) {
+            if (u == W - 1 || m[u] != 0) {
+                const int b = __builtin_ctzll(m[u]);
+                const u64 bit = 1ull << b;
+                P[J][u] ^= bit;
+                if (J + 1 < kPlanes) P[J + 1][u] |= bit;
+                if (MORE) {
+#pragma unroll
+                    for (int v = 0; v < W; v++)
+                        E[v] |= (u64)(unsigned)__builtin_amdgcn_readlane((int)lm[u][2 * v], b) |
+                                ((u64)(unsigned)__builtin_amdgcn_readlane((int)lm[u][2 * v + 1], b) << 32);
+                }
+                return J + 1 < kPlanes ? 64 * u + b : -2;
+            }
+        }
+    }
+    if constexpr (J + 1 < kPlanes) return planes_pick_from<W, J + 1, MORE>(P, E, lm);
+    return -1;
+}
+
+#ifndef BLANCE_SIMT_EMU
+// planes_walk_w2<K>: the steps of a batch for regions of up to 128 leaves (two 64-bit words per plane)
+// as long as every pick finds its leaf on plane 0 or 1 -- the hand-scheduled scalar loop of this kernel.
+// One wave issues an instruction every ~4.5 cycles and pays ~10 / ~25 cycles for a branch not taken /
+// taken (measured, tools/dev_lat_micro.hip), so the loop is laid out by instruction count: the
+// expected case (plane 0 has the leaf) falls through every rare-case branch, the two words of a plane
+// are two code paths (one branch) instead of selects, the last pick's paths each carry their own loop
+// tail, picks from plane 1 (a quarter of the steps at BASELINE config 3: the end of every round, when
+// the lowest level is left in excluded racks only) sit behind the loop and jump back.
+// Per step: 4 v_readlane (the step's exclude mask), per pick 6 + 4 scalar instructions, 4 v_readlane
+// (the picked leaf's class mask) and 2 s_or unless it is the step's last pick, 1 v_writelane.
+// Leaves the loop (a) at r == nb; (b) before a pick that has no candidate on planes 0 and 1, or finds
+// plane 0 empty: `slot` = its index, E = the exclude mask so far -- the caller finishes that step with
+// planes_pick_from, drops an empty plane 0, and comes back.
+#define BLANCE_PL_HEAD                                           \
+    "0:\n\t"                                                     \
+    "v_readlane_b32 s44, %[ex0], %[r]\n\t"                       \
+    "v_readlane_b32 s45, %[ex1], %[r]\n\t"                       \
+    "v_readlane_b32 s46, %[ex2], %[r]\n\t"                       \
+    "v_readlane_b32 s47, %[ex3], %[r]\n\t"                       \
+    "s_mov_b32 m0, %[r]\n\t"
+// candidates of plane (PL, PH) in s[52:53] / s[54:55]; none: to label NONE; else word 1 only: to label W1
+#define BLANCE_PL_FIND(PL, PH, NONE, W1)                         \
+    "s_andn2_b64 s[52:53], %[" #PL "], s[44:45]\n\t"             \
+    "s_andn2_b64 s[54:55], %[" #PH "], s[46:47]\n\t"             \
+    "s_or_b64 s[48:49], s[52:53], s[54:55]\n\t"                  \
+    "s_cbranch_scc0 " NONE "\n\t"                                \
+    "s_cmp_lg_u64 s[52:53], 0\n\t"                               \
+    "s_cbranch_scc0 " W1 "\n\t"
+// lowest candidate of word T (s56 = its bit index) leaves plane word FROM for plane word TO
+#define BLANCE_PL_TAKE(T, FROM, TO)                              \
+    "s_ff1_i32_b64 s56, " T "\n\t"                               \
+    "s_lshl_b64 " T ", 1, s56\n\t"                               \
+    "s_xor_b64 %[" #FROM "], %[" #FROM "], " T "\n\t"            \
+    "s_or_b64 %[" #TO "], %[" #TO "], " T "\n\t"
+#define BLANCE_PL_CLASS(SET)                                     \
+    "v_readlane_b32 s48, %[lm" #SET "0], s56\n\t"                \
+    "v_readlane_b32 s49, %[lm" #SET "1], s56\n\t"                \
+    "v_readlane_b32 s50, %[lm" #SET "2], s56\n\t"                \
+    "v_readlane_b32 s51, %[lm" #SET "3], s56\n\t"                \
+    "s_or_b64 s[44:45], s[44:45], s[48:49]\n\t"                  \
+    "s_or_b64 s[46:47], s[46:47], s[50:51]\n\t"
+#define BLANCE_PL_TAIL                                           \
+    "s_add_u32 %[r], %[r], 1\n\t"                                \
+    "s_cmp_lt_u32 %[r], %[nb]\n\t"                               \
+    "s_cbranch_scc1 0b\n\t"                                      \
+    "s_branch 7f\n"
+// both words' paths of a pick from plane (PL, PH) into (QL, QH); CONT: what follows the pick
+#define BLANCE_PL_WORDS_MORE(SLOT, PL, PH, QL, QH, W1, CONT)     \
+    BLANCE_PL_TAKE("s[52:53]", PL, QL) BLANCE_PL_CLASS(0)        \
+    "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
+    "s_branch " CONT "\n"                                        \
+    W1 ":\n\t"                                                   \
+    BLANCE_PL_TAKE("s[54:55]", PH, QH) BLANCE_PL_CLASS(1)        \
+    "s_or_b32 s56, s56, 64\n\t"                                  \
+    "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"
+#define BLANCE_PL_WORDS_LAST(SLOT, PL, PH, QL, QH, W1)           \
+    BLANCE_PL_TAKE("s[52:53]", PL, QL)                           \
+    "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
+    BLANCE_PL_TAIL                                               \
+    W1 ":\n\t"                                                   \
+    BLANCE_PL_TAKE("s[54:55]", PH, QH)                           \
+    "s_or_b32 s56, s56, 64\n\t"                                  \
+    "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
+    BLANCE_PL_TAIL
+// in the loop: a pick from plane 0 (labels 1<slot> .. 3<slot>); behind the loop: the same pick from plane 1
+#define BLANCE_PL_PICK_MORE(SLOT)                                \
+    BLANCE_PL_FIND(p0l, p0h, "5" #SLOT "f", "2" #SLOT "f")       \
+    BLANCE_PL_WORDS_MORE(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT, "3" #SLOT "f") \
+    "3" #SLOT ":\n\t"
+#define BLANCE_PL_PICK_LAST(SLOT)                                \
+    BLANCE_PL_FIND(p0l, p0h, "5" #SLOT "f", "2" #SLOT "f")       \
+    BLANCE_PL_WORDS_LAST(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT)
+#define BLANCE_PL_SLOW_HEAD(SLOT)                                \
+    "5" #SLOT ":\n\t"                                            \
+    "s_or_b64 s[48:49], %[p0l], %[p0h]\n\t"                      \
+    "s_cbranch_scc0 9" #SLOT "f\n\t"                             \
+    BLANCE_PL_FIND(p1l, p1h, "9" #SLOT "f", "6" #SLOT "f")
+#define BLANCE_PL_SLOW_MORE(SLOT)                                \
+    BLANCE_PL_SLOW_HEAD(SLOT)                                    \
+    BLANCE_PL_WORDS_MORE(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT, "3" #SLOT "b") \
+    "s_branch 3" #SLOT "b\n"                                     \
+    "9" #SLOT ":\n\ts_mov_b32 %[slot], " #SLOT "\n\ts_branch 7f\n"
+#define BLANCE_PL_SLOW_LAST(SLOT)                                \
+    BLANCE_PL_SLOW_HEAD(SLOT)                                    \
+    BLANCE_PL_WORDS_LAST(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT)    \
+    "9" #SLOT ":\n\ts_mov_b32 %[slot], " #SLOT "\n\ts_branch 7f\n"
+#define BLANCE_PL_EXIT "7:\n\ts_mov_b64 %[elo], s[44:45]\n\ts_mov_b64 %[ehi], s[46:47]\n"
+#define BLANCE_PL_OPERANDS                                                                                          \
+    [p0l] "+s"(P[0][0]), [p0h] "+s"(P[0][1]), [p1l] "+s"(P[1][0]), [p1h] "+s"(P[1][1]), [p2l] "+s"(P[2][0]),         \
+    [p2h] "+s"(P[2][1]), [r] "+s"(r), [slot] "=&s"(slot), [elo] "=&s"(E[0]), [ehi] "=&s"(E[1])
+#define BLANCE_PL_INPUTS                                                                                            \
+    [nb] "s"(nb), [ex0] "v"(ex[0]), [ex1] "v"(ex[1]), [ex2] "v"(ex[2]), [ex3] "v"(ex[3]),                           \
+    [lm00] "v"(lm[0][0]), [lm01] "v"(lm[0][1]), [lm02] "v"(lm[0][2]), [lm03] "v"(lm[0][3]),                         \
+    [lm10] "v"(lm[1][0]), [lm11] "v"(lm[1][1]), [lm12] "v"(lm[1][2]), [lm13] "v"(lm[1][3])
+#define BLANCE_PL_CLOBBER "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "m0", "scc"
+
+template <int K>
+__device__ __forceinline__ void planes_walk_w2(unsigned long long (&P)[kPlanes][2], unsigned long long (&E)[2], int& r, int nb,
+                                               int& slot, const unsigned (&ex)[4], const unsigned (&lm)[2][4], int (&my_w)[K]) {
+    if constexpr (K == 1) {
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_LAST(0) BLANCE_PL_SLOW_LAST(0) BLANCE_PL_EXIT
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
+    } else if constexpr (K == 2) {
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0) BLANCE_PL_PICK_LAST(1) BLANCE_PL_SLOW_MORE(0) BLANCE_PL_SLOW_LAST(1) BLANCE_PL_EXIT
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
+    } else if constexpr (K == 3) {
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0) BLANCE_PL_PICK_MORE(1) BLANCE_PL_PICK_LAST(2)
+                     BLANCE_PL_SLOW_MORE(0) BLANCE_PL_SLOW_MORE(1) BLANCE_PL_SLOW_LAST(2) BLANCE_PL_EXIT
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
+    } else {
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0) BLANCE_PL_PICK_MORE(1) BLANCE_PL_PICK_MORE(2) BLANCE_PL_PICK_LAST(3)
+                     BLANCE_PL_SLOW_MORE(0) BLANCE_PL_SLOW_MORE(1) BLANCE_PL_SLOW_MORE(2) BLANCE_PL_SLOW_LAST(3) BLANCE_PL_EXIT
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2]), [w3] "+v"(my_w[3])
+                     : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
+    }
+}
+#endif
+
+template <int W, int K>
+__global__ __launch_bounds__(64) void k_pass_chain_planes(ChainParams q) {
+    BLANCE_DYN_LDS(lds);
+    typedef unsigned long long u64;
+    const int lane = threadIdx.x;
+    const int rg = q.region_base + blockIdx.x;
+    const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
+    const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
+    if (cbeg >= cend) return;
+    const int k = K;
+    int* nidL = (int*)lds;                                 // [64 W] node id of a leaf
+    unsigned* cmL = (unsigned*)(nidL + 64 * W);            // [64 W classes][2 W words] leaves of an exclude class
+    bool bad = size > 64 * W || q.k != K || q.NP != 0 || q.flat != 0 || (q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1]);
+    for (int i = lane; i < 64 * W * 2 * W; i += 64) cmL[i] = 0;
+    for (int i = lane; i < 64 * W; i += 64) nidL[i] = -2;
+    __syncthreads();
+    int nid[W], cntv[W], cls[W];
+    unsigned alive_m = 0;
+    int mx = 0;
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+        const int pos = lo + lane + 64 * u;
+        nid[u] = -2; cntv[u] = 0; cls[u] = -1;
+        if (pos < hi) {
+            const int n = q.leaf_node[pos];
+            if (n >= 0) {
+                nid[u] = n;
+                cntv[u] = q.cnt[q.s * q.NX + n];
+                if (q.node_has_weight[n]) bad = true;
+                if (n < q.N && q.alive[n]) alive_m |= 1u << u;
+                cls[u] = q.leaf_cls[pos];
+                if (cls[u] >= 64 * W) bad = true;
+                if (cls[u] >= 0) atomicOr((int*)&cmL[cls[u] * 2 * W + 2 * u + (lane >> 5)], (int)(1u << (lane & 31)));
+                else if ((alive_m >> u) & 1) bad = true;      // a live leaf without an exclude class
+            }
+            const int cs = q.cls_size[pos];                // sizes are stored per class index at reg_lo + c
+            if (cs > mx) mx = cs;
+            nidL[lane + 64 * u] = nid[u];
+        }
+    }
+    __syncthreads();
+    {   // node ids must rise with the leaf index; k classes must never cover the region
+        int prev = -1;
+        bool mono = true;
+        if (lane == 0)
+            for (int i = 0; i < size; i++) { const int n = nidL[i]; if (n >= 0) { if (n <= prev) mono = false; prev = n; } }
+        if (!__builtin_amdgcn_readlane(mono ? 1 : 0, 0)) bad = true;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { int t = __shfl_xor(mx, off, 64); mx = t > mx ? t : mx; }
+        if ((long long)mx * (k + 1) >= (long long)size) bad = true;
+    }
+    // the one partition weight of this chain, the lowest count, every live leaf's level above it
+    const int w0 = q.crec[(size_t)cbeg * kCW + 1];
+    int base_cnt = INT_MAX;
+#pragma unroll
+    for (int u = 0; u < W; u++) if (((alive_m >> u) & 1) && cntv[u] < base_cnt) base_cnt = cntv[u];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { int t = __shfl_xor(base_cnt, off, 64); base_cnt = t < base_cnt ? t : base_cnt; }
+    if (w0 <= 0 || w0 > (1 << 20) || base_cnt == INT_MAX) bad = true;
+    int level[W];
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+        level[u] = -1;
+        if (((alive_m >> u) & 1) && !bad) {
+            const long long dlt = (long long)cntv[u] - base_cnt;
+            if (dlt % w0 != 0 || dlt / w0 >= kPlanes) bad = true;
+            else level[u] = (int)(dlt / w0);
+        }
+    }
+    if (__ballot(bad)) {
+        if (lane == 0) q.flags[1] = 1;
+        return;
+    }
+    // planes (wave-uniform: SGPRs), and for every leaf the mask of its exclude class
+    u64 P[kPlanes][W];
+#pragma unroll
+    for (int j = 0; j < kPlanes; j++)
+#pragma unroll
+        for (int u = 0; u < W; u++) P[j][u] = __ballot(level[u] == j);
+    unsigned lm[W][2 * W];
+#pragma unroll
+    for (int u = 0; u < W; u++)
+#pragma unroll
+        for (int x = 0; x < 2 * W; x++) lm[u][x] = cls[u] >= 0 ? cmL[cls[u] * 2 * W + x] : 0u;
+    int shifts = 0;                                        // planes dropped below: plane j is level shifts + j
+    bool failed = false;
+    PH_DECL;
+#ifdef BLANCE_PHASE_PROF
+    int ph_exits = 0;
+#endif
+    // step records of a batch, lane r: step r -- weight, counts word, top's exclude class, higher priority leaves
+    int rw, rc5, rtc, rhv[kChainHigh];
+    {
+        const int nb0 = cend - cbeg < 64 ? cend - cbeg : 64;
+        const int* rp = q.crec + (size_t)(cbeg + (lane < nb0 ? lane : 0)) * kCW;
+        rw = rp[1]; rc5 = rp[5]; rtc = rp[6];
+#pragma unroll
+        for (int j = 0; j < kChainHigh; j++) rhv[j] = rp[kCHigh + j];
+    }
+    for (int base = cbeg; base < cend; base += 64) {
+        const int nb = cend - base < 64 ? cend - base : 64;
+        const bool active = lane < nb;
+        const int w = rw, c5 = rc5, tcv = rtc;
+        int hv[kChainHigh];
+#pragma unroll
+        for (int j = 0; j < kChainHigh; j++) hv[j] = rhv[j];
+        if (base + 64 < cend) {                            // the next batch's words travel while this one is walked
+            const int nbn = cend - base - 64 < 64 ? cend - base - 64 : 64;
+            const int* rp = q.crec + (size_t)(base + 64 + (lane < nbn ? lane : 0)) * kCW;
+            rw = rp[1]; rc5 = rp[5]; rtc = rp[6];
+#pragma unroll
+            for (int j = 0; j < kChainHigh; j++) rhv[j] = rp[kCHigh + j];
+        }
+        const bool blank = (c5 & 0xff00ff) == 0 && w == w0 && tcv >= 0 && tcv < 64 * W;
+        if (__ballot(active && !blank)) { failed = true; break; }
+        // the step's exclude mask: its top priority node's class, its higher priority nodes (plan.go:146-154)
+        unsigned ex[2 * W];
+#pragma unroll
+        for (int x = 0; x < 2 * W; x++) ex[x] = active ? cmL[tcv * 2 * W + x] : 0u;
+        if (__ballot(active && (c5 & 0xff00) != 0)) {
+#pragma unroll
+            for (int j = 0; j < kChainHigh; j++) {
+                const int h = hv[j];
+#pragma unroll
+                for (int x = 0; x < 2 * W; x++) ex[x] |= (h >= 0 && (h >> 5) == x) ? 1u << (h & 31) : 0u;
+            }
+        }
+        int my_w[K];                                       // lane r keeps the picks of step r
+#pragma unroll
+        for (int c = 0; c < K; c++) my_w[c] = 0;
+        int trouble = 0;                                   // sign bit: a pick found no candidate / left the planes
+        int r = 0;
+        PH(0);
+        while (r < nb) {
+            u64 E[W];
+            int slot0 = 0;
+            bool resumed = false;
+#ifndef BLANCE_SIMT_EMU
+            if constexpr (W == 2) {                        // the scalar loop; comes back where a pick needs more than plane 0
+                planes_walk_w2<K>(P, E, r, nb, slot0, ex, lm, my_w);
+                PH(1);
+                if (r >= nb) break;
+                resumed = true;
+#ifdef BLANCE_PHASE_PROF
+                ph_exits++;
+#endif
+            }
+#endif
+            if (!resumed) {
+#pragma unroll
+                for (int u = 0; u < W; u++)
+                    E[u] = (u64)(unsigned)__builtin_amdgcn_readlane((int)ex[2 * u], r) |
+                           ((u64)(unsigned)__builtin_amdgcn_readlane((int)ex[2 * u + 1], r) << 32);
+            }
+#pragma unroll
+            for (int slot = 0; slot < K; slot++) {
+                if (slot >= slot0) {
+                    // the next pick also avoids this pick's class (plan.go:185-212)
+                    const int f = slot + 1 < K ? planes_pick_from<W, 0, true>(P, E, lm) : planes_pick_from<W, 0, false>(P, E, lm);
+                    trouble |= f;
+                    my_w[slot] = write_lane(f, r, my_w[slot]);
+                }
+            }
+            u64 p0 = 0;
+#pragma unroll
+            for (int u = 0; u < W; u++) p0 |= P[0][u];
+            if (p0 == 0) {                                 // nobody left on the lowest level: drop it
+#pragma unroll
+                for (int j = 0; j + 1 < kPlanes; j++)
+#pragma unroll
+                    for (int u = 0; u < W; u++) P[j][u] = P[j + 1][u];
+#pragma unroll
+                for (int u = 0; u < W; u++) P[kPlanes - 1][u] = 0;
+                shifts++;
+            }
+            r++;
+            PH(2);
+        }
+        if (trouble < 0 || shifts > (1 << 24)) { failed = true; break; }
+        if (active) {
+            int32_t* o = q.out + (size_t)(base + lane) * q.OW;
+            o[0] = K;
+#pragma unroll
+            for (int c = 0; c < K; c++) o[1 + c] = nidL[my_w[c]];
+        }
+        PH(3);
+    }
+#ifdef BLANCE_PHASE_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("[planes] %d steps, %d returns of the scalar loop, %d planes dropped\n", cend - cbeg, ph_exits, shifts);
+#endif
+    PH_DUMP(cend - cbeg);
+    if (failed) {
+        if (lane == 0) q.flags[1] = 1;
+        return;
+    }
+    // every region must succeed before any of them may publish its counters: publish to
+    // the scratch copy; the host commits it when no chain failed
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+        if (nid[u] < 0) continue;
+        int c = cntv[u];
+#pragma unroll
+        for (int j = 0; j < kPlanes; j++)
+            if ((P[j][u] >> lane) & 1) c = (int)((long long)base_cnt + (long long)(shifts + j) * w0);
+        q.cnt_out[q.s * q.NX + nid[u]] = c;
+    }
+}
+
 }  // namespace blance

@@ -217,16 +217,12 @@ __global__ void k_chain_orphans(DevProblem d, int m, int top_state, const int32_
 
 // Compact chain records (layout: blance_kernels.h): the step's nodes as leaf
 // indices local to its region.  Steps the chain kernel cannot represent raise flags[0].
-__global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
-                               const int32_t* chain_oi,
-                               const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
-                               const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
-                               const int32_t* leaf_cls, const int32_t* cls_size, int flat, int32_t* crec,
-                               int32_t* flags) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.P) return;
-    int p = chain_order[i];
-    int32_t* r = crec + (size_t)i * kCW;
+// one step's compact record (24 words at r)
+__device__ __forceinline__ void gather_chain_record(const DevProblem& d, int m, int top_state, int higher_mask, int p, int oi,
+                                                    const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
+                                                    const int32_t* node_leaf_pos, const int32_t* node_region,
+                                                    const int32_t* reg_lo, const int32_t* leaf_cls, const int32_t* cls_size,
+                                                    int flat, int32_t* r, int32_t* flags) {
     for (int j = 0; j < kCW; j++) r[j] = -1;
     int w = 1;
     double stick = 1.5;
@@ -234,7 +230,7 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
         if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
         else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
     }
-    r[0] = chain_oi ? chain_oi[i] : i; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+    r[0] = oi; r[1] = w; r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
     int idxT = p * d.M + top_state;
     int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
     int rg = flat ? 0 : (top >= 0 ? node_region[top] : -1);
@@ -289,33 +285,58 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
     if (bad) flags[0] = 1;
 }
 
-// exclusive scan of n ints by one workgroup of 1024 threads: tiles of 8192
-// elements, 8 contiguous per thread (coalesced), carry across tiles
-__global__ __launch_bounds__(1024) void k_scan_excl(int n, int32_t* data) {
+__global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
+                               const int32_t* chain_oi,
+                               const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
+                               const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
+                               const int32_t* leaf_cls, const int32_t* cls_size, int flat, int32_t* crec,
+                               int32_t* flags) {
+    // a thread builds its record in LDS (row stride kCW + 1: no bank conflicts); the workgroup then writes its
+    // 256 records as one contiguous block -- per-thread 24-word rows written straight to HBM cost 3.7 times
+    // their bytes in write traffic (rocprofv3 WRITE_SIZE, round 2)
     BLANCE_DYN_LDS(lds);
-    int* wsum = (int*)lds;                       // [16] wave totals, [16] carry
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + tid;
+    int32_t* r = (int32_t*)lds + tid * (kCW + 1);
+    if (i < d.P) gather_chain_record(d, m, top_state, higher_mask, chain_order[i], chain_oi ? chain_oi[i] : i, state_stickiness,
+                                     state_has_stickiness, node_leaf_pos, node_region, reg_lo, leaf_cls, cls_size, flat, r, flags);
+    __syncthreads();
+    const int first = blockIdx.x * blockDim.x;
+    const int n_here = d.P - first < (int)blockDim.x ? d.P - first : (int)blockDim.x;
+    for (int j = tid; j < n_here * kCW; j += blockDim.x)
+        crec[(size_t)first * kCW + j] = ((const int32_t*)lds)[(j / kCW) * (kCW + 1) + j % kCW];
+}
+
+
+// Exclusive scan of n ints.  One tile = 8192 elements of one workgroup of 1024 threads, 8 contiguous
+// per thread (coalesced).  Short arrays: k_scan_excl, one workgroup carrying across its tiles.  Long
+// arrays, three launches that fill the chip: k_scan_tile_sums (a total per tile) -> k_scan_excl over
+// the totals -> k_scan_apply (every tile scans itself from its carry).
+constexpr int kScanTile = 8192;
+
+// scans tile [base, base + 8192) in place from `carry` (write = true) and returns the tile's total
+__device__ __forceinline__ int scan_tile(int n, int32_t* data, int base, int carry, bool write, int* wsum) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int carry = 0;
-    for (int base = 0; base < n; base += 8192) {
-        int v[8];
-        int sum = 0;
+    int v[8];
+    int sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int i = base + tid * 8 + j;
-            v[j] = i < n ? data[i] : 0;
-            sum += v[j];
-        }
-        int incl = sum;                          // inclusive scan of the thread sums inside the wave
+    for (int j = 0; j < 8; j++) {
+        int i = base + tid * 8 + j;
+        v[j] = i < n ? data[i] : 0;
+        sum += v[j];
+    }
+    int incl = sum;                          // inclusive scan of the thread sums inside the wave
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int wbase = 0, total = 0;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 16; w++) { int x = wsum[w]; if (w < wave) wbase += x; total += x; }
+    for (int w = 0; w < 16; w++) { int x = wsum[w]; if (w < wave) wbase += x; total += x; }
+    if (write) {
         int acc = carry + wbase + incl - sum;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -323,9 +344,26 @@ __global__ __launch_bounds__(1024) void k_scan_excl(int n, int32_t* data) {
             if (i < n) data[i] = acc;
             acc += v[j];
         }
-        carry += total;
-        __syncthreads();
     }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_excl(int n, int32_t* data) {
+    BLANCE_DYN_LDS(lds);
+    int carry = 0;
+    for (int base = 0; base < n; base += kScanTile) carry += scan_tile(n, data, base, carry, true, (int*)lds);
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(int n, int32_t* data, int32_t* sums) {
+    BLANCE_DYN_LDS(lds);
+    const int total = scan_tile(n, data, blockIdx.x * kScanTile, 0, false, (int*)lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(int n, int32_t* data, const int32_t* sums) {
+    BLANCE_DYN_LDS(lds);
+    (void)scan_tile(n, data, blockIdx.x * kScanTile, sums[blockIdx.x], true, (int*)lds);
 }
 
 __global__ void k_region_offsets(int B, int n_chunks, int P, const int32_t* offsets, int32_t* reg_off) {
@@ -385,16 +423,17 @@ __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32
 
 // Apply the pass's choices to the live lists (plan.go:290-299); list edits only
 // touch the step's own partition, so this runs in parallel after the pass.
-__global__ void k_scatter(DevProblem d, int m, int RW, int OW, const int32_t* order, const int32_t* rec,
-                          const int32_t* out) {
+__global__ void k_scatter(DevProblem d, int m, int OW, const int32_t* order, const int32_t* out) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
     if (oi >= d.P) return;
     int p = order[oi];
-    const int32_t* r = rec + (size_t)oi * RW;
     const int32_t* o = out + (size_t)oi * OW;
     int n_out = o[0] & 0xffff, is_nil = o[0] >> 16;
-    const int32_t* old_s = r + kRecHead + m * (1 + d.L);
-    int n_old = (old_s[0] >> 16) == kListAbsent ? 0 : (old_s[0] & 0xffff);
+    // the partition's list in this state as the pass saw it: the pass itself only wrote `out`
+    const int idx_m = p * d.M + m;
+    // (that list is only rewritten at the end of this function)
+    const int n_old = d.live_kind[idx_m] == kListAbsent ? 0 : d.live_len[idx_m];
+    const int32_t* old_l = d.live + (size_t)idx_m * d.L;
     for (int t = 0; t < d.M; t++) {
         int idx = p * d.M + t;
         if (t == m) continue;
@@ -404,7 +443,7 @@ __global__ void k_scatter(DevProblem d, int m, int RW, int OW, const int32_t* or
         for (int i = 0; i < len; i++) {
             int x = lst[i];
             bool rm = false;
-            for (int j = 0; j < n_old; j++) rm |= old_s[1 + j] == x;
+            for (int j = 0; j < n_old; j++) rm |= old_l[j] == x;
             for (int j = 0; j < n_out; j++) rm |= o[1 + j] == x;
             if (!rm) lst[w++] = x;
         }
@@ -421,9 +460,10 @@ __global__ void k_scatter(DevProblem d, int m, int RW, int OW, const int32_t* or
 // partitionsToAssign[name] = nextMap[name] (plan.go:49-52).
 __global__ void k_converge(DevProblem d, int32_t* not_match) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.P) return;
+    const bool in_range = p < d.P;
+    if (!in_range) p = d.P - 1;                      // keep the wave whole for the ballot below
     bool diff = !d.in_prev[p] || d.never_equal[p];
-    for (int m = 0; m < d.M; m++) {
+    for (int m = 0; m < d.M && in_range; m++) {
         int idx = p * d.M + m;
         int len = d.live_len[idx];
         if (d.live_kind[idx] != d.prv_kind[idx] || len != d.prv_len[idx]) diff = true;
@@ -435,9 +475,14 @@ __global__ void k_converge(DevProblem d, int32_t* not_match) {
         d.prv_len[idx] = len;
         d.prv_kind[idx] = d.live_kind[idx];
     }
-    d.in_prev[p] = 1;
-    d.never_equal[p] = 0;
-    if (diff) atomicOr(not_match, 1);
+    if (in_range) {
+        d.in_prev[p] = 1;
+        d.never_equal[p] = 0;
+    }
+    // one word for the whole sweep: one atomic per wave, and none once it is set (in a first sweep
+    // every partition differs)
+    const unsigned long long dm = __ballot(in_range && diff);
+    if (dm && (int)(threadIdx.x & 63) == __ffsll((long long)dm) - 1 && *(volatile int32_t*)not_match == 0) atomicOr(not_match, 1);
 }
 
 

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libblance_hip.so")
 EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", "blance_validate",
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
            "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get",
-           "blance_comm_unique_id", "blance_comm_init_rccl", "blance_comm_set"]
+           "blance_comm_unique_id", "blance_comm_init_rccl", "blance_comm_set", "blance_comm_stats",
+           "blance_is_emulated"]
 
 _libs = {}
 
@@ -66,6 +67,9 @@ def load_library(path=None):
     lib.blance_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.blance_comm_set.restype = C.c_int
     lib.blance_comm_set.argtypes = [C.c_void_p, C.POINTER(abi.Comm)]
+    lib.blance_comm_stats.restype = C.c_int
+    lib.blance_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.blance_is_emulated.restype = C.c_int
     if lib.blance_abi_version() != abi.ABI_VERSION:
         raise ImportError("ABI version mismatch")
     _libs[path] = lib
@@ -76,7 +80,7 @@ class Planner:
     """One blance_ctx: a planner bound to one gfx950 device."""
 
     def __init__(self, device_id=0, engine=abi.ENGINE_AUTO, lib_path=None, force_threads=0,
-                 chain_min_parts=0, seq_speculation=True, tree="auto"):
+                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True):
         self.lib = load_library(lib_path)
         opt = abi.Options()
         opt.engine = engine
@@ -86,7 +90,8 @@ class Planner:
         # test knobs: 1 = k_pass_seq without verified stays; k_pass_tree (flat passes): 2 = never,
         # 4 = every general step scores all nodes, 8 = also when a k_pass_seq workgroup size is forced,
         # 16 = every general step decodes its record (none served from the validating lane's registers)
-        opt.reserved[2] = (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
+        # 32 = the all-blank chain pass on k_pass_chain_blank (lane minima) instead of k_pass_chain_planes
+        opt.reserved[2] = (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))
@@ -121,20 +126,33 @@ class Planner:
         self._check(self.lib.blance_comm_init_rccl(self._h, world, rank, ident))
         return world
 
-    def comm_set_callback(self, rank, n_ranks, allreduce):
-        """A caller-provided collective: allreduce(address, count) sums `count` int32 values in place
-        over the ranks (device memory of this context; host memory under the SIMT emulator)."""
-        def _cb(_user, ptr, count):
-            try:
-                allreduce(ptr, count)
-                return 0
-            except Exception:                      # no exception may cross the C boundary
-                import traceback
-                traceback.print_exc()
-                return 1
-        self._comm_cb = abi.ALLREDUCE_FN(_cb)       # keep the trampoline alive
-        comm = abi.Comm(rank, n_ranks, self._comm_cb, None)
+    def comm_set_callback(self, rank, n_ranks, allreduce, allgather=None):
+        """An embedder's collectives: allreduce(address, count) sums `count` int32 values in place over the
+        ranks; allgather(address, count_per_rank) completes n_ranks blocks of which this rank's is filled in
+        (None: the library sums zero-padded outputs with allreduce instead).  The addresses are device
+        memory of this context (host memory under the SIMT emulator)."""
+        def _wrap(fn):
+            def _cb(_user, ptr, count):
+                try:
+                    fn(ptr, count)
+                    return 0
+                except Exception:                      # no exception may cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return abi.ALLREDUCE_FN(_cb)
+        self._comm_cb = (_wrap(allreduce), _wrap(allgather) if allgather else abi.ALLREDUCE_FN())   # keep the trampolines alive
+        comm = abi.Comm(rank, n_ranks, self._comm_cb[0], None, self._comm_cb[1])
         self._check(self.lib.blance_comm_set(self._h, C.byref(comm)))
+
+    def comm_stats(self):
+        """(collectives made, int32 words moved) by this context's sharded plans so far."""
+        calls, words = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.blance_comm_stats(self._h, C.byref(calls), C.byref(words)))
+        return int(calls.value), int(words.value)
+
+    def is_emulated(self):
+        return bool(self.lib.blance_is_emulated())
 
     def comm_clear(self):
         self._check(self.lib.blance_comm_set(self._h, None))

@@ -1,32 +1,50 @@
 // SURVEY.md 8(f-4): the orchestrator's move selection at a million partitions.  Host-side Go by the north
 // star -- no device code.  ADD to package blance; the three call-site changes are listed below.  Like the
-// rest of go/blance it cannot be compiled in this repository's build image.
+// rest of go/blance it cannot be compiled in this repository's build image; its compiled twin, structure for
+// structure, is blance_amd/csrc/host/move_index.hpp, checked against the reference's rescan by a randomised
+// simulation of the supply rounds (move_index_sim.cpp, tests/test_move_index.py).
 //
 // findAvailableMovesUnlocked (orchestrate.go:749-763) rebuilds, every supply round, a map node -> the
 // partitions whose NEXT move goes to that node, by walking all of o.mapPartitionToNextMoves: O(P) per
-// round, and the number of rounds grows with P, so a rebalance of a million partitions is quadratic
-// there once the planner in front of it takes milliseconds.  The index below keeps the same map
-// incrementally: a partition sits in the bucket of the node of its next move and changes bucket only when
-// its Next advances (orchestrate.go:689) -- O(1) per completed move, nothing per round.
+// round; filterNextPlausibleMovesForNode (orchestrate.go:482-504) then materialises a node's whole bucket
+// once per slot for FindMoveFunc.  moveIndex keeps the buckets incrementally instead:
+//   * a partition sits in bucket (node, op) of its next move; position tables make removal a swap -- O(1)
+//     per completed move (orchestrate.go:689), nothing per round;
+//   * nodes with pending moves are a dense list: a round touches those nodes only;
+//   * lowestWeight(node, count) answers filterNextPlausibleMovesForNode for the default FindMoveFunc
+//     LowestWeightPartitionMoveForNode (orchestrate.go:174-184): `count` moves in ascending MoveOpWeight.  The
+//     order among equal weights is unspecified in the reference (it ranges over a Go map, orchestrate.go:755);
+//   * bucket(node) lists a node's pending partitions for an application FindMoveFunc.
 //
 // Call sites (all under o.m, like the fields they replace):
 //   * OrchestrateMoves, after mapPartitionToNextMoves is filled (orchestrate.go:271-290):
 //         o.moveIndex = newMoveIndex(mapPartitionToNextMoves)
-//   * runSupplyMoves, instead of o.findAvailableMovesUnlocked() (orchestrate.go:521):
-//         availableMoves := o.moveIndex.available()
+//   * runSupplyMoves, instead of o.findAvailableMovesUnlocked() (orchestrate.go:521) and of the per-node
+//     filterNextPlausibleMovesForNode call (orchestrate.go:549):
+//         for _, node := range o.moveIndex.activeNodes() { nxt := o.moveIndex.lowestWeight(node, count) ... }
+//     (with an application FindMoveFunc: filterNextPlausibleMovesForNode(node, o.moveIndex.bucket(node)))
 //   * where a move completes, next to nextMoves[i].Next++ (orchestrate.go:689):
-//         o.moveIndex.advanced(nextMoves[i], oldNode)      // oldNode = Moves[Next-1].Node
-// The order of the partitions inside a bucket is not specified by the reference (it ranges over a Go map);
-// findMove (orchestrate.go:158-177) picks by weight, not by position.
+//         o.moveIndex.advanced(nextMoves[i])
 
 package blance
 
+var moveOpClass = map[string]int{"promote": 0, "demote": 1, "add": 2, "del": 3} // ascending MoveOpWeight
+
+type moveIndexNode struct {
+	byOp      [4][]*NextMoves // partitions whose next move is (this node, op)
+	pending   int
+	activePos int // position in moveIndex.active, -1 if pending == 0
+}
+
 type moveIndex struct {
-	buckets map[string]map[*NextMoves]struct{} // node -> partitions whose next move targets it
+	nodes  map[string]*moveIndexNode
+	active []string           // nodes with pending > 0
+	where  map[*NextMoves]int // position inside its bucket
+	total  int
 }
 
 func newMoveIndex(all map[string]*NextMoves) *moveIndex {
-	ix := &moveIndex{buckets: map[string]map[*NextMoves]struct{}{}}
+	ix := &moveIndex{nodes: map[string]*moveIndexNode{}, where: make(map[*NextMoves]int, len(all))}
 	for _, nm := range all {
 		ix.insert(nm)
 	}
@@ -37,36 +55,82 @@ func (ix *moveIndex) insert(nm *NextMoves) {
 	if nm.Next >= len(nm.Moves) {
 		return // nothing left to do for this partition
 	}
-	node := nm.Moves[nm.Next].Node
-	b := ix.buckets[node]
-	if b == nil {
-		b = map[*NextMoves]struct{}{}
-		ix.buckets[node] = b
+	m := nm.Moves[nm.Next]
+	n := ix.nodes[m.Node]
+	if n == nil {
+		n = &moveIndexNode{activePos: -1}
+		ix.nodes[m.Node] = n
 	}
-	b[nm] = struct{}{}
+	op := moveOpClass[m.Op]
+	ix.where[nm] = len(n.byOp[op])
+	n.byOp[op] = append(n.byOp[op], nm)
+	if n.pending == 0 {
+		n.activePos = len(ix.active)
+		ix.active = append(ix.active, m.Node)
+	}
+	n.pending++
+	ix.total++
 }
 
-// advanced re-files a partition whose Next was just incremented; oldNode is the node of the move that
-// completed (its bucket held the partition until now).
-func (ix *moveIndex) advanced(nm *NextMoves, oldNode string) {
-	if b := ix.buckets[oldNode]; b != nil {
-		delete(b, nm)
-		if len(b) == 0 {
-			delete(ix.buckets, oldNode)
-		}
+func (ix *moveIndex) remove(nm *NextMoves, node string, opName string) {
+	n := ix.nodes[node]
+	op := moveOpClass[opName]
+	b := n.byOp[op]
+	at, last := ix.where[nm], b[len(b)-1]
+	b[at] = last
+	ix.where[last] = at
+	b[len(b)-1] = nil
+	n.byOp[op] = b[:len(b)-1]
+	delete(ix.where, nm)
+	n.pending--
+	if n.pending == 0 {
+		ln := ix.active[len(ix.active)-1]
+		ix.active[n.activePos] = ln
+		ix.nodes[ln].activePos = n.activePos
+		ix.active = ix.active[:len(ix.active)-1]
+		n.activePos = -1
 	}
+	ix.total--
+}
+
+// advanced re-files a partition whose Next was just incremented (orchestrate.go:689).
+func (ix *moveIndex) advanced(nm *NextMoves) {
+	old := nm.Moves[nm.Next-1]
+	ix.remove(nm, old.Node, old.Op)
 	ix.insert(nm)
 }
 
-// available is findAvailableMovesUnlocked's result: keyed by node name, the partitions with a next move for it.
-func (ix *moveIndex) available() map[string][]*NextMoves {
-	out := make(map[string][]*NextMoves, len(ix.buckets))
-	for node, b := range ix.buckets {
-		lst := make([]*NextMoves, 0, len(b))
-		for nm := range b {
-			lst = append(lst, nm)
+// activeNodes: the key set of findAvailableMovesUnlocked's map.
+func (ix *moveIndex) activeNodes() []string { return ix.active }
+
+// lowestWeight: up to count partitions whose next move goes to node, ascending MoveOpWeight.
+func (ix *moveIndex) lowestWeight(node string, count int) []*NextMoves {
+	n := ix.nodes[node]
+	if n == nil {
+		return nil
+	}
+	if count <= 0 {
+		count = 1 // orchestrate.go:485-487
+	}
+	var out []*NextMoves
+	for op := 0; op < 4 && count > 0; op++ {
+		for i := 0; i < len(n.byOp[op]) && count > 0; i++ {
+			out = append(out, n.byOp[op][i])
+			count--
 		}
-		out[node] = lst
+	}
+	return out
+}
+
+// bucket: every partition whose next move goes to node (findAvailableMovesUnlocked()[node]).
+func (ix *moveIndex) bucket(node string) []*NextMoves {
+	n := ix.nodes[node]
+	if n == nil {
+		return nil
+	}
+	out := make([]*NextMoves, 0, n.pending)
+	for op := 0; op < 4; op++ {
+		out = append(out, n.byOp[op]...)
 	}
 	return out
 }

@@ -14,8 +14,12 @@
  * mutations of plan.go:49-55.  See INTEGRATION.md for the cgo stub.
  *
  * ABI rules: plain C, caller owns every buffer, nothing is retained after a
- * call returns (cgo pointer rule), no callbacks, no exceptions cross the
- * boundary, every entry point returns an int status (0 = ok, <0 = error).
+ * call returns (cgo pointer rule), no exceptions cross the boundary, every
+ * entry point returns an int status (0 = ok, <0 = error).  The planning entry
+ * points take no callbacks; the one function-pointer table of this header is
+ * the struct blance_comm: an embedder's own collectives for a plan sharded over several
+ * ranks; a production multi-GPU caller uses blance_comm_init_rccl instead
+ * and passes none.
  *
  * Id spaces
  *   node id      0..n_nodes-1 = position in nodesAll (plan.go:72-75; names must
@@ -43,7 +47,7 @@
 extern "C" {
 #endif
 
-#define BLANCE_ABI_VERSION 2
+#define BLANCE_ABI_VERSION 3
 
 /* status codes */
 #define BLANCE_OK                0
@@ -260,26 +264,43 @@ int blance_plan_stats_get(blance_ctx* ctx, blance_plan_stats* stats);
 /* ---- one plan on several GPUs (BASELINE.json config 4) ------------------------------------
  * The steps of a state pass that runs as region chains (one chain per hierarchy region)
  * shard over the ranks by region: every rank holds the whole problem (upload the same problem on
- * every rank), runs the chains of its slice of the regions, and the ranks exchange, once per such
- * pass, the pass outputs and the change of the per-node load vector (stateNodeCounts, plan.go:94)
- * by an int32 sum all-reduce -- pass boundaries are the only exact exchange points of
- * plan.go:253-303.  Everything else (flat passes, ordering, convergence test) is computed by every
- * rank identically, so all ranks return the same result, bit-identical to a single-rank plan.
+ * every rank) and runs the chains of its contiguous slice of the regions.  Per such pass the ranks
+ * make exactly TWO collectives -- pass boundaries are the only exact exchange points of
+ * plan.go:253-303:
+ *   A. one int32 sum all-reduce of [8 pass flags | change of the per-node load vector
+ *      (stateNodeCounts, plan.go:94)]: (n_states + 1) * n_nodes_ext + 8 words;
+ *   B. one all-gather of the pass outputs: a rank's steps are contiguous in chain order, every
+ *      rank contributes its slice (padded to the longest slice).
+ * Everything else (flat passes, ordering, convergence test) is computed by every rank identically,
+ * so all ranks return the same result, bit-identical to a single-rank plan.
  * Collectives: the library's own RCCL communicator (blance_comm_init_rccl; one process per GPU,
  * the 128-byte id of blance_comm_unique_id() made on rank 0 and handed to the others by the host),
- * or a caller-provided all-reduce (blance_comm_set; used by the GPU-less tests over gloo).
- * Every rank must make the same sequence of plan calls. */
+ * or an embedder's (blance_comm_set; used by the tests: gloo ranks over the SIMT emulator, and G
+ * contexts on ONE MI355X whose buffers the hook sums / gathers).
+ * Every rank must make the same sequence of plan calls.  A rank that fails before collective A
+ * still takes part in it with a poison flag, so that all ranks return BLANCE_ERR_COMM together;
+ * after any failed sharded call the communicator is invalid (destroy the contexts). */
 typedef struct blance_comm {
     int32_t rank, n_ranks;
     /* in-place sum over the ranks of `count` int32 values at `device_buf` (device memory of this
      * context); called between kernels with the stream idle; 0 = ok */
     int (*allreduce_sum_i32)(void* user, int32_t* device_buf, int64_t count);
     void* user;
+    /* in-place all-gather: `device_buf` holds n_ranks blocks of `count_per_rank` int32 values, this
+     * rank's block (at rank * count_per_rank) is filled in; on return every block is.  May be NULL:
+     * the outputs are then summed with allreduce_sum_i32 (every rank's foreign slices zeroed). */
+    int (*allgather_i32)(void* user, int32_t* device_buf, int64_t count_per_rank);
 } blance_comm;
 
 int blance_comm_unique_id(void* id_out_128 /* 128 bytes */);
 int blance_comm_init_rccl(blance_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id_128);
 int blance_comm_set(blance_ctx* ctx, const blance_comm* comm /* NULL: back to a single rank */);
+/* collectives made / int32 words moved by this context's sharded plans so far */
+int blance_comm_stats(blance_ctx* ctx, int64_t* calls, int64_t* words);
+
+/* 1 if this library is the GPU-less SIMT emulator build of the tests (its "device" memory is host
+ * memory), 0 for the gfx950 product. */
+int blance_is_emulated(void);
 
 /* Validate a problem without touching a device (sizes, id ranges, supported
  * envelope).  Same status codes as blance_plan. */

@@ -66,3 +66,22 @@ def edge_cases():
                                                         "replica": [{"includeLevel": 2, "excludeLevel": 1}]}}),
     ]
     return cases
+
+
+def sharded_cases():
+    """Problems whose replica pass runs as region chains over 2..8 regions (enough for plans sharded over up to
+    8 ranks): config 3's shape, a small-rack tree with 8 zones, and config 5's ingredients (Zipf partition
+    weights, node weights, stickiness) on a tree of 5 zones.  Returns (problems, rebalance case, its options):
+    problems[-1] is the initial plan of the rebalance case."""
+    from blance_amd import synth
+    cases = [synth.config_flat(3, P=300, N=256), synth.config_flat(3, P=700, N=300), synth.config_flat(2, P=300, N=20)]
+    c8 = synth.config_case(3, P=500, N=96)
+    c8["nodeHierarchy"] = synth.hierarchy_names(96, rack=4, racks_per_zone=3, zones_per_dc=4)
+    cases.append(synth.case_to_flat(c8))
+    c = synth.rebalance_case(P=300, N=60, hierarchy=True)
+    c["nodeHierarchy"] = synth.hierarchy_names(60, rack=3, racks_per_zone=4, zones_per_dc=2)
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
+    cases.append(problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts))
+    return cases, c, opts

@@ -205,3 +205,32 @@ def random_regular_case(seed, max_parts=60):
             "model": model, "booster": None, "seed": seed}
     case.update(opts)
     return case
+
+
+def random_flat_wide_case(seed, k=None):
+    """random_case() with a flat model of 3 or 4 copies in the second state (the shapes k_pass_tree<4> takes): no
+    hierarchy rules, enough nodes for the copies most of the time."""
+    rng = random.Random(seed * 7919 + 13)
+    c = random_case(seed, max_nodes=16, max_parts=40)
+    k = k or rng.choice([3, 4])
+    kind = rng.choice(["pr", "pr", "p", "prx"])
+    if kind == "p":
+        c["model"] = {"primary": {"priority": 0, "constraints": k}}
+    elif kind == "pr":
+        c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
+    else:
+        c["model"] = {"primary": {"priority": 0, "constraints": rng.choice([1, 2])},
+                      "replica": {"priority": 1, "constraints": k}, "zreadonly": {"priority": 2, "constraints": rng.choice([0, 1, 3])}}
+    c["hierarchyRules"] = None
+    c["modelStateConstraints"] = None
+    if c.get("stateStickiness"):
+        c["stateStickiness"] = {s: v for s, v in c["stateStickiness"].items() if s in c["model"]}
+    states = set(c["model"])
+
+    def trim(m):
+        for p in (m or {}).values():
+            p["nodesByState"] = {s: l for s, l in p["nodesByState"].items() if s in states or s == "dead"}
+    trim(c["prevMap"])
+    if not c["aliased"]:
+        trim(c["partitionsToAssign"])
+    return c

@@ -27,7 +27,7 @@ emu_switch:
 .size emu_switch, .-emu_switch
 )");
 namespace emu {
-Block* t_block = nullptr;
-dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+thread_local Block* t_block = nullptr;
+thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 }
 #include "../../blance_amd/csrc/blance_hip.hip"

@@ -64,8 +64,9 @@ struct Block {
     int cur = -1;
     std::function<void()> body;
 };
-extern Block* t_block;
-extern dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+// thread_local: several contexts may run kernels from several host threads (a fiber never leaves its OS thread)
+extern thread_local Block* t_block;
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 
 inline void barrier_wait(Barrier& b) {
     Block* blk = t_block;
@@ -120,7 +121,7 @@ void launch_threads(dim3 grid, dim3 block, size_t lds_bytes, F body) {
         t_blockIdx = dim3(b);
         for (unsigned t = 0; t < block.x; t++) {
             Fiber& f = blk.fibers[t];
-            static std::vector<unsigned char*> pool;
+            static thread_local std::vector<unsigned char*> pool;
             if (pool.size() <= t) pool.resize(t + 1, nullptr);
             if (!pool[t]) pool[t] = (unsigned char*)malloc(kStackBytes);
             f.stack = pool[t];

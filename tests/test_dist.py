@@ -1,8 +1,11 @@
-"""The N > 1 paths without GPUs, world size 2 over gloo:
-  * one plan sharded over two ranks (region chains split by region, int32 sum all-reduce of the pass
-    outputs and of the load-vector change after every such pass) gives the SAME digest on both
-    ranks as the single-rank plan and as the CPU oracle -- the kernels run on the SIMT emulator,
-    the collective is the caller-provided one of blance_comm_set;
+"""The N > 1 paths without GPUs:
+  * world size 2 over gloo: one plan sharded over two ranks (region chains split by region; per chain
+    pass ONE int32 sum all-reduce of [flags | load-vector change] and ONE all-gather of the output
+    slices) gives the SAME digest on both ranks as the single-rank plan and as the CPU oracle -- the
+    kernels run on the SIMT emulator, the collectives are the embedder's of blance_comm_set;
+  * the same with 2, 3 and 5 ranks as threads of one process (blance_amd.dist_util.LocalGroup -- the
+    arrangement the GPU suite uses to run the sharded path on one MI355X), and without an all-gather
+    hook (outputs summed instead);
   * the ranks agree on the slowest rank's time (bench.py's timing rule)."""
 import os
 import subprocess
@@ -34,30 +37,39 @@ def test_sharded_plan_world_size_2(tmp_path):
         from oracle import loader
         dist.init_process_group("gloo")
         rank, world = dist.get_rank(), dist.get_world_size()
-        cases = [synth.config_flat(3, P=300, N=256), synth.config_flat(3, P=700, N=300), synth.config_flat(2, P=300, N=20)]
-        c = synth.rebalance_case(P=300, N=64, hierarchy=True)
-        fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
-        opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
-                    node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
-        cases.append(problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts))
+        from helpers import sharded_cases
+        cases, c, opts = sharded_cases()
         single = hip.Planner(lib_path=%r, chain_min_parts=8)
         want = [single.plan(fp).digest() for fp in cases]
         assert want == [loader.plan(fp).digest() for fp in cases]
         sharded = hip.Planner(lib_path=%r, chain_min_parts=8)
         calls = []
-        inner = dist_util.gloo_allreduce(dist)
-        def counted(ptr, count):
-            calls.append(count)
-            inner(ptr, count)
-        sharded.comm_set_callback(rank, world, counted)
-        got = [sharded.plan(fp) for fp in cases]
+        ar, ag = dist_util.gloo_collectives(sharded, dist)
+        def counted(kind, inner):
+            def f(ptr, count):
+                calls.append((kind, count))
+                inner(ptr, count)
+            return f
+        sharded.comm_set_callback(rank, world, counted("reduce", ar), counted("gather", ag))
+        got = []
+        for fp in cases:
+            before = len(calls)
+            got.append(sharded.plan(fp))
+            # every chain pass: collective A (flags + loads) and B (output slices), nothing else;
+            # at most one chain pass per sweep in these models (one state with a hierarchy rule)
+            mine = calls[before:]
+            assert len(mine) <= 2 * got[-1].iterations, (mine, got[-1].iterations)
+            assert [k for k, _ in mine] == ["reduce", "gather"] * (len(mine) // 2), mine
         assert [g.digest() for g in got] == want, "sharded plan differs from the single-rank plan"
         assert got[0].struct.steps_batched > 0
-        assert len(calls) >= 3 * 3 and max(calls) == 700 * 3, calls      # flags, loads, outputs of every chain pass
+        assert len(calls) >= 2 * (3 + 3 + 3 + 2), calls                 # every hierarchical case did shard
+        assert sharded.comm_stats()[0] == len(calls)
         # the rebalance from the sharded plan (events, nodes outside their region) as well
-        plan1, _ = problem.decode_result(cases[3], got[3])
+        plan1, _ = problem.decode_result(cases[-1], got[-1])
         fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+        before = len(calls)
         assert sharded.plan(fp2).digest() == loader.plan(fp2).digest()
+        assert len(calls) > before
         sharded.comm_clear()
         assert sharded.plan(cases[0]).digest() == want[0]
         dist.barrier()
@@ -65,6 +77,40 @@ def test_sharded_plan_world_size_2(tmp_path):
         print("rank", rank, "ok")
     """ % (ROOT, ROOT, emu, emu), 29519)
     assert out.count("ok") == 2
+
+
+def test_sharded_plan_threads_one_process():
+    """G ranks = G contexts driven by G threads (LocalGroup): digests equal the oracle's for every G, with
+    the all-gather of output slices and with the summed outputs (no all-gather hook)."""
+    from blance_amd import dist_util, hip, problem
+    from oracle import loader
+    from test_simt_emulated import build_emu
+    emu = build_emu()
+    from helpers import sharded_cases
+    cases, c, opts = sharded_cases()
+    want = [loader.plan(fp).digest() for fp in cases]
+    for G, gather in ((2, True), (3, True), (5, True), (8, True), (2, False)):
+        grp, planners = dist_util.local_sharded_planners(G, lambda: hip.Planner(lib_path=emu, chain_min_parts=8))
+        if not gather:
+            for r, pl in enumerate(planners):
+                pl.comm_set_callback(r, G, grp.rank_collectives(r)[0], None)
+
+        def work(rank, pl):
+            got = [pl.plan(fp) for fp in cases]
+            # the rebalance from the sharded plan (events, nodes outside their region) as well
+            plan1, _ = problem.decode_result(cases[-1], got[-1])
+            fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+            mid = pl.comm_stats()[0]
+            return [g.digest() for g in got], pl.plan(fp2).digest(), fp2, mid, pl.comm_stats()[0], [g.iterations for g in got]
+        res = grp.run(planners, work)
+        for digests, d2, fp2, mid, end, iters in res:
+            assert digests == want, G
+            assert d2 == loader.plan(fp2).digest(), G
+            # the 8-zone case shards for every G, two collectives per chain pass (= per sweep); so does its rebalance
+            assert mid >= 2 * iters[3] and (end > mid or G > 5), (G, mid, end, iters)     # the weighted tree has 5 zones
+            assert mid <= 2 * sum(iters)
+        for pl in planners:
+            pl.close()
 
 
 def test_max_over_ranks_world_size_2(tmp_path):

@@ -351,3 +351,74 @@ def test_rccl_communicator_of_one_rank(planner):
     fp = synth.config_flat(3, P=4096, N=512)
     _same(pl.plan(fp), _oracle(fp), "after comm_init_rccl")
     pl.close()
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_sharded_plan_contexts_on_one_gpu(G):
+    """BASELINE.json config 4 on a one-GPU box: G ranks = G contexts on this device, each walking the region
+    chains of its slice (region_base > 0), the load-vector change summed and the output slices gathered by
+    the embedder's collectives (blance_amd.dist_util.LocalGroup stages them through the host).  Every rank's
+    result at config 3's FULL size carries the oracle's digest; a weighted hierarchical plan and the
+    rebalance from it (events: nodes outside their partition's region) as well."""
+    from blance_amd import dist_util
+    want = _golden_digests()["config3"]
+    fp3 = synth.config_flat(3)
+    c = synth.rebalance_case(P=20000, N=1024, hierarchy=True)             # 8 zones
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
+    fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
+    w1 = _oracle(fp1)
+    plan1, _ = problem.decode_result(fp1, w1)
+    fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+    w2 = _oracle(fp2)
+    grp, planners = dist_util.local_sharded_planners(G, lambda: hip.Planner(device_id=0))
+
+    def work(rank, pl):
+        r3 = pl.plan(fp3)
+        n3 = pl.comm_stats()[0]
+        r1 = pl.plan(fp1)
+        n1 = pl.comm_stats()[0]
+        r2 = pl.plan(fp2)
+        return r3, r1, r2, n3, n1, pl.comm_stats()[0]
+    res = grp.run(planners, work)
+    for r3, r1, r2, n3, n1, n2 in res:
+        assert (r3.iterations, r3.n_warnings, r3.digest()) == (want["iterations"], want["warnings"], want["digest"]), G
+        _same(r1, w1, ("weighted hierarchical plan", G))
+        _same(r2, w2, ("its rebalance", G))
+        assert n3 == 2 * r3.iterations, (G, n3)                  # collectives A and B of every replica pass
+        assert n1 > n3 and n2 > n1, (G, n3, n1, n2)              # the weighted plans sharded as well
+    for pl in planners:
+        pl.close()
+
+
+def _flat_wide_k(planner_obj, k, P, N):
+    """A flat state with k = 3 or 4 copies (k_pass_tree<4>): weighted fresh plan and the rebalance from it."""
+    c = synth.rebalance_case(P=P, N=N, hierarchy=False)
+    c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=None, hierarchy_rules=None)
+    fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
+    r1 = planner_obj.plan(fp1)
+    _same(r1, _oracle(fp1), ("flat k", k, "initial"))
+    plan1, _ = problem.decode_result(fp1, r1)
+    fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+    _same(planner_obj.plan(fp2), _oracle(fp2), ("flat k", k, "rebalance"))
+
+
+@pytest.mark.parametrize("k", [3, 4])
+def test_tree_pass_flat_three_and_four_copies(planner, k):
+    """k_pass_tree<4>: flat states with 3 and 4 copies, clusters of one and of several leaf groups."""
+    _flat_wide_k(planner, k, P=4000, N=50)
+    _flat_wide_k(planner, k, P=6000, N=700)
+    from randgen import random_flat_wide_case
+    n = 0
+    for seed in range(120):
+        try:
+            fp = build_from_case(random_flat_wide_case(seed, k))
+        except problem.Unsupported:
+            continue
+        _same(planner.plan(fp), _oracle(fp), ("random flat k", k, seed))
+        n += 1
+    assert n > 80

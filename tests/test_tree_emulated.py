@@ -5,7 +5,7 @@ import pytest
 
 from blance_amd import hip, problem, synth
 from helpers import build_from_case, edge_cases
-from randgen import random_case
+from randgen import random_case, random_flat_wide_case
 from test_simt_emulated import build_emu
 
 
@@ -62,8 +62,10 @@ def test_random_instances_tree_dense_and_bulk(emu_lib):
     pb.close()
 
 
-def _rebalance(pl, P, N, check_stays=False, **kw):
+def _rebalance(pl, P, N, check_stays=False, model=None, **kw):
     c = synth.rebalance_case(P=P, N=N, hierarchy=False, **kw)
+    if model:
+        c["model"] = model
     fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
     opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
                 node_weights=c["nodeWeights"], node_hierarchy=None, hierarchy_rules=None)
@@ -121,4 +123,29 @@ def test_edge_shapes_tree(emu_lib):
             fp = problem.build_problem(*a, **k)
             got, want = pl.plan(fp), _oracle(fp)
             assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), i
+        pl.close()
+
+
+@pytest.mark.parametrize("k", [3, 4])
+def test_flat_three_and_four_copies_tree(emu_lib, k):
+    """k_pass_tree<4> (flat state, k = 3 / 4): random instances in the bounded-walk, dense and record-decoding
+    modes, and the weighted rebalance shape."""
+    planners = [hip.Planner(lib_path=emu_lib, tree=mode) for mode in ("on", "dense", "long")]
+    n = 0
+    for seed in range(150):
+        try:
+            fp = build_from_case(random_flat_wide_case(seed, k))
+        except problem.Unsupported:
+            continue
+        want = _oracle(fp)
+        for pl in planners[:1] if seed % 3 else planners:
+            got = pl.plan(fp)
+            assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
+        n += 1
+    assert n > 100
+    model = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
+    _rebalance(planners[0], 160, 30, model=model)
+    _rebalance(planners[0], 200, 150, model=model)
+    _rebalance(planners[2], 100, 70, model=model)
+    for pl in planners:
         pl.close()
