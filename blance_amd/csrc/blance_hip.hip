@@ -599,8 +599,9 @@ static int launch_scan_excl(blance_ctx* c, int n, int32_t* data) {
 }
 #define SCANTRY(n, data) do { int e__ = launch_scan_excl(c, (n), (data)); if (e__) return e__; } while (0)
 
-// stable LSD radix sort of n (key, value) pairs; result ends in the *_a buffers
-static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
+// stable LSD radix sort of the n (key, value) pairs in the f_*_a buffers; *sorted_vals = the buffer the sorted
+// values ended in (a or b: no copy back), *other_vals = the other one (free for the caller)
+static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches, int32_t** sorted_vals, int32_t** other_vals) {
     const int n_tiles = cdiv(n, kSortTile);
     unsigned long long* ka = c->f_keys_a.as<unsigned long long>();
     unsigned long long* kb = c->f_keys_b.as<unsigned long long>();
@@ -610,7 +611,7 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
     unsigned long long* vbits = (unsigned long long*)(c->scalars.as<int32_t>() + 14);
     unsigned long long varying = 0;
     HIPTRY(hipMemsetAsync(vbits, 0, sizeof varying, c->stream));
-    BLANCE_LAUNCH(k_sort_varbits, cdiv(n, 256), 256, 0, c->stream, n, ka, vbits);
+    BLANCE_LAUNCH(k_sort_varbits, cdiv(n, 256 * kVarbitsPer), 256, 0, c->stream, n, ka, vbits);
     HIPTRY(hipMemcpyAsync(&varying, vbits, sizeof varying, hipMemcpyDeviceToHost, c->stream));
     HIPTRY(hipStreamSynchronize(c->stream));
     *launches += 1;
@@ -626,10 +627,9 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches) {
         *launches += 3;
         done++;
     }
-    if (done & 1) {                                  // callers read the *_a buffers
-        HIPTRY(hipMemcpyAsync(kb, ka, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-        HIPTRY(hipMemcpyAsync(vb, va, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    }
+    (void)done;
+    *sorted_vals = va;                               // (the loop swapped the roles after every pass)
+    *other_vals = vb;
     return 0;
 }
 
@@ -738,19 +738,19 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
                           c->f_moff.as<int32_t>());
             BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
                                  c->f_keys_a.as<unsigned long long>(), c->f_vals_a.as<int32_t>());
-            int e = radix_sort_pairs(c, RS, launches);
+            int32_t *sorted_vals = nullptr, *other_vals = nullptr;
+            int e = radix_sort_pairs(c, RS, launches, &sorted_vals, &other_vals);
             if (e) return e;
-            const int32_t* picks = c->f_vals_a.as<int32_t>();
+            const int32_t* picks = sorted_vals;
             if (excl) {
                 int32_t bad = INT_MAX;
                 HIPTRY(hipMemcpyAsync(scal + 10, &bad, sizeof bad, hipMemcpyHostToDevice, sm));
-                BLANCE_LAUNCH(k_fresh_excl, 1, 1024, 2048 + 64, sm, fq, pos, R, c->f_vals_a.as<int32_t>(),
-                              c->f_vals_b.as<int32_t>(), scal + 10);
+                BLANCE_LAUNCH(k_fresh_excl, 1, 1024, 2048 + 64, sm, fq, pos, R, sorted_vals, other_vals, scal + 10);
                 HIPTRY(hipMemcpyAsync(&bad, scal + 10, sizeof bad, hipMemcpyDeviceToHost, sm));
                 HIPTRY(hipStreamSynchronize(sm));
                 *launches += 1;
                 if (bad < R) R = bad;               // a pending node came up again: the run ends before that step
-                picks = c->f_vals_b.as<int32_t>();
+                picks = other_vals;
                 HIPTRY(hipMemsetAsync(c->f_m.p, 0, sizeof(int32_t) * ((size_t)q.N + 1), sm));
                 if (R > 0) BLANCE_LAUNCH_NOSYNC(k_fresh_hist, cdiv((int64_t)q.k * R, 256), 256, 0, sm, q.k * R, picks, c->f_m.as<int32_t>());
             }
@@ -1267,13 +1267,20 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             const int k = c->state_constraints[m];
             if (k <= 0 || P == 0) continue;
             const int n_chunks = cdiv(P, kPartChunk);
-            BLANCE_LAUNCH_NOSYNC(k_category, cdiv(P, 256), 256, 0, sm, d, m, any_removed, add_nil, c->cat.as<uint8_t>());
-            BLANCE_LAUNCH(k_part_count, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
-                          c->part_order.as<int32_t>(), n_chunks, 3, c->chunk_counts.as<int32_t>());
-            SCANTRY(3 * n_chunks, c->chunk_counts.as<int32_t>());
-            BLANCE_LAUNCH(k_part_scatter, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
-                          c->part_order.as<int32_t>(), c->part_order.as<int32_t>(), n_chunks, 3, 2,
-                          c->chunk_counts.as<int32_t>(), c->order.as<int32_t>(), (int32_t*)nullptr);
+            if (first) {
+                BLANCE_LAUNCH_NOSYNC(k_category, cdiv(P, 256), 256, 0, sm, d, m, any_removed, add_nil, c->cat.as<uint8_t>());
+                BLANCE_LAUNCH(k_part_count, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
+                              c->part_order.as<int32_t>(), n_chunks, 3, c->chunk_counts.as<int32_t>());
+                SCANTRY(3 * n_chunks, c->chunk_counts.as<int32_t>());
+                BLANCE_LAUNCH(k_part_scatter, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
+                              c->part_order.as<int32_t>(), c->part_order.as<int32_t>(), n_chunks, 3, 2,
+                              c->chunk_counts.as<int32_t>(), c->order.as<int32_t>(), (int32_t*)nullptr);
+            } else {
+                // sweeps >= 2 run with nodesToRemove = nodesToAdd = [] (non-nil, plan.go:53-55): no partition's
+                // nodes are in either, so every category is "1" (plan.go:542-561) and the pass order is the
+                // static order itself
+                HIPTRY(hipMemcpyAsync(c->order.p, c->part_order.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToDevice, sm));
+            }
             if (NP > 0)                                             // nodeToNodeCounts := fresh, plan.go:266
                 HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
             const int OW = 1 + k;

@@ -40,17 +40,48 @@ struct Unsupported {
     std::string why;
 };
 
+// name -> dense id: open addressing over the names themselves (FNV-1a), no node allocation per entry --
+// a plan of a million partitions interns a few million node references
 struct Intern {
-    std::unordered_map<std::string, int> ids;
     std::vector<std::string> names;
-    int add(const std::string& s) {
-        auto it = ids.find(s);
-        if (it != ids.end()) return it->second;
-        int i = (int)names.size();
-        ids.emplace(s, i);
-        names.push_back(s);
-        return i;
+    std::vector<int32_t> slots;                  // id or -1; capacity a power of two, load <= 1/2
+    static uint64_t hash(const std::string& s) {
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
+        return h ^ (h >> 29);
     }
+    void grow() {
+        const size_t cap = slots.empty() ? 64 : slots.size() * 2;
+        slots.assign(cap, -1);
+        for (size_t i = 0; i < names.size(); i++) {
+            size_t at = hash(names[i]) & (cap - 1);
+            while (slots[at] >= 0) at = (at + 1) & (cap - 1);
+            slots[at] = (int32_t)i;
+        }
+    }
+    int find(const std::string& s) const {
+        if (slots.empty()) return -1;
+        const size_t mask = slots.size() - 1;
+        for (size_t at = hash(s) & mask;; at = (at + 1) & mask) {
+            const int32_t id = slots[at];
+            if (id < 0) return -1;
+            if (names[(size_t)id] == s) return id;
+        }
+    }
+    bool has(const std::string& s) const { return find(s) >= 0; }
+    int add(const std::string& s) {
+        int id = find(s);
+        if (id >= 0) return id;
+        if ((names.size() + 1) * 2 > slots.size()) grow();
+        id = (int)names.size();
+        names.push_back(s);
+        const size_t mask = slots.size() - 1;
+        size_t at = hash(s) & mask;
+        while (slots[at] >= 0) at = (at + 1) & mask;
+        slots[at] = id;
+        return id;
+    }
+    int at(const std::string& s) const { return find(s); }
 };
 
 bool atoi_go(const std::string& s, long long* out) {       // strconv.Atoi, plan.go:525
@@ -150,101 +181,73 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     // ---- nodes
     Intern nodes;
     for (auto& n : nodesAll) {
-        if (nodes.ids.count(n)) throw Unsupported{"duplicate node name in nodesAll"};
+        if (nodes.has(n)) throw Unsupported{"duplicate node name in nodesAll"};
         nodes.add(n);
     }
     const int N = (int)nodes.names.size();
 
-    // ---- partitions
+    // ---- partitions.  The maps are ordered by name (std::map, like the sorted walk the shim makes of Go's maps):
+    // prevMap and PartitionWeights are joined by walking them alongside partitionsToAssign, not looked up per name.
     const bool weights_nil = !o.PartitionWeights.has_value();
-    std::vector<std::string> pnames;
+    std::vector<const std::string*> pnames;
+    std::vector<const Partition*> pparts;
+    pnames.reserve(assign.size());
+    pparts.reserve(assign.size());
     for (auto& kv : assign) {
         if (!kv.second) throw Unsupported{"nil *Partition in partitionsToAssign"};
         if (kv.second->Name != kv.first) throw Unsupported{"partition key != Partition.Name"};
-        pnames.push_back(kv.first);
+        pnames.push_back(&kv.first);
+        pparts.push_back(kv.second.get());
     }
     const int P = (int)pnames.size();
     f.part_weight.assign(P, 1);
     f.part_has_weight.assign(P, 0);
     f.part_in_prev.assign(P, 0);
     f.never_equal.assign(P, 0);
-    if (!weights_nil)
-        for (int i = 0; i < P; i++) {
-            auto it = o.PartitionWeights->find(pnames[i]);
-            if (it != o.PartitionWeights->end()) { f.part_weight[i] = it->second; f.part_has_weight[i] = 1; }
+    if (!weights_nil) {
+        auto iw = o.PartitionWeights->begin();
+        const auto we = o.PartitionWeights->end();
+        for (int i = 0; i < P && iw != we; i++) {
+            while (iw != we && iw->first < *pnames[i]) ++iw;
+            if (iw != we && iw->first == *pnames[i]) { f.part_weight[i] = iw->second; f.part_has_weight[i] = 1; }
         }
-    std::set<std::string> removed_set;
-    if (nodesToRemove) removed_set.insert(nodesToRemove->begin(), nodesToRemove->end());
+    }
+    const bool any_removed = nodesToRemove && !nodesToRemove->empty();
+    f.a_off.reserve((size_t)P * M + 1);
+    f.p_off.reserve((size_t)P * M + 1);
+    f.a_kind.reserve((size_t)P * M);
+    f.p_kind.reserve((size_t)P * M);
     f.a_off.push_back(0);
     f.p_off.push_back(0);
     long long abs_load = 0;
     auto labs64 = [](long long v) { return v < 0 ? -v : v; };
-    for (int i = 0; i < P; i++) {
-        const std::string& name = pnames[i];
-        const Partition& pa = *assign.at(name);
-        static const std::map<std::string, StringList> no_states;
-        const auto& nbs = pa.NodesByState ? *pa.NodesByState : no_states;
-        for (auto& kv : nbs)
-            if (!sid.count(kv.first)) throw Unsupported{"partition carries a state that is not in the model"};
-        for (auto& s : states) {
-            auto it = nbs.find(s);
-            if (it != nbs.end()) {
-                if (it->second) {
-                    std::set<std::string> seen(it->second->begin(), it->second->end());
-                    if (seen.size() != it->second->size()) throw Unsupported{"duplicate node inside a state list"};
-                    for (auto& x : *it->second) f.a_nodes.push_back(nodes.add(x));
-                }
-                f.a_kind.push_back(it->second ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
-            } else {
-                f.a_kind.push_back(BLANCE_LIST_ABSENT);
-            }
-            f.a_off.push_back((int32_t)f.a_nodes.size());
+    static const std::map<std::string, StringList> no_states;
+    // the model's states inside a NodesByState map: both are ordered by name -> one pass, no lookups
+    std::vector<int> by_name(M);                            // state ids in name order
+    for (int m = 0; m < M; m++) by_name[m] = m;
+    std::sort(by_name.begin(), by_name.end(), [&](int a, int b) { return states[a] < states[b]; });
+    std::vector<const StringList*> lists(M);
+    std::vector<char> present(M);
+    auto split = [&](const std::map<std::string, StringList>& nbs, bool* foreign) {
+        for (int m = 0; m < M; m++) { lists[m] = nullptr; present[m] = 0; }
+        int bi = 0;
+        for (auto& kv : nbs) {
+            while (bi < M && states[by_name[bi]] < kv.first) bi++;
+            if (bi < M && states[by_name[bi]] == kv.first) { lists[by_name[bi]] = &kv.second; present[by_name[bi]] = 1; }
+            else *foreign = true;
         }
-        auto ip = prevMap.find(name);
-        const long long w = f.part_weight[i];
-        if (ip == prevMap.end()) {
-            if (!removed_set.empty() && any_pass)
-                throw Unsupported{"nodesToRemove non-empty but a partition is missing from prevMap (plan.go:545)"};
-            for (int m = 0; m < M; m++) { f.p_kind.push_back(BLANCE_LIST_ABSENT); f.p_off.push_back((int32_t)f.p_nodes.size()); }
-            continue;
-        }
-        if (!ip->second) throw Unsupported{"nil *Partition in prevMap"};
-        f.part_in_prev[i] = 1;
-        const Partition& pp = *ip->second;
-        if (!pp.NodesByState || pp.Name != name) f.never_equal[i] = 1;
-        const auto& pn = pp.NodesByState ? *pp.NodesByState : no_states;
-        for (auto& s : states) {
-            auto it = pn.find(s);
-            if (it != pn.end()) {
-                f.p_kind.push_back(it->second ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
-                if (it->second)
-                    for (auto& x : *it->second) { f.p_nodes.push_back(nodes.add(x)); abs_load += labs64(w); }
-            } else {
-                f.p_kind.push_back(BLANCE_LIST_ABSENT);
-            }
-            f.p_off.push_back((int32_t)f.p_nodes.size());
-        }
-        for (auto& kv : pn) {
-            if (sid.count(kv.first)) continue;
-            f.never_equal[i] = 1;
-            if (kv.second)
-                for (auto& x : *kv.second) {
-                    f.load_state.push_back(M); f.load_node.push_back(nodes.add(x));
-                    f.load_weight.push_back((int32_t)w); f.load_first.push_back(1);
-                    abs_load += labs64(w);
-                }
-        }
-    }
-    for (auto& kv : prevMap) {                              // partitions only in prevMap
-        if (assign.count(kv.first)) continue;
-        if (!kv.second) throw Unsupported{"nil *Partition in prevMap"};
+    };
+    auto ip = prevMap.begin();
+    const auto pe = prevMap.end();
+    auto prev_only = [&](const std::string& name, const PartitionPtr& pp) {     // partitions only in prevMap
+        if (!pp) throw Unsupported{"nil *Partition in prevMap"};
         long long w = 1;
         if (!weights_nil) {
-            auto it = o.PartitionWeights->find(kv.first);
+            auto it = o.PartitionWeights->find(name);
             if (it != o.PartitionWeights->end()) w = it->second;
         }
-        if (kv.second->NodesByState)
-            for (auto& sl : *kv.second->NodesByState) {
+        if (pp->NodesByState)
+            for (auto& sl : *pp->NodesByState) {
                 if (!sl.second) continue;
                 auto is = sid.find(sl.first);
                 for (auto& x : *sl.second) {
@@ -253,7 +256,70 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
                     abs_load += labs64(w);
                 }
             }
+    };
+    for (int i = 0; i < P; i++) {
+        const std::string& name = *pnames[i];
+        const Partition& pa = *pparts[i];
+        const auto& nbs = pa.NodesByState ? *pa.NodesByState : no_states;
+        bool foreign = false;
+        split(nbs, &foreign);
+        if (foreign) throw Unsupported{"partition carries a state that is not in the model"};
+        for (int m = 0; m < M; m++) {
+            if (present[m]) {
+                const StringList& l = *lists[m];
+                if (l) {
+                    const size_t first = f.a_nodes.size();
+                    for (auto& x : *l) f.a_nodes.push_back(nodes.add(x));
+                    for (size_t a = first; a < f.a_nodes.size(); a++)
+                        for (size_t b = first; b < a; b++)
+                            if (f.a_nodes[a] == f.a_nodes[b]) throw Unsupported{"duplicate node inside a state list"};
+                }
+                f.a_kind.push_back(l ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
+            } else {
+                f.a_kind.push_back(BLANCE_LIST_ABSENT);
+            }
+            f.a_off.push_back((int32_t)f.a_nodes.size());
+        }
+        while (ip != pe && ip->first < name) { prev_only(ip->first, ip->second); ++ip; }
+        const long long w = f.part_weight[i];
+        if (ip == pe || ip->first != name) {
+            if (any_removed && any_pass)
+                throw Unsupported{"nodesToRemove non-empty but a partition is missing from prevMap (plan.go:545)"};
+            for (int m = 0; m < M; m++) { f.p_kind.push_back(BLANCE_LIST_ABSENT); f.p_off.push_back((int32_t)f.p_nodes.size()); }
+            continue;
+        }
+        if (!ip->second) throw Unsupported{"nil *Partition in prevMap"};
+        f.part_in_prev[i] = 1;
+        const Partition& pp = *ip->second;
+        ++ip;
+        if (!pp.NodesByState || pp.Name != name) f.never_equal[i] = 1;
+        const auto& pn = pp.NodesByState ? *pp.NodesByState : no_states;
+        foreign = false;
+        split(pn, &foreign);
+        for (int m = 0; m < M; m++) {
+            if (present[m]) {
+                const StringList& l = *lists[m];
+                f.p_kind.push_back(l ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
+                if (l)
+                    for (auto& x : *l) { f.p_nodes.push_back(nodes.add(x)); abs_load += labs64(w); }
+            } else {
+                f.p_kind.push_back(BLANCE_LIST_ABSENT);
+            }
+            f.p_off.push_back((int32_t)f.p_nodes.size());
+        }
+        if (foreign)
+            for (auto& kv : pn) {
+                if (sid.count(kv.first)) continue;
+                f.never_equal[i] = 1;
+                if (kv.second)
+                    for (auto& x : *kv.second) {
+                        f.load_state.push_back(M); f.load_node.push_back(nodes.add(x));
+                        f.load_weight.push_back((int32_t)w); f.load_first.push_back(1);
+                        abs_load += labs64(w);
+                    }
+            }
     }
+    for (; ip != pe; ++ip) prev_only(ip->first, ip->second);
     {
         long long sumw = 0, maxw = 0, ksum = 0;
         for (int i = 0; i < P; i++) { sumw += labs64(f.part_weight[i]); maxw = std::max<long long>(maxw, labs64(f.part_weight[i])); }
@@ -269,10 +335,10 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     if (o.NodeWeights) for (auto& kv : *o.NodeWeights) nodes.add(kv.first);
     const int NX = (int)nodes.names.size();
     f.node_removed.assign(NX, 0); f.node_added.assign(NX, 0); f.node_weight.assign(NX, 0); f.node_has_weight.assign(NX, 0);
-    if (nodesToRemove) for (auto& x : *nodesToRemove) f.node_removed[nodes.ids[x]] = 1;
-    if (nodesToAdd) for (auto& x : *nodesToAdd) f.node_added[nodes.ids[x]] = 1;
+    if (nodesToRemove) for (auto& x : *nodesToRemove) f.node_removed[nodes.at(x)] = 1;
+    if (nodesToAdd) for (auto& x : *nodesToAdd) f.node_added[nodes.at(x)] = 1;
     if (o.NodeWeights)
-        for (auto& kv : *o.NodeWeights) { f.node_weight[nodes.ids[kv.first]] = kv.second; f.node_has_weight[nodes.ids[kv.first]] = 1; }
+        for (auto& kv : *o.NodeWeights) { f.node_weight[nodes.at(kv.first)] = kv.second; f.node_has_weight[nodes.at(kv.first)] = 1; }
 
     f.state_stickiness.assign(M, 0); f.state_has_stickiness.assign(M, 0);
     if (o.StateStickiness)
@@ -298,7 +364,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
             int k = f.state_constraints[m];
             if (k > 0 && (f.rule_off[m + 1] - f.rule_off[m]) * k > 64) throw Unsupported{"more than 64 hierarchy picks"};
         }
-        if (nodes.ids.count("")) throw Unsupported{"\"\" used as a node name"};
+        if (nodes.has("")) throw Unsupported{"\"\" used as a node name"};
         Intern v = nodes;
         static const std::map<std::string, std::string> no_hier;
         const auto& hier = o.NodeHierarchy ? *o.NodeHierarchy : no_hier;
@@ -309,7 +375,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
         std::vector<std::vector<int>> children(VX);
         std::vector<char> has_parent(VX, 0);
         for (auto& kv : hier) {                             // std::map: children in name order (plan.go:705-715)
-            int c = v.ids[kv.first], p = v.ids[kv.second];
+            int c = v.at(kv.first), p = v.at(kv.second);
             f.v_parent[c] = p;
             children[p].push_back(c);
             has_parent[c] = 1;
@@ -342,27 +408,46 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
         f.leaf_pos.assign(NX, -1);
     }
 
-    // ---- static part of partitionSorter's key (plan.go:519-540), compared as the reference's strings
+    // ---- static part of partitionSorter's key (plan.go:519-540): ("%10d" of 999999999 - weight, "%10d" of the name if
+    // it is a non-negative number else the name, Name), compared as strings.  "%10d" renderings of values in
+    // [0, 9999999999] compare like the values (digits right-aligned behind spaces), so such keys are sorted as
+    // integers; a problem with any other key takes the string comparison of the reference literally.
     {
-        struct Key { std::string w, n, name; int i; };
-        std::vector<Key> keys;
-        for (int i = 0; i < P; i++) {
+        struct Num { long long w, n; int i; };
+        std::vector<Num> nums((size_t)P);
+        bool simple = true;
+        for (int i = 0; i < P && simple; i++) {
             long long v = 0;
-            std::string nkey = (atoi_go(pnames[i], &v) && v >= 0) ? pad10(v) : pnames[i];
-            long long w = 1;
-            if (!weights_nil) {
-                auto it = o.PartitionWeights->find(pnames[i]);
-                if (it != o.PartitionWeights->end()) w = it->second;
-            }
-            keys.push_back({pad10(999999999LL - w), nkey, pnames[i], i});
+            const bool numeric = atoi_go(*pnames[i], &v) && v >= 0;
+            const long long wk = 999999999LL - (long long)f.part_weight[i];
+            if (!numeric || v > 9999999999LL || wk < 0 || wk > 9999999999LL) simple = false;
+            nums[(size_t)i] = {wk, v, i};
         }
-        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-            if (a.w != b.w) return a.w < b.w;
-            if (a.n != b.n) return a.n < b.n;
-            if (a.name != b.name) return a.name < b.name;
-            return a.i < b.i;
-        });
-        for (auto& k : keys) f.part_order.push_back(k.i);
+        if (simple) {
+            std::sort(nums.begin(), nums.end(), [&](const Num& a, const Num& b) {
+                if (a.w != b.w) return a.w < b.w;
+                if (a.n != b.n) return a.n < b.n;
+                if (a.i == b.i) return false;
+                return *pnames[a.i] < *pnames[b.i];            // "7" and "007": equal padded keys, then by Name
+            });
+            f.part_order.reserve((size_t)P);
+            for (auto& k : nums) f.part_order.push_back(k.i);
+        } else {
+            struct Key { std::string w, n; const std::string* name; int i; };
+            std::vector<Key> keys;
+            for (int i = 0; i < P; i++) {
+                long long v = 0;
+                std::string nkey = (atoi_go(*pnames[i], &v) && v >= 0) ? pad10(v) : *pnames[i];
+                keys.push_back({pad10(999999999LL - (long long)f.part_weight[i]), nkey, pnames[i], i});
+            }
+            std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+                if (a.w != b.w) return a.w < b.w;
+                if (a.n != b.n) return a.n < b.n;
+                if (*a.name != *b.name) return *a.name < *b.name;
+                return a.i < b.i;
+            });
+            for (auto& k : keys) f.part_order.push_back(k.i);
+        }
     }
 
     blance_problem& pb = f.pb;
@@ -386,7 +471,9 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     pb.rule_off = ptr(f.rule_off); pb.rule_inc = ptr(f.rule_inc); pb.rule_exc = ptr(f.rule_exc);
     pb.vertex_parent = ptr(f.v_parent); pb.vertex_leaf_lo = ptr(f.v_lo); pb.vertex_leaf_hi = ptr(f.v_hi);
     pb.node_leaf_pos = ptr(f.leaf_pos);
-    f.node_names = nodes.names; f.state_names = states; f.part_names = pnames;
+    f.node_names = nodes.names; f.state_names = states;
+    f.part_names.reserve((size_t)P);
+    for (const std::string* n : pnames) f.part_names.push_back(*n);
 }
 
 }  // namespace
@@ -472,20 +559,31 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     out.iterations = res.iterations;
     out.converged = res.converged != 0;
     if (res.iterations == 0) { out.nil_result = true; return out; }
+    // ids -> strings.  What this costs is allocations -- per partition its Partition, two map nodes, two list buffers,
+    // a node of the result map (node names fit the small-string buffer): ~7 M mallocs at config 3.  Building the objects
+    // on several threads does not help (measured on the MI355X box: 1 thread 205 ms, 4 threads 215 ms, 32 threads 440 ms
+    // -- the allocator and the page faults behind it serialise), so this is one loop; the map is filled in name order
+    // -- the order the partitions were taken from partitionsToAssign -- so every insertion lands at the end.
+    std::vector<PartitionPtr> parts((size_t)P);
     for (int p = 0; p < P; p++) {
         auto part = std::make_shared<Partition>();
         part->Name = f.part_names[p];
         part->NodesByState.emplace();
+        auto& nbs = *part->NodesByState;
         for (int m = 0; m < M; m++) {
             size_t i = (size_t)p * M + m;
             if (out_kind[i] == BLANCE_LIST_ABSENT) continue;
-            if (out_kind[i] == BLANCE_LIST_NIL) { (*part->NodesByState)[f.state_names[m]] = std::nullopt; continue; }
+            if (out_kind[i] == BLANCE_LIST_NIL) { nbs.emplace_hint(nbs.end(), f.state_names[m], std::nullopt); continue; }
             std::vector<std::string> lst;
+            lst.reserve((size_t)(out_off[i + 1] - out_off[i]));
             for (int32_t j = out_off[i]; j < out_off[i + 1]; j++) lst.push_back(f.node_names[out_nodes[j]]);
-            (*part->NodesByState)[f.state_names[m]] = std::move(lst);
+            nbs[f.state_names[m]] = std::move(lst);
         }
-        out.nextMap[part->Name] = part;
+        parts[(size_t)p] = std::move(part);
     }
+    out.unintern_parts_ms = ms_since(t_un);
+    for (int p = 0; p < P; p++) out.nextMap.emplace_hint(out.nextMap.end(), f.part_names[p], parts[(size_t)p]);
+    out.unintern_map_ms = ms_since(t_un) - out.unintern_parts_ms;
     for (int64_t i = 0; i < res.n_warnings; i++) {           // plan.go:231-234
         const std::string& name = f.part_names[warn_part[i]];
         char buf[64];
@@ -495,8 +593,20 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     }
     // plan.go:49-52: every non-converged sweep stores its partitions into both input maps;
     // the last such store has the final map's content
-    if ((res.iterations > 1 || !res.converged) && prevMap)
-        for (auto& kv : out.nextMap) { (*prevMap)[kv.first] = kv.second; partitionsToAssign[kv.first] = kv.second; }
+    if ((res.iterations > 1 || !res.converged) && prevMap) {
+        auto store = [&](PartitionMap& dst) {              // both ordered by name: one walk, no lookups
+            auto id = dst.begin();
+            for (auto& kv : out.nextMap) {
+                while (id != dst.end() && id->first < kv.first) ++id;
+                if (id != dst.end() && id->first == kv.first) id->second = kv.second;
+                else id = dst.emplace_hint(id, kv.first, kv.second);
+            }
+        };
+        const auto t_st = std::chrono::steady_clock::now();
+        store(*prevMap);
+        if (&partitionsToAssign != prevMap) store(partitionsToAssign);
+        out.store_ms = ms_since(t_st);
+    }
     out.unintern_ms = ms_since(t_un);
     return out;
 }

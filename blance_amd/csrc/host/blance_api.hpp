@@ -62,6 +62,8 @@ struct PlanOutcome {
     bool converged = false;
     // where the call's time went (ms): strings -> ids, blance_plan (H2D + device + D2H), ids -> strings
     double intern_ms = 0.0, plan_ms = 0.0, unintern_ms = 0.0, device_ms = 0.0;
+    // inside unintern_ms: the Partition objects (threads), the result map, the stores of plan.go:49-52 into the input maps
+    double unintern_parts_ms = 0.0, unintern_map_ms = 0.0, store_ms = 0.0;
 };
 
 // The C ABI entry points, resolved at run time so that one binary can drive

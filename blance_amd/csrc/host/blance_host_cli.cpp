@@ -169,6 +169,7 @@ static int run_bench(Library& lib, int cfg, int P, int N) {
             assign[p->Name] = p;
         }
         build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        r = PlanOutcome();                             // (the previous round's million partitions are freed outside the timed call)
         auto t1 = std::chrono::steady_clock::now();
         r = PlanNextMapEx(lib, &prev, assign, nodes, std::vector<std::string>{}, nodes, model, o);
         total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
@@ -177,9 +178,11 @@ static int run_bench(Library& lib, int cfg, int P, int N) {
     const double assignments = 3.0 * P;
     printf("{\"what\": \"blance::PlanNextMapEx (C++ mirror of api.go:147), string maps in -> string maps out, second call\", "
            "\"partitions\": %d, \"nodes\": %d, \"sweeps\": %d, \"total_ms\": %.3f, \"intern_ms\": %.3f, "
-           "\"blance_plan_ms\": %.3f, \"device_ms\": %.3f, \"unintern_ms\": %.3f, \"caller_builds_input_maps_ms\": %.3f, "
+           "\"blance_plan_ms\": %.3f, \"device_ms\": %.3f, \"unintern_ms\": %.3f, \"unintern_parts_ms\": %.3f, \"unintern_map_ms\": %.3f, "
+           "\"store_into_input_maps_ms\": %.3f, \"caller_builds_input_maps_ms\": %.3f, "
            "\"assignments_per_s\": %.1f, \"result_partitions\": %zu}\n",
-           P, N, r.iterations, total_ms, r.intern_ms, r.plan_ms, r.device_ms, r.unintern_ms, build_ms,
+           P, N, r.iterations, total_ms, r.intern_ms, r.plan_ms, r.device_ms, r.unintern_ms, r.unintern_parts_ms, r.unintern_map_ms,
+           r.store_ms, build_ms,
            assignments / (total_ms * 1e-3), r.nextMap.size());
     return 0;
 }

@@ -217,13 +217,17 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
             c_mid[i] = a;
             sum += a;
         }
-        part[tid] = sum;
-        __syncthreads();
-        for (int off = 512; off >= 1; off >>= 1) {
-            if (tid < off) part[tid] += part[tid + off];
-            __syncthreads();
+        // 64 outer probes: the block sum costs two barriers (wave sums by lane shuffles, 16 partials in LDS)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int lo32 = __shfl_xor((int)(unsigned)sum, off, 64), hi32 = __shfl_xor((int)(sum >> 32), off, 64);
+            sum += (long long)(((unsigned long long)(unsigned)hi32 << 32) | (unsigned)lo32);
         }
-        long long total = part[0];
+        if ((tid & 63) == 0) part[tid >> 6] = sum;
+        __syncthreads();
+        long long total = 0;
+#pragma unroll
+        for (int wv = 0; wv < 16; wv++) total += part[wv];
         __syncthreads();
         if (total >= R) {
             hi = mid;
@@ -450,9 +454,13 @@ __device__ __forceinline__ unsigned long long same_digit_lanes(int digit, bool v
 }
 
 // bits in which the keys differ from keys[0]: byte positions that are equal everywhere need no pass
+constexpr int kVarbitsPer = 16;          // keys per thread of k_sort_varbits
 __global__ void k_sort_varbits(int n, const unsigned long long* keys, unsigned long long* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = i < n ? (keys[i] ^ keys[0]) : 0ull;
+    const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * kVarbitsPer;
+    const unsigned long long k0 = keys[0];
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int j = 0; j < kVarbitsPer; j++) v |= i0 + j < n ? (keys[i0 + j] ^ k0) : 0ull;
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

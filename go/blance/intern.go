@@ -142,6 +142,10 @@ func internProblem(
 				k = v
 			}
 		}
+		// the device tables are int32 (weights and stickiness are range-checked below the same way)
+		if int64(model[s].Priority) != int64(int32(model[s].Priority)) || int64(k) != int64(int32(k)) {
+			return nil, unsupported("Priority / Constraints of state %q beyond int32", s)
+		}
 		f.statePriority = append(f.statePriority, int32(model[s].Priority))
 		f.stateConstraints = append(f.stateConstraints, int32(k))
 		if k > 0 {
