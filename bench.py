@@ -13,9 +13,11 @@ N > 1 (one process per GPU; `--gpus N` launches the ranks itself through torch.d
 when it is not already running under it):
   * value: every rank plans an instance of the same shape (replicas, weak scaling) -- all ranks'
     assignments / the slowest rank's time;
-  * "sharded": ONE plan with its region chains sharded over the ranks and RCCL all-reduces of the
-    pass outputs and the load-vector change after every chain pass (BASELINE.json config 4),
-    timed the same way and reported beside it, whatever it is (DESIGN.md "Multi-GPU").
+  * "sharded": ONE plan with its region chains sharded over the ranks -- per chain pass one RCCL sum
+    all-reduce of [flags | load-vector change] and one all-gather of the output slices (BASELINE.json
+    config 4) -- timed the same way and reported beside it, whatever it is (DESIGN.md "Multi-GPU").
+N = 1 also reports "sharded_on_one_gpu": the same sharded plan with 8 ranks as 8 contexts of this one
+device (collectives staged through the host) -- it proves the path on real kernels, it is not a speed.
 """
 import argparse
 import json
@@ -74,9 +76,19 @@ def cpu_baseline(parts, nodes, cfg):
     res = loader.plan(fp)
     dt = time.perf_counter() - t0
     info["value"] = synth.assignments(fp) / dt
+    info["extrapolated"] = True
     info["sample"] = ("oracle/blance_oracle.c, %s (%d sweeps) on %d partitions x %d nodes (%s of the partitions, same "
-                      "nodes/hierarchy/model; per-step cost is O(nodes), so assignments/s carries over), %.1f s"
-                      % (what, res.iterations, sample_parts, nodes, frac, dt))
+                      "nodes/hierarchy/model; per-step cost is O(nodes), so assignments/s carries over: EXTRAPOLATED "
+                      "from the sample, the full-size run is %s), %.1f s"
+                      % (what, res.iterations, sample_parts, nodes, frac,
+                         "8 minutes" if cfg == 5 else "126 s on this repository's build container", dt))
+    # config 2 in full (65,536 x 256, not sampled), same port, same core
+    fp2 = synth.config_flat(2)
+    t0 = time.perf_counter()
+    res2 = loader.plan(fp2)
+    dt2 = time.perf_counter() - t0
+    info["config2_full"] = {"value": synth.assignments(fp2) / dt2, "unit": "assignments/s", "sweeps": res2.iterations,
+                            "partitions": fp2.n_parts, "nodes": fp2.n_nodes, "seconds": dt2, "extrapolated": False}
     try:
         from oracle import naive_loader
         info["naive_proxy"] = naive_loader.timed_sample(cfg, nodes)
@@ -134,6 +146,7 @@ def main():
     ap.add_argument("--parts", type=int, default=0, help="override partition count (not the headline)")
     ap.add_argument("--nodes", type=int, default=0, help="override node count (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the 8-contexts-on-one-GPU leg of N = 1")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -173,7 +186,7 @@ def main():
             pl.plan_resident()
         barrier()
         t0 = time.perf_counter()
-        acc = {"pass_ms": 0.0, "pass_launches": 0, "flat_ms": 0.0, "flat_passes": 0, "device_ms": 0.0}
+        acc = {"pass_ms": 0.0, "pass_launches": 0, "flat_ms": 0.0, "flat_passes": 0, "device_ms": 0.0, "blank_ms": 0.0, "blank_launches": 0}
         r = None
         for _ in range(steps):
             r = pl.plan_resident()                  # returns after the device finished the call
@@ -181,6 +194,8 @@ def main():
             acc["pass_launches"] += r.pass_kernel_launches
             acc["flat_ms"] += r.flat_pass_ms
             acc["flat_passes"] += r.flat_passes
+            acc["blank_ms"] += r.blank_pass_ms
+            acc["blank_launches"] += r.blank_pass_launches
             acc["device_ms"] += r.device_ms
         barrier()
         dt = time.perf_counter() - t0
@@ -204,61 +219,81 @@ def main():
         k_by_state = [int(fp.state_constraints[m]) for m in range(M)]
         RW = 4 + M * (1 + max(k_by_state + [1]))
         kernel_states = synth.pass_kernel_states(fp)
-        # ---- dominant kernel and the bytes its schedule has to move per launch (DESIGN.md "Measurement"):
-        # every step reads its record and writes its choice; nothing else leaves registers / LDS
-        if acc["pass_launches"]:
-            dom_ms, dom_launches = acc["pass_ms"], acc["pass_launches"]
-            if args.config == 5:
-                kernel_label = "k_pass_tree (flat replica pass, one wave64, one launch per pass)"
-                words = RW + 1 + max(k_by_state)
-                prof_prefix = ("k_pass_tree",)
-                chains = 1
-            else:
-                kernel_label = "k_pass_chain_blank / k_pass_chain (one wave64 per hierarchy region, one launch per replica pass)"
-                words = K_CW + 1 + max(k_by_state)
-                prof_prefix = ("k_pass_chain",)
-                chains = -(-N // 128)                # zones of 8 racks x 16 nodes
-        else:
-            dom_ms, dom_launches = acc["flat_ms"], acc["flat_passes"]
-            kernel_label = "flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)"
-            words = RW + 2
-            prof_prefix = ("k_flat", "k_fresh", "k_sort")
-            chains = None
-        bytes_per_launch = 4.0 * words * P
-        avg_launch_ms = dom_ms / max(dom_launches, 1)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if dom_launches else 0.0
-        # measured HBM traffic of that kernel, from the committed PMC passes of the same sources
-        hbm, hbm_src = profile_json("r2_pmc_hbm_config%d.json" % args.config)
-        traffic = None
+        # ---- per kernel: the bytes its schedule has to move per launch (DESIGN.md "Measurement": every step reads its
+        # record and writes its choice; nothing else leaves registers / LDS) over its average launch duration, measured
+        # in this run with HIP events on the planner's stream
         headline_shape = not args.parts and not args.nodes
-        if hbm and headline_shape:
-            tot, calls = kernel_counters(hbm, prof_prefix)
-            if calls:
-                # gfx950: FETCH_SIZE (KB) counts half of a streaming read's bytes (MI355X_MICROARCH.md, HBM)
-                traffic = (2.0 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024 / calls
-        # what actually bounds the kernel: one dependent chain per wave
-        critical = None
-        sq, sq_src = profile_json("r2_pmc_sq_config%d.json" % args.config)
-        if chains and dom_launches:
-            chain_steps = -(-P // chains)
-            ns = avg_launch_ms * 1e6 / chain_steps
-            critical = {"chains_per_launch": chains, "dependent_steps_per_chain": chain_steps,
+        hbm, hbm_src = profile_json("r3_pmc_hbm_config%d.json" % args.config)
+        sq, sq_src = profile_json("r3_pmc_sq_config%d.json" % args.config)
+
+        def kernel_line(label, prefix, words, ms, launches, chains):
+            if not launches:
+                return None
+            bytes_per_launch = 4.0 * words * P
+            avg_ms = ms / launches
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            line = {"kernel": label, "launches": launches, "avg_launch_ms": avg_ms, "bound": "hbm", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "algorithmic_bytes_model": "%d partitions x %d words x 4 B: every step reads its record and writes its "
+                                               "choice; load tables stay in registers / LDS (DESIGN.md 5)" % (P, words),
+                    "traffic": None, "traffic_from": hbm_src + " -- a committed profile of the same kernel sources, NOT measured in this run"}
+            if hbm and headline_shape:
+                tot, calls = kernel_counters(hbm, prefix)
+                if calls:
+                    # gfx950: FETCH_SIZE (KB) counts half of a streaming read's bytes (MI355X_MICROARCH.md, HBM)
+                    line["traffic"] = (2.0 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024 / calls
+            if chains:
+                chain_steps = -(-P // chains)
+                ns = avg_ms * 1e6 / chain_steps
+                line["occupancy"] = {"waves": chains, "cus": N_CUS, "simd_slots": N_CUS * SIMDS_PER_CU,
+                                     "simd_slots_used_frac": chains / float(N_CUS * SIMDS_PER_CU)}
+                crit = {"chains_per_launch": chains, "dependent_steps_per_chain": chain_steps,
                         "avg_ns_per_dependent_step": ns, "avg_cycles_per_dependent_step": ns * SCLK_GHZ}
-            if sq and headline_shape:
-                tot, calls = kernel_counters(sq, prof_prefix)
-                if calls and tot.get("SQ_WAVES"):
-                    instr = tot.get("SQ_INSTS_VALU", 0) + tot.get("SQ_INSTS_SALU", 0) + tot.get("SQ_INSTS_LDS", 0) + \
-                        tot.get("SQ_INSTS_SMEM", 0) + tot.get("SQ_INSTS_VMEM_RD", 0) + tot.get("SQ_INSTS_VMEM_WR", 0)
-                    per_step = instr / tot["SQ_WAVES"] / chain_steps
-                    critical.update({
-                        "instructions_per_step_per_wave": per_step,
-                        "cycles_per_instruction": ns * SCLK_GHZ / per_step if per_step else None,
-                        # a lone wave64 issues at most one VALU instruction per 4 cycles (16 lanes x 4)
-                        "issue_bound_ns_per_step": per_step * 4 / SCLK_GHZ,
-                        "issue_bound_frac": (per_step * 4 / SCLK_GHZ) / ns if ns else None,
-                        "wave_active_frac": tot.get("SQ_ACTIVE_INST_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
-                        "wave_waiting_frac": tot.get("SQ_WAIT_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
-                        "counters_from": sq_src})
+                if sq and headline_shape:
+                    tot, calls = kernel_counters(sq, prefix)
+                    if calls and tot.get("SQ_WAVES"):
+                        instr = tot.get("SQ_INSTS_VALU", 0) + tot.get("SQ_INSTS_SALU", 0) + tot.get("SQ_INSTS_LDS", 0) + \
+                            tot.get("SQ_INSTS_SMEM", 0) + tot.get("SQ_INSTS_VMEM_RD", 0) + tot.get("SQ_INSTS_VMEM_WR", 0)
+                        per_step = instr / tot["SQ_WAVES"] / chain_steps
+                        crit.update({
+                            "instructions_per_step_per_wave": per_step,
+                            "cycles_per_instruction": ns * SCLK_GHZ / per_step if per_step else None,
+                            # one wave issues at most one instruction per ~4.5 cycles (tools/dev_lat_micro.hip, measured)
+                            "issue_bound_ns_per_step": per_step * 4.5 / SCLK_GHZ,
+                            "issue_bound_frac": (per_step * 4.5 / SCLK_GHZ) / ns if ns else None,
+                            "wave_active_frac": tot.get("SQ_ACTIVE_INST_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
+                            "wave_waiting_frac": tot.get("SQ_WAIT_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
+                            "counters_from": sq_src + " (committed profile, not this run)"})
+                line["critical_path"] = crit
+            return line
+
+        kernels = []
+        kmax = max(k_by_state)
+        if args.config == 5:
+            kernels.append(kernel_line("k_pass_tree (flat replica pass, one wave64, one launch per sub-range of a pass)", ("k_pass_tree",),
+                                       RW + 1 + kmax, acc["pass_ms"], acc["pass_launches"], 1))
+        else:
+            zones = -(-N // 128)                     # zones of 8 racks x 16 nodes: one chain each
+            kernels.append(kernel_line("k_pass_chain_planes (all-blank replica pass of the first sweep: scalar bit-plane automaton, one "
+                                       "wave64 per hierarchy region)", ("k_pass_chain_planes", "k_pass_chain_blank"),
+                                       K_CW + 1 + kmax, acc["blank_ms"], acc["blank_launches"], zones))
+            kernels.append(kernel_line("k_pass_chain (replica passes of the later sweeps: verified stays, one wave64 per hierarchy region)",
+                                       ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"],
+                                       acc["pass_launches"] - acc["blank_launches"], zones))
+        kernels.append(kernel_line("flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)",
+                                   ("k_flat", "k_fresh", "k_sort"), RW + 2, acc["flat_ms"], acc["flat_passes"], None))
+        kernels = [k for k in kernels if k]
+        kernels.sort(key=lambda k: -k["avg_launch_ms"] * k["launches"])
+        dom = dict(kernels[0]) if kernels else {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+        # the whole call against the HBM peak: every kernel's measured traffic (committed profile) over this run's device time
+        whole = None
+        if hbm and headline_shape:
+            tot, calls = kernel_counters(hbm, ("",))
+            per_call = (2.0 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024 / max(hbm.get("plan_calls", 1), 1)
+            dev_s = acc["device_ms"] / args.steps * 1e-3
+            whole = {"hbm_bytes_per_call": per_call, "GBps": per_call / dev_s / 1e9, "frac_of_hbm_peak": per_call / dev_s / 1e9 / HBM_PEAK_GBS,
+                     "from": hbm_src + " (committed profile of the same kernel sources) over this run's device time"}
         dense = synth.algorithmic_bytes_per_sweep(fp) * iterations * args.steps / (acc["device_ms"] * 1e-3) / 1e9
         out = {
             "metric": "partition-state assignments/sec at 1M partitions x 4,096 nodes",
@@ -275,20 +310,14 @@ def main():
                        "sweeps_per_call": iterations, "parallelism": "replicas x%d" % world,
                        "steps_bulk": int(batched), "steps_one_by_one": int(sequential),
                        "headline": bool(args.config == 3 and headline_shape)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": hbm_src,
-                         "kernel": kernel_label, "launches": dom_launches, "avg_launch_ms": avg_launch_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "algorithmic_bytes_model": "%d partitions x %d words x 4 B: every step reads its record and writes its "
-                                                    "choice; load tables stay in registers / LDS (DESIGN.md 5)" % (P, words),
-                         "occupancy": ({"waves": chains, "cus": N_CUS, "simd_slots": N_CUS * SIMDS_PER_CU,
-                                        "simd_slots_used_frac": chains / float(N_CUS * SIMDS_PER_CU)} if chains else None),
-                         "critical_path": critical,
-                         "reference_dense_scan_equivalent_GBps": dense,
-                         "note": "the kernel is bound by the latency of one dependent chain per wave, not by HBM: frac is the "
-                                 "honest HBM fraction of the bytes the implemented schedule moves; "
-                                 "reference_dense_scan_equivalent_GBps prices the SAME wall time at the bytes the reference's "
-                                 "dense per-step scan would read (SURVEY.md 8d) -- not executed work, may exceed the HBM peak"},
+            "roofline": dict(dom, **{
+                "reference_dense_scan_equivalent_GBps": dense,
+                "whole_call": whole,
+                "note": "the dominant kernel is bound by the instruction issue of one dependent chain per wave (one wave64 per "
+                        "hierarchy region; critical_path), not by HBM: frac is the honest HBM fraction of the bytes its schedule "
+                        "moves; reference_dense_scan_equivalent_GBps prices this run's device time at the bytes the reference's "
+                        "dense per-step scan would read (SURVEY.md 8d) -- not executed work, may exceed the HBM peak"}),
+            "roofline_per_kernel": kernels,
             "device_ms_per_step": acc["device_ms"] / args.steps,
             "pass_kernel_ms_per_step": acc["pass_ms"] / args.steps, "flat_pass_ms_per_step": acc["flat_ms"] / args.steps,
             "transfers": {"upload_s": upload_s, "download_s": download_s,
@@ -301,6 +330,11 @@ def main():
                 want = json.load(f).get("config%d" % args.config)
             if want:
                 out["matches_oracle_digest"] = (want["rebalance"] if args.config == 5 else want)["digest"] == digest
+        if world == 1:
+            out["sharded"] = ("see sharded_on_one_gpu; N > 1 runs report the RCCL plan here" if args.config == 3 else
+                              "not applicable: flat passes are one chain (DESIGN.md 7); only config 3's region chains shard")
+            if args.config == 3 and not args.no_sharded:
+                out["sharded_on_one_gpu"] = sharded_on_one_gpu(fp, digest, local_rank, dt / args.steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config)
             out["host_end_to_end"] = host_end_to_end(args.config)
@@ -320,19 +354,28 @@ def main():
         dog.start()
         try:
             replica_digest = digest_all
-            dist_util.shard_plan_rccl(pl, dist)
-            sdt, sacc, sr = timed(args.steps, args.warmup)
-            sdig = pl.download().digest()
-            box = [None] * world
-            dist.all_gather_object(box, sdig)
-            sharded = {"what": "one PlanNextMap with its region chains sharded over the ranks; RCCL int32 sum all-reduce of "
-                               "the pass outputs, the load-vector change and the chain flags after every chain pass",
-                       "rccl_world_size": world, "ms_per_step": sdt * 1e3 / args.steps,
-                       "value": assignments * args.steps / sdt, "unit": "assignments/s", "scaling": "strong",
-                       "device_ms_per_step": sacc["device_ms"] / args.steps,
-                       "same_digest_on_every_rank": len(set(box)) == 1,
-                       "same_digest_as_single_rank_plan": sdig == replica_digest,
-                       "speedup_vs_one_rank_of_this_run": (dt / args.steps) / (sdt / args.steps)}
+            if args.config != 3:
+                # configs 2 and 5 have no hierarchy rule: their passes are flat -- one dependency chain per pass, nothing to shard
+                sharded = "not applicable: flat passes are one chain (DESIGN.md 7); only config 3's region chains shard"
+            else:
+                dist_util.shard_plan_rccl(pl, dist)
+                calls0, words0 = pl.comm_stats()
+                sdt, sacc, sr = timed(args.steps, args.warmup)
+                calls1, words1 = pl.comm_stats()
+                n_plans = args.steps + args.warmup
+                sdig = pl.download().digest()
+                box = [None] * world
+                dist.all_gather_object(box, sdig)
+                sharded = {"what": "one PlanNextMap with its region chains sharded over the ranks; per chain pass one RCCL int32 sum "
+                                   "all-reduce of [flags | load-vector change] and one all-gather of the output slices",
+                           "comm_calls_per_plan": (calls1 - calls0) / float(n_plans),
+                           "comm_bytes_per_plan": 4.0 * (words1 - words0) / n_plans,
+                           "rccl_world_size": world, "ms_per_step": sdt * 1e3 / args.steps,
+                           "value": assignments * args.steps / sdt, "unit": "assignments/s", "scaling": "strong",
+                           "device_ms_per_step": sacc["device_ms"] / args.steps,
+                           "same_digest_on_every_rank": len(set(box)) == 1,
+                           "same_digest_as_single_rank_plan": sdig == replica_digest,
+                           "speedup_vs_one_rank_of_this_run": (dt / args.steps) / (sdt / args.steps)}
         except Exception as e:                      # the replicas line is still worth printing
             sharded = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         dog.cancel()
@@ -345,6 +388,37 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_on_one_gpu(fp, want_digest, device, one_rank_s, n_ranks=8):
+    """BASELINE.json config 4 without a multi-GPU node: the SAME sharded code path (chains of a slice of the regions per
+    rank, collective A = all-reduce of [flags | load change], collective B = all-gather of output slices) with the ranks as
+    contexts of this one device, driven by threads; the collectives are staged through the host by the harness.  It shows
+    that the path runs on the real kernels and gives the right answer; the time is NOT a multi-GPU time (the ranks share
+    one GPU and the collectives are host copies) and is reported as such."""
+    from blance_amd import dist_util, hip
+    try:
+        grp, planners = dist_util.local_sharded_planners(n_ranks, lambda: hip.Planner(device_id=device))
+
+        def work(rank, pl):
+            pl.plan(fp)                                 # warm-up (first touch of every buffer)
+            t0 = time.perf_counter()
+            res = pl.plan(fp)
+            return time.perf_counter() - t0, res.digest(), res.struct.device_ms, pl.comm_stats()
+        res = grp.run(planners, work)
+        for pl in planners:
+            pl.close()
+        calls, words = res[0][3]
+        return {"what": "one PlanNextMap sharded over %d ranks = %d contexts on ONE GPU, collectives staged through the host by the "
+                        "test harness: a correctness run of the sharded path, not a multi-GPU speed" % (n_ranks, n_ranks),
+                "ranks": n_ranks, "same_digest_on_every_rank": len({r[1] for r in res}) == 1,
+                "same_digest_as_single_rank_plan": res[0][1] == want_digest,
+                "ms_per_plan_host_to_host_slowest_rank": max(r[0] for r in res) * 1e3,
+                "device_ms_slowest_rank": max(r[2] for r in res),
+                "single_rank_ms_per_plan_resident": one_rank_s * 1e3,
+                "comm_calls_per_plan": calls / 2.0, "comm_bytes_per_plan": 4.0 * words / 2.0}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def host_end_to_end(cfg):

@@ -60,6 +60,7 @@ class Result(C.Structure):
         ("kernel_launches", C.c_int64),
         ("pass_kernel_ms", C.c_double), ("pass_kernel_launches", C.c_int64),
         ("flat_pass_ms", C.c_double), ("flat_passes", C.c_int64),
+        ("blank_pass_ms", C.c_double), ("blank_pass_launches", C.c_int64),
     ]
 
 

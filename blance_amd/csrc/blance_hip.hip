@@ -122,8 +122,8 @@ struct blance_ctx {
     double device_ms = 0.0, pass_ms = 0.0;
     std::vector<hipEvent_t> pass_events;     // begin/end pairs around every pass kernel
     std::vector<int> pass_kind;              // 0 = one pass kernel, 1 = flat bulk driver
-    double flat_ms = 0.0;
-    int64_t flat_passes = 0;
+    double flat_ms = 0.0, blank_ms = 0.0;
+    int64_t flat_passes = 0, blank_launches = 0;
 
     void free_all() {
         DevBuf* all[] = {&node_removed, &node_added, &node_weight, &node_has_weight, &alive, &zeros_nx,
@@ -1143,7 +1143,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
     launches += 8;
     c->pass_kind.resize(n_pass + 1);
-    c->pass_kind[n_pass] = 0;
+    c->pass_kind[n_pass] = lean ? 2 : 0;           // 2: the all-blank kernel did the pass
     n_pass++;
     int32_t fl[kXHead] = {0};
     if (sharded) {
@@ -1408,19 +1408,23 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     }
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    double pass_ms = 0.0, flat_ms = 0.0;
-    int n_kernel_pass = 0, n_flat = 0;
+    double pass_ms = 0.0, flat_ms = 0.0, blank_ms = 0.0;
+    int n_kernel_pass = 0, n_flat = 0, n_blank = 0;
     for (int i = 0; i < n_pass; i++) {
         float pm = 0.f;
         HIPTRY(hipEventElapsedTime(&pm, c->pass_events[2 * i], c->pass_events[2 * i + 1]));
-        if (c->pass_kind[i] == 0) { pass_ms += pm; n_kernel_pass++; } else { flat_ms += pm; n_flat++; }
+        if (c->pass_kind[i] != 1) { pass_ms += pm; n_kernel_pass++; } else { flat_ms += pm; n_flat++; }
+        if (c->pass_kind[i] == 2) { blank_ms += pm; n_blank++; }
         if (c->trace)
-            fprintf(stderr, "[blance] pass %d (%s): %.3f ms\n", i, c->pass_kind[i] ? "flat bulk driver" : "pass kernel", pm);
+            fprintf(stderr, "[blance] pass %d (%s): %.3f ms\n", i,
+                    c->pass_kind[i] == 1 ? "flat bulk driver" : c->pass_kind[i] == 2 ? "all-blank chain kernel" : "pass kernel", pm);
     }
     c->pass_ms = pass_ms;
     c->pass_launches = n_kernel_pass;
     c->flat_ms = flat_ms;
     c->flat_passes = n_flat;
+    c->blank_ms = blank_ms;
+    c->blank_launches = n_blank;
     c->iterations = iterations;
     c->converged = converged;
     c->device_ms = ms;
@@ -1443,6 +1447,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         res->pass_kernel_launches = n_kernel_pass;
         res->flat_pass_ms = flat_ms;
         res->flat_passes = n_flat;
+        res->blank_pass_ms = blank_ms;
+        res->blank_pass_launches = n_blank;
     }
     return BLANCE_OK;
 }
@@ -1500,6 +1506,8 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     res->pass_kernel_launches = c->pass_launches;
     res->flat_pass_ms = c->flat_ms;
     res->flat_passes = c->flat_passes;
+    res->blank_pass_ms = c->blank_ms;
+    res->blank_pass_launches = c->blank_launches;
     return BLANCE_OK;
 }
 

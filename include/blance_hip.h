@@ -182,6 +182,10 @@ typedef struct blance_result {
     int64_t  pass_kernel_launches;
     double   flat_pass_ms;
     int64_t  flat_passes;
+    /* out: of pass_kernel_ms / pass_kernel_launches, the part of the all-blank chain kernel
+     * (k_pass_chain_planes / k_pass_chain_blank: the first hierarchy pass of a fresh plan) */
+    double   blank_pass_ms;
+    int64_t  blank_pass_launches;
 } blance_result;
 
 typedef struct blance_options {

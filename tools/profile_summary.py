@@ -76,7 +76,8 @@ def pmc(out, out_json, title, dbs):
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:10]))
     if out_json != "-":
-        json.dump({"source_hash": source_hash(), "title": title,
+        m = re.search(r"\((\d+) PlanNextMap call", title)
+        json.dump({"source_hash": source_hash(), "title": title, "plan_calls": int(m.group(1)) if m else 1,
                    "git_head": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
                    "kernels": {short(k): per[k] for k in order}}, open(out_json, "w"), indent=1)
 
