@@ -72,6 +72,10 @@ struct blance_ctx {
     blance_comm comm{0, 1, nullptr, nullptr, nullptr};
     void* rccl_comm = nullptr;      // ncclComm_t of blance_comm_init_rccl
     DevBuf scan_sums;               // tile totals of launch_scan_excl
+    DevBuf topkey, top_counts, top_off, top_order;   // k_stay_by_top: steps grouped by the leaf of their top priority node
+    std::vector<int64_t> last_stays; // [state] steps the last chain pass of that state committed as verified stays
+    bool no_stay_top = false;       // test knob (& 64): never k_stay_by_top
+    bool force_stay_top = false;    // test knob (& 128): try k_stay_by_top in every chain pass with NumPartitions > 0
     DevBuf cnt_base, xbuf, gath;    // sharded pass: loads at pass start, [flags | load change], gathered output slices
     std::vector<int32_t> h_reg_off; // host copy of the chain offsets (slice sizes of the all-gather)
     bool trace = false;             // BLANCE_TRACE, read once at context creation
@@ -96,6 +100,8 @@ struct blance_ctx {
         bool ok = false;
         int n_regions = 0, max_size = 0;
         DevBuf node_region, reg_lo, reg_hi, leaf_cls, cls_size;
+        DevBuf wg_region, wg_chunk;     // k_stay_by_top: workgroup b walks the tops at leaves reg_lo + 64 chunk + lane of its region
+        int n_stay_wgs = 0, n_leaves = 0;
     };
     std::vector<RuleRegions> rule_regions;
     DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save, crec;
@@ -135,8 +141,9 @@ struct blance_ctx {
                          &cnt, &ntn, &cat, &order, &chunk_counts, &rec, &out, &warn_part,
                          &warn_state, &scalars};
         for (DevBuf* b : all) b->release();
-        for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
+        for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
         rule_regions.clear();
+        topkey.release(); top_counts.release(); top_off.release(); top_order.release();
         cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release();
         dl_off.release(); dl_nodes.release();
         for (DevBuf& b : mv) b.release();
@@ -292,6 +299,8 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->tree_always = opt && (opt->reserved[2] & 8);
     c->tree_long = opt && (opt->reserved[2] & 16);
     c->no_planes = opt && (opt->reserved[2] & 32);
+    c->no_stay_top = opt && (opt->reserved[2] & 64);
+    c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->trace = getenv("BLANCE_TRACE") != nullptr;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
@@ -394,9 +403,10 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     PUT(state_has_stick, pb->state_has_stickiness, M);
     PUT(rule_inc, pb->rule_inc, pb->n_rules);
     PUT(rule_exc, pb->rule_exc, pb->n_rules);
-    for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); }
+    for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
     c->rule_regions.clear();
     c->any_node_weight = 0;
+    c->last_stays.assign((size_t)M, 0);
     for (int n = 0; n < NX; n++) if (pb->node_has_weight[n]) c->any_node_weight = 1;
     if (!pb->hierarchy_rules_nil) {
         // leaf-interval table of every (rule, anchor): plan.go:723-734, :755-774
@@ -482,7 +492,15 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
             rr.ok = ok;
             rr.n_regions = ok ? (int)rlo.size() : 0;
             rr.max_size = max_size;
+            rr.n_leaves = n_leaves;
+            std::vector<int32_t> wg_region, wg_chunk;
+            if (ok)
+                for (size_t g = 0; g < rlo.size(); g++)
+                    for (int ch = 0; ch * 64 < rhi[g] - rlo[g]; ch++) { wg_region.push_back((int32_t)g); wg_chunk.push_back(ch); }
+            rr.n_stay_wgs = (int)wg_region.size();
             if (ok) {
+                if (put(c, rr.wg_region, wg_region.data(), wg_region.size())) return BLANCE_ERR_DEVICE;
+                if (put(c, rr.wg_chunk, wg_chunk.data(), wg_chunk.size())) return BLANCE_ERR_DEVICE;
                 if (put(c, rr.node_region, node_region.data(), node_region.size())) return BLANCE_ERR_DEVICE;
                 if (put(c, rr.reg_lo, rlo.data(), rlo.size())) return BLANCE_ERR_DEVICE;
                 if (put(c, rr.reg_hi, rhi.data(), rhi.size())) return BLANCE_ERR_DEVICE;
@@ -1074,12 +1092,22 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                       c->ev_counts.as<int32_t>(), c->ev_perm.as<int32_t>(), (int32_t*)nullptr);
         launches += 5;
     }
+    // A pass of stays only (the last sweep of every plan that converges)?  Worth a try when the state's pass of the
+    // sweep before was one but for a few steps: k_stay_by_top checks every step in parallel.
+    const bool try_stay = !sharded && !c->no_stay_top && NP > 0 && !cfl[0] && !cfl[6] && !cfl[7] && rr.max_size <= kStayMaxLeaves &&
+                          rr.n_stay_wgs > 0 && (c->force_stay_top || c->last_stays[m] * 100 >= (int64_t)P * 99);
+    if (try_stay) {
+        RESERVE(topkey, sizeof(int32_t) * ((size_t)P + 1));
+        RESERVE(top_order, sizeof(int32_t) * ((size_t)P + 1));
+        RESERVE(top_off, sizeof(int32_t) * ((size_t)rr.n_leaves + 2));
+        RESERVE(top_counts, sizeof(int32_t) * ((size_t)rr.n_leaves * nbc + 1));
+    }
     BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, a.higher_mask,
                          c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>(), c->state_stick.as<int32_t>(),
                          c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
                          rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
                          rr.cls_size.as<int32_t>(), 0,
-                         c->crec.as<int32_t>(), scal + 4);
+                         c->crec.as<int32_t>(), scal + 4, try_stay ? c->topkey.as<int32_t>() : (int32_t*)nullptr);
     const size_t cnt_words = (size_t)(M + 1) * NX;
     HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
     ChainParams cq;
@@ -1116,6 +1144,53 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         if (!gather_out) HIPTRY(hipMemsetAsync(c->out.p, 0, sizeof(int32_t) * (size_t)P * OW, sm));
     }
     HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
+    bool stayed = false;
+    if (try_stay) {
+        // steps grouped by the leaf of their top priority node, pass order inside a group (stable counting sort)
+        const int BL = rr.n_leaves;
+        int lbits = 1;
+        while ((1 << lbits) < BL) lbits++;
+        BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * BL + 64, sm, P, c->topkey.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, BL, c->top_counts.as<int32_t>());
+        SCANTRY(BL * nbc, c->top_counts.as<int32_t>());
+        BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(BL + 1, 64), 64, 0, sm, BL, nbc, P, c->top_counts.as<int32_t>(), c->top_off.as<int32_t>());
+        BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * BL + 64, sm, P, c->topkey.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, nbc, BL, lbits,
+                      c->top_counts.as<int32_t>(), c->top_order.as<int32_t>(), (int32_t*)nullptr);
+        StayParams sq;
+        memset(&sq, 0, sizeof sq);
+        sq.N = N; sq.NX = NX; sq.M = M; sq.s = m; sq.k = k; sq.NP = NP; sq.OW = OW; sq.booster_kind = h.booster_kind;
+        sq.wg_region = rr.wg_region.as<int32_t>(); sq.wg_chunk = rr.wg_chunk.as<int32_t>();
+        sq.reg_lo = rr.reg_lo.as<int32_t>(); sq.reg_hi = rr.reg_hi.as<int32_t>();
+        sq.leaf_node = c->leaf_node.as<int32_t>(); sq.leaf_cls = rr.leaf_cls.as<int32_t>(); sq.cls_size = rr.cls_size.as<int32_t>();
+        sq.alive = c->alive.as<uint8_t>(); sq.node_weight = c->node_weight.as<int32_t>(); sq.node_has_weight = c->node_has_weight.as<uint8_t>();
+        sq.cnt = c->cnt.as<int32_t>(); sq.crec = c->crec.as<int32_t>();
+        sq.top_off = c->top_off.as<int32_t>(); sq.top_order = c->top_order.as<int32_t>();
+        sq.out = c->out.as<int32_t>(); sq.flag = scal + 11;
+        HIPTRY(hipMemsetAsync(scal + 11, 0, 4, sm));
+        if (launch_stay_by_top(sm, sq, rr.n_stay_wgs, rr.max_size)) {
+            int32_t sf[8] = {0};                        // [0] a step is not region-local (k_gather_chain), [7] not all stays
+            HIPTRY(hipMemcpyAsync(sf, scal + 4, sizeof sf, hipMemcpyDeviceToHost, sm));
+            HIPTRY(hipStreamSynchronize(sm));
+            launches += 5;
+            stayed = !sf[0] && !sf[7];
+            if (c->trace) fprintf(stderr, "[blance] chain pass state %d: stays verified per top priority node: %s\n", m, stayed ? "all of them" : "no");
+        }
+    }
+    if (stayed) {
+        HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
+        c->pass_kind.resize(n_pass + 1);
+        c->pass_kind[n_pass] = 0;
+        n_pass++;
+        c->last_stays[m] = P;
+        if (dump_pass(c, a.it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
+        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, OW, c->chain_order.as<int32_t>(), c->out.as<int32_t>());
+        launches++;
+        *batched_io += P;
+        *done = true;
+        *launches_io += launches;
+        return 0;
+    }
     // a fresh plan's first sweep: every step blank -> the lean kernel; it either does this rank's
     // whole slice or changes nothing that is not restored below (a rank-local decision: the full
     // kernel makes the same choices)
@@ -1165,6 +1240,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     if (c->trace)
         fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
                 m, fl[2], P, fl[3]);
+    c->last_stays[m] = (!fl[0] && !fl[1]) ? fl[2] : 0;
     if (!fl[0] && !fl[1]) {
         if (sharded) {
             // every rank's chains wrote their own regions' loads and their own steps' outputs
@@ -1226,6 +1302,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     int n_pass = 0;
 
     DevProblem d = dev_problem(c);
+    c->last_stays.assign((size_t)(M > 0 ? M : 1), 0);
 
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 64, sm));
@@ -1348,7 +1425,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                                      c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_one.as<int32_t>(), 1,
-                                     c->crec.as<int32_t>(), scal + 4);
+                                     c->crec.as<int32_t>(), scal + 4, (int32_t*)nullptr);
                 int32_t bad = 0;
                 HIPTRY(hipMemcpyAsync(&bad, scal + 4, sizeof bad, hipMemcpyDeviceToHost, sm));
                 HIPTRY(hipStreamSynchronize(sm));

@@ -107,6 +107,29 @@ struct ChainParams {
                                    // [4] flat mode: first step not done, [5] stopped by the key range
 };
 
+// k_stay_by_top (k_stay.h): a chain pass of stays verified by one thread per top priority node
+constexpr int kStayMaxLeaves = 256;
+struct StayParams {
+    int32_t N, NX, M, s, k, NP, OW, booster_kind;
+    const int32_t* wg_region;      // [grid] region of workgroup b ...
+    const int32_t* wg_chunk;       // ... and which 64 leaves of it: leaf = reg_lo + 64 * chunk + lane
+    const int32_t* reg_lo;
+    const int32_t* reg_hi;
+    const int32_t* leaf_node;
+    const int32_t* leaf_cls;
+    const int32_t* cls_size;
+    const uint8_t* alive;
+    const int32_t* node_weight;
+    const uint8_t* node_has_weight;
+    const int32_t* cnt;
+    const int32_t* top_off;        // [n_leaves + 1]
+    const int32_t* crec;           // compact step records, chain order
+    const int32_t* top_order;      // chain indices grouped by top leaf
+    int32_t* out;
+    int32_t* flag;                 // set to 1 by any step that is not a certain stay
+};
+
+
 // Flat (no hierarchy rule) passes resolved in bulk: DESIGN.md "Flat bulk engine".
 constexpr int kTopList = 8;      // smallest partition-independent scores kept for the stay test
 

@@ -37,4 +37,6 @@ bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
 void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size);
 // k_pass_chain_planes (tu_chain.hip): the all-blank pass as a scalar bit-plane automaton; false: shape outside it
 bool launch_chain_planes(hipStream_t stream, const ChainParams& q, int max_size);
+// k_stay_by_top (tu_chain.hip): a chain pass of stays, one thread per top priority node; false: shape outside it
+bool launch_stay_by_top(hipStream_t stream, const StayParams& q, int n_wgs, int max_size);
 }  // namespace blance

@@ -170,10 +170,14 @@ __global__ void k_flat_commit_stay(FlatParams q, int beg, int end) {
 }
 
 // ---- fresh identical run: how many of the R picks each node receives --------
+// (score of node n after c picks of weight w; hasw / nw: the node's weight, loaded by the caller)
+__device__ __forceinline__ unsigned long long fresh_key_w(const FlatParams& q, int hasw, int nw, int cnt0, int tot0, int ntn0,
+                                                          int w, int c) {
+    return sortable_key(node_score(cnt0 + c * w, ntn0 + c, tot0 + c * w, hasw, nw, q.NP, 0.0, q.booster_kind));
+}
 __device__ __forceinline__ unsigned long long fresh_key(const FlatParams& q, int n, int cnt0, int tot0, int ntn0,
                                                         int w, int c) {
-    return sortable_key(node_score(cnt0 + c * w, ntn0 + c, tot0 + c * w, q.node_has_weight[n], q.node_weight[n],
-                                   q.NP, 0.0, q.booster_kind));
+    return fresh_key_w(q, q.node_has_weight[n], q.node_weight[n], cnt0, tot0, ntn0, w, c);
 }
 
 // #{c in [0, R): key(n, c) <= tau}; the keys grow with c
@@ -198,21 +202,31 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
     // the inner searches shrink with the outer one (a node's count is monotone in tau)
     constexpr int kPer = 8;                          // N <= 8192 = 8 * 1024
     int c_lo[kPer], c_hi[kPer], c_mid[kPer];
+    // this thread's nodes: their counters stay in registers over the ~60 probes of the search
+    int n_c0[kPer], n_t0[kPer], n_nt[kPer], n_hw[kPer], n_nw[kPer];
+    bool n_on[kPer];
 #pragma unroll
-    for (int i = 0; i < kPer; i++) { c_lo[i] = 0; c_hi[i] = R; c_mid[i] = 0; }
+    for (int i = 0; i < kPer; i++) {
+        c_lo[i] = 0; c_hi[i] = R; c_mid[i] = 0;
+        const int n = tid + i * 1024;
+        n_on[i] = n < q.N && q.alive[n];
+        n_c0[i] = n_on[i] ? q.cnt[q.s * q.NX + n] : 0;
+        n_t0[i] = n_on[i] ? q.tot[n] : 0;
+        n_nt[i] = (n_on[i] && q.NP > 0) ? q.ntn[(size_t)q.NX * q.N + n] : 0;
+        n_hw[i] = n_on[i] ? q.node_has_weight[n] : 0;
+        n_nw[i] = n_on[i] ? q.node_weight[n] : 0;
+    }
     while (lo < hi) {
         unsigned long long mid = lo + (hi - lo) / 2;
         long long sum = 0;
 #pragma unroll
         for (int i = 0; i < kPer; i++) {
-            const int n = tid + i * 1024;
-            if (n >= q.N || !q.alive[n]) continue;
-            int ntn0 = q.NP > 0 ? q.ntn[(size_t)q.NX * q.N + n] : 0;
-            const int c0 = q.cnt[q.s * q.NX + n], t0 = q.tot[n];
+            if (!n_on[i]) continue;
+            const int ntn0 = n_nt[i], c0 = n_c0[i], t0 = n_t0[i];
             int a = c_lo[i], b = c_hi[i];            // first c in [a, b] with key > mid
             while (a < b) {
                 int m = a + (b - a) / 2;
-                if (fresh_key(q, n, c0, t0, ntn0, w, m) <= mid) a = m + 1; else b = m;
+                if (fresh_key_w(q, n_hw[i], n_nw[i], c0, t0, ntn0, w, m) <= mid) a = m + 1; else b = m;
             }
             c_mid[i] = a;
             sum += a;

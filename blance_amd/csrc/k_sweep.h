@@ -217,8 +217,9 @@ __global__ void k_chain_orphans(DevProblem d, int m, int top_state, const int32_
 
 // Compact chain records (layout: blance_kernels.h): the step's nodes as leaf
 // indices local to its region.  Steps the chain kernel cannot represent raise flags[0].
-// one step's compact record (24 words at r)
-__device__ __forceinline__ void gather_chain_record(const DevProblem& d, int m, int top_state, int higher_mask, int p, int oi,
+// one step's compact record (24 words at r); returns the global leaf index of the step's top priority node (0 if it has
+// none inside a region: flags[0] is raised for such a step)
+__device__ __forceinline__ int gather_chain_record(const DevProblem& d, int m, int top_state, int higher_mask, int p, int oi,
                                                     const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
                                                     const int32_t* node_leaf_pos, const int32_t* node_region,
                                                     const int32_t* reg_lo, const int32_t* leaf_cls, const int32_t* cls_size,
@@ -234,7 +235,7 @@ __device__ __forceinline__ void gather_chain_record(const DevProblem& d, int m, 
     int idxT = p * d.M + top_state;
     int top = (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) ? d.live[(size_t)idxT * d.L] : -1;
     int rg = flat ? 0 : (top >= 0 ? node_region[top] : -1);
-    if (rg < 0) { flags[0] = 1; r[4] = 0; r[5] = 0; r[6] = -1; return; }
+    if (rg < 0) { flags[0] = 1; r[4] = 0; r[5] = 0; r[6] = -1; return 0; }
     const int lo = reg_lo[rg];
     if (flat) {
         r[4] = top >= 0 ? top : d.NX;              // the "" row when there is no top priority node
@@ -283,6 +284,7 @@ __device__ __forceinline__ void gather_chain_record(const DevProblem& d, int m, 
     }
     r[5] = n_own | (n_h << 8) | (n_low << 16) | (present << 24) | (remote << 25);
     if (bad) flags[0] = 1;
+    return flat ? 0 : lo + r[4];
 }
 
 __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_mask, const int32_t* chain_order,
@@ -290,7 +292,7 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
                                const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
                                const int32_t* node_leaf_pos, const int32_t* node_region, const int32_t* reg_lo,
                                const int32_t* leaf_cls, const int32_t* cls_size, int flat, int32_t* crec,
-                               int32_t* flags) {
+                               int32_t* flags, int32_t* topkey /* or null: global leaf of the step's top priority node */) {
     // a thread builds its record in LDS (row stride kCW + 1: no bank conflicts); the workgroup then writes its
     // 256 records as one contiguous block -- per-thread 24-word rows written straight to HBM cost 3.7 times
     // their bytes in write traffic (rocprofv3 WRITE_SIZE, round 2)
@@ -298,8 +300,11 @@ __global__ void k_gather_chain(DevProblem d, int m, int top_state, int higher_ma
     const int tid = threadIdx.x;
     const int i = blockIdx.x * blockDim.x + tid;
     int32_t* r = (int32_t*)lds + tid * (kCW + 1);
-    if (i < d.P) gather_chain_record(d, m, top_state, higher_mask, chain_order[i], chain_oi ? chain_oi[i] : i, state_stickiness,
-                                     state_has_stickiness, node_leaf_pos, node_region, reg_lo, leaf_cls, cls_size, flat, r, flags);
+    if (i < d.P) {
+        const int tl = gather_chain_record(d, m, top_state, higher_mask, chain_order[i], chain_oi ? chain_oi[i] : i, state_stickiness,
+                                           state_has_stickiness, node_leaf_pos, node_region, reg_lo, leaf_cls, cls_size, flat, r, flags);
+        if (topkey) topkey[i] = tl;
+    }
     __syncthreads();
     const int first = blockIdx.x * blockDim.x;
     const int n_here = d.P - first < (int)blockDim.x ? d.P - first : (int)blockDim.x;

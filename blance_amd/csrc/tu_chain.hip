@@ -1,6 +1,7 @@
 // Translation unit of k_pass_chain / k_pass_chain_blank: region chains and their launch wrappers.
 #include "dev_prelude.h"
 #include "k_pass_chain.h"
+#include "k_stay.h"
 
 namespace blance {
 
@@ -72,6 +73,15 @@ bool launch_chain_planes(hipStream_t stream, const ChainParams& q, int max_size)
     if (max_size > 128 || q.k > 4 || q.k < 1) return false;
     const size_t lds = sizeof(int32_t) * (64 * 2 + 64 * 2 * 2 * 2) + 64;
     return launch_planes_w<2>(stream, q, lds);
+}
+
+
+bool launch_stay_by_top(hipStream_t stream, const StayParams& q, int n_wgs, int max_size) {
+    if (max_size > kStayMaxLeaves || q.k < 1 || q.k > 4 || n_wgs < 1) return false;
+    const size_t lds = sizeof(int32_t) * (size_t)max_size * (7 + 64) + 64;
+    if (q.k <= 2) { auto kern = k_stay_by_top<2>; BLANCE_LAUNCH(kern, n_wgs, 64, lds, stream, q); }
+    else { auto kern = k_stay_by_top<4>; BLANCE_LAUNCH(kern, n_wgs, 64, lds, stream, q); }
+    return true;
 }
 
 }  // namespace blance

@@ -80,7 +80,7 @@ class Planner:
     """One blance_ctx: a planner bound to one gfx950 device."""
 
     def __init__(self, device_id=0, engine=abi.ENGINE_AUTO, lib_path=None, force_threads=0,
-                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True):
+                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True, stay_top="auto"):
         self.lib = load_library(lib_path)
         opt = abi.Options()
         opt.engine = engine
@@ -91,7 +91,9 @@ class Planner:
         # 4 = every general step scores all nodes, 8 = also when a k_pass_seq workgroup size is forced,
         # 16 = every general step decodes its record (none served from the validating lane's registers)
         # 32 = the all-blank chain pass on k_pass_chain_blank (lane minima) instead of k_pass_chain_planes
-        opt.reserved[2] = (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
+        # 64 = never k_stay_by_top (a chain pass of stays verified per top priority node), 128 = try it in every
+        # chain pass with NumPartitions > 0
+        opt.reserved[2] = {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))

@@ -422,3 +422,25 @@ def test_tree_pass_flat_three_and_four_copies(planner, k):
         _same(planner.plan(fp), _oracle(fp), ("random flat k", k, seed))
         n += 1
     assert n > 80
+
+
+def test_stays_verified_per_top_priority_node():
+    """k_stay_by_top on the device: forced in every chain pass with NumPartitions > 0 (random regular hierarchies: mostly
+    refused, the chain kernel redoes the pass), taken on its own in config 3's converged sweep, switched off."""
+    pl = hip.Planner(device_id=0, chain_min_parts=1, stay_top="force")
+    n = 0
+    for seed in range(300):
+        try:
+            fp = build_from_case(random_regular_case(seed))
+        except problem.Unsupported:
+            continue
+        _same(pl.plan(fp), _oracle(fp), ("forced stay verification", seed))
+        n += 1
+    assert n > 200
+    pl.close()
+    for mode in ("auto", "off", "force"):
+        pl = hip.Planner(device_id=0, stay_top=mode)
+        for P, N in ((16384, 1024), (20000, 777), (4096, 4096)):
+            fp = synth.config_flat(3, P=P, N=N)
+            _same(pl.plan(fp), _oracle(fp), ("cfg3", mode, P, N))
+        pl.close()

@@ -107,6 +107,28 @@ def test_region_chains(emu_lib):
     pl.close()
 
 
+def test_stays_verified_per_top_priority_node(emu_lib):
+    """k_stay_by_top tried in EVERY chain pass with NumPartitions > 0 (knob "force"): passes of stays are taken by it,
+    any other pass makes it raise its flag and the chain kernel redoes the pass -- same results either way; and the
+    converged sweep of config 3's shape is one it takes on its own ("auto")."""
+    pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1, stay_top="force")
+    for seed in range(100, 180):
+        try:
+            fp = build_from_case(random_regular_case(seed))
+        except problem.Unsupported:
+            continue
+        got, want = pl.plan(fp), _oracle(fp)
+        assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
+    for fp in (synth.config_flat(3, P=3000, N=256), synth.config_flat(3, P=900, N=300)):
+        assert pl.plan(fp).digest() == _oracle(fp).digest()
+    pl.close()
+    for mode in ("auto", "off"):
+        pl = hip.Planner(lib_path=emu_lib, chain_min_parts=8, stay_top=mode)
+        fp = synth.config_flat(3, P=4096, N=256)
+        assert pl.plan(fp).digest() == _oracle(fp).digest()
+        pl.close()
+
+
 def test_random_instances_bulk_engines(emu_lib):
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     n = bulk = 0
