@@ -8,6 +8,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -632,7 +633,7 @@ extern "C" {
 int blance_wire_abi_version(void) { return kAbiVersion; }
 const char* blance_wire_last_error(void) { return g_err.c_str(); }
 
-int blance_wire_decode(const char* json, size_t len, blance_wire_map** out) {
+int blance_wire_decode(const char* json, size_t len, blance_wire_map** out) try {
     if (!out || (!json && len)) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
     *out = nullptr;
     blance_wire_map* m = new blance_wire_map();
@@ -646,6 +647,10 @@ int blance_wire_decode(const char* json, size_t len, blance_wire_map** out) {
     }
     *out = m;
     return BLANCE_WIRE_OK;
+} catch (const std::bad_alloc&) {
+    return fail(BLANCE_WIRE_ERR_ARG, "out of memory");           // no exception crosses the C boundary
+} catch (...) {
+    return fail(BLANCE_WIRE_ERR_ARG, "unexpected exception");
 }
 
 int blance_wire_view_of(const blance_wire_map* m, blance_wire_view* v) {
@@ -790,7 +795,7 @@ int encode_to(const blance_wire_view* v, std::string& o) {
 
 extern "C" {
 
-int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_len) {
+int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_len) try {
     if (!v || !out_json || !out_len) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
     std::string o;
     const int st = encode_to(v, o);
@@ -802,9 +807,13 @@ int blance_wire_encode(const blance_wire_view* v, char** out_json, size_t* out_l
     *out_json = buf;
     *out_len = o.size();
     return BLANCE_WIRE_OK;
+} catch (const std::bad_alloc&) {
+    return fail(BLANCE_WIRE_ERR_ARG, "out of memory");           // no exception crosses the C boundary
+} catch (...) {
+    return fail(BLANCE_WIRE_ERR_ARG, "unexpected exception");
 }
 
-int blance_wire_encode_into(const blance_wire_view* v, char* buf, size_t cap, size_t* need) {
+int blance_wire_encode_into(const blance_wire_view* v, char* buf, size_t cap, size_t* need) try {
     if (!v || !need || (!buf && cap)) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
     std::string o;
     const int st = encode_to(v, o);
@@ -813,9 +822,13 @@ int blance_wire_encode_into(const blance_wire_view* v, char* buf, size_t cap, si
     if (o.size() > cap) return fail(BLANCE_WIRE_ERR_SPACE, "the caller's buffer is too small (see *need)");
     memcpy(buf, o.data(), o.size());
     return BLANCE_WIRE_OK;
+} catch (const std::bad_alloc&) {
+    return fail(BLANCE_WIRE_ERR_ARG, "out of memory");           // no exception crosses the C boundary
+} catch (...) {
+    return fail(BLANCE_WIRE_ERR_ARG, "unexpected exception");
 }
 
-int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b, blance_wire_view* view) {
+int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b, blance_wire_view* view) try {
     if (!b || !view) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
     blance_wire_map* m = nullptr;
     int st = blance_wire_decode(json, len, &m);
@@ -857,6 +870,10 @@ int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b
     view->entry_off = b->entry_off;     view->entry_nodes = b->entry_nodes;
     blance_wire_free(m);
     return BLANCE_WIRE_OK;
+} catch (const std::bad_alloc&) {
+    return fail(BLANCE_WIRE_ERR_ARG, "out of memory");           // no exception crosses the C boundary
+} catch (...) {
+    return fail(BLANCE_WIRE_ERR_ARG, "unexpected exception");
 }
 
 }  // extern "C"

@@ -27,7 +27,8 @@ emu_switch:
 .size emu_switch, .-emu_switch
 )");
 namespace emu {
-thread_local Block* t_block = nullptr;
-thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+Block* t_block = nullptr;
+dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+std::mutex g_launch_mu;
 }
 #include "../../blance_amd/csrc/blance_hip.hip"

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -33,7 +34,7 @@
 
 struct dim3 {
     unsigned x, y, z;
-    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+    constexpr dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 
 namespace emu {
@@ -64,9 +65,11 @@ struct Block {
     int cur = -1;
     std::function<void()> body;
 };
-// thread_local: several contexts may run kernels from several host threads (a fiber never leaves its OS thread)
-extern thread_local Block* t_block;
-extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+// one launch at a time: several contexts may be driven from several host threads (tests/test_dist.py), the
+// emulator's state is global -- launches take g_launch_mu (plain globals keep threadIdx a load, not a TLS call)
+extern Block* t_block;
+extern dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern std::mutex g_launch_mu;
 
 inline void barrier_wait(Barrier& b) {
     Block* blk = t_block;
@@ -101,6 +104,7 @@ inline void fiber_entry() {
 
 template <class F>
 void launch_threads(dim3 grid, dim3 block, size_t lds_bytes, F body) {
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     t_blockDim = block; t_gridDim = grid;
     for (unsigned b = 0; b < grid.x; b++) {
         Block blk;
@@ -121,7 +125,7 @@ void launch_threads(dim3 grid, dim3 block, size_t lds_bytes, F body) {
         t_blockIdx = dim3(b);
         for (unsigned t = 0; t < block.x; t++) {
             Fiber& f = blk.fibers[t];
-            static thread_local std::vector<unsigned char*> pool;
+            static std::vector<unsigned char*> pool;
             if (pool.size() <= t) pool.resize(t + 1, nullptr);
             if (!pool[t]) pool[t] = (unsigned char*)malloc(kStackBytes);
             f.stack = pool[t];
@@ -158,6 +162,7 @@ void launch_threads(dim3 grid, dim3 block, size_t lds_bytes, F body) {
 
 template <class F>
 void launch_serial(dim3 grid, dim3 block, F body) {
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     t_block = nullptr;
     t_blockDim = block; t_gridDim = grid;
     for (unsigned b = 0; b < grid.x; b++)

@@ -92,7 +92,7 @@ def test_region_chains(emu_lib):
     verified-stay speculation) and its escape to the sequential pass."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     chains = 0
-    for seed in range(0, 100):               # the GPU suite walks 800 of these (tests/test_hip_parity.py)
+    for seed in range(0, 60):                # the GPU suite walks 800 of these (tests/test_hip_parity.py)
         try:
             fp = build_from_case(random_regular_case(seed))
         except problem.Unsupported:
@@ -100,7 +100,7 @@ def test_region_chains(emu_lib):
         got = pl.plan(fp)
         assert got.digest() == _oracle(fp).digest(), seed
         chains += got.struct.steps_batched > 0
-    assert chains >= 45
+    assert chains >= 25
     fp = synth.config_flat(3, P=160, N=200)
     got = pl.plan(fp)
     assert got.digest() == _oracle(fp).digest() and got.struct.steps_batched > 0
@@ -112,7 +112,7 @@ def test_stays_verified_per_top_priority_node(emu_lib):
     any other pass makes it raise its flag and the chain kernel redoes the pass -- same results either way; and the
     converged sweep of config 3's shape is one it takes on its own ("auto")."""
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1, stay_top="force")
-    for seed in range(100, 180):
+    for seed in range(100, 145):
         try:
             fp = build_from_case(random_regular_case(seed))
         except problem.Unsupported:
@@ -132,7 +132,7 @@ def test_stays_verified_per_top_priority_node(emu_lib):
 def test_random_instances_bulk_engines(emu_lib):
     pl = hip.Planner(lib_path=emu_lib, force_threads=64, chain_min_parts=1)
     n = bulk = 0
-    for seed in range(600, 780):             # the GPU suite walks 1,000 of these
+    for seed in range(600, 700):             # the GPU suite walks 1,000 of these
         try:
             fp = build_from_case(random_case(seed))
         except problem.Unsupported:
@@ -141,7 +141,7 @@ def test_random_instances_bulk_engines(emu_lib):
         assert got.digest() == _oracle(fp).digest(), seed
         n += 1
         bulk += got.struct.steps_batched > 0
-    assert n > 115 and bulk > 25
+    assert n > 60 and bulk > 12
     pl.close()
 
 
@@ -279,7 +279,7 @@ def test_fresh_runs_with_excluded_node(emu_lib):
     model = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": 1}}
     pl = hip.Planner(lib_path=emu_lib, chain_min_parts=1)
     bulk = 0
-    for seed in range(40):
+    for seed in range(24):
         rnd = random.Random(seed)
         n = rnd.choice([2, 3, 5, 9, 40, 70])
         nodes = ["n%02d" % i for i in range(n)]
@@ -296,7 +296,7 @@ def test_fresh_runs_with_excluded_node(emu_lib):
         got, want = pl.plan(fp), _oracle(fp)
         assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
         bulk += got.struct.steps_batched > 0
-    assert bulk > 20
+    assert bulk > 10
     pl.close()
 
 
@@ -307,7 +307,7 @@ def test_fresh_runs_two_picks(emu_lib):
     import random
     pl = hip.Planner(lib_path=emu_lib, chain_min_parts=1)
     bulk = 0
-    for seed in range(36):
+    for seed in range(18):
         rnd = random.Random(1000 + seed)
         n = rnd.choice([2, 3, 4, 7, 30, 70])
         nodes = ["n%02d" % i for i in range(n)]
@@ -329,7 +329,7 @@ def test_fresh_runs_two_picks(emu_lib):
         got, want = pl.plan(fp), _oracle(fp)
         assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
         bulk += got.struct.steps_batched > 0
-    assert bulk > 20
+    assert bulk > 9
     for fp in (synth.config5_initial(400, 60), synth.config5_initial(900, 30)):
         assert pl.plan(fp).digest() == _oracle(fp).digest()
     pl.close()

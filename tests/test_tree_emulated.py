@@ -50,7 +50,7 @@ def test_random_instances_tree(emu_lib):
 def test_random_instances_tree_dense_and_bulk(emu_lib):
     pd = hip.Planner(lib_path=emu_lib, tree="dense")
     pb = hip.Planner(lib_path=emu_lib, tree="long", chain_min_parts=1)
-    for seed in range(500, 640):             # (the GPU suite walks 300 of these in dense mode)
+    for seed in range(500, 580):             # (the GPU suite walks 300 of these in dense mode)
         try:
             fp = build_from_case(random_case(seed))
         except problem.Unsupported:
@@ -132,7 +132,7 @@ def test_flat_three_and_four_copies_tree(emu_lib, k):
     modes, and the weighted rebalance shape."""
     planners = [hip.Planner(lib_path=emu_lib, tree=mode) for mode in ("on", "dense", "long")]
     n = 0
-    for seed in range(150):
+    for seed in range(70):
         try:
             fp = build_from_case(random_flat_wide_case(seed, k))
         except problem.Unsupported:
@@ -142,7 +142,7 @@ def test_flat_three_and_four_copies_tree(emu_lib, k):
             got = pl.plan(fp)
             assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
         n += 1
-    assert n > 100
+    assert n > 45
     model = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
     _rebalance(planners[0], 160, 30, model=model)
     _rebalance(planners[0], 200, 150, model=model)
