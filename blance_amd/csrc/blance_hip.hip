@@ -102,6 +102,7 @@ struct blance_ctx {
         DevBuf node_region, reg_lo, reg_hi, leaf_cls, cls_size;
         DevBuf wg_region, wg_chunk;     // k_stay_by_top: workgroup b walks the tops at leaves reg_lo + 64 chunk + lane of its region
         int n_stay_wgs = 0, n_leaves = 0;
+        int cls_run = 0;                // S if every exclude class is an aligned run of S = 2^e <= 64 node-carrying leaves, else 0
     };
     std::vector<RuleRegions> rule_regions;
     DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save, crec;
@@ -466,6 +467,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
             // pairwise disjoint (racks inside a zone), so "leaf is excluded by anchor a"
             // is "leaf has a's class".  Intervals that cover the region get class -1.
             std::vector<int32_t> leaf_cls((size_t)n_leaves, -1), cls_size((size_t)n_leaves, 0);
+            int cls_run = -1;
             for (size_t g = 0; g < rlo.size() && ok; g++) {
                 std::vector<std::pair<int, int>> cl;
                 for (int lp = rlo[g]; lp < rhi[g]; lp++) {
@@ -477,6 +479,12 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
                 std::sort(cl.begin(), cl.end());
                 cl.erase(std::unique(cl.begin(), cl.end()), cl.end());
                 for (size_t i = 1; i < cl.size() && ok; i++) if (cl[i].first < cl[i - 1].second) ok = false;
+                for (size_t i = 0; i < cl.size() && ok; i++) {       // equal, aligned, power-of-two runs? (k_pass_chain_planes)
+                    const int sz = cl[i].second - cl[i].first;
+                    if (cls_run == -1) cls_run = sz;
+                    if (sz != cls_run || sz < 1 || sz > 64 || (sz & (sz - 1)) || (cl[i].first - rlo[g]) % sz) cls_run = 0;
+                    for (int lp = cl[i].first; lp < cl[i].second && cls_run > 0; lp++) if (leaf_node[lp] < 0) cls_run = 0;
+                }
                 for (size_t i = 0; i < cl.size() && ok; i++) cls_size[rlo[g] + i] = cl[i].second - cl[i].first;
                 for (int lp = rlo[g]; lp < rhi[g] && ok; lp++) {
                     int a = leaf_node[lp];
@@ -493,6 +501,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
             rr.n_regions = ok ? (int)rlo.size() : 0;
             rr.max_size = max_size;
             rr.n_leaves = n_leaves;
+            rr.cls_run = ok && cls_run > 0 ? cls_run : 0;
             std::vector<int32_t> wg_region, wg_chunk;
             if (ok)
                 for (size_t g = 0; g < rlo.size(); g++)
@@ -1115,6 +1124,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
     cq.NP = NP; cq.OW = OW; cq.booster_kind = h.booster_kind;
     cq.n_regions = B;
+    cq.cls_run = rr.cls_run;
     // a sharded plan: this rank walks the chains of its slice of the regions
     auto slice_lo = [&](int r) { return (int)((int64_t)B * r / G); };
     cq.region_base = sharded ? slice_lo(rank) : 0;

@@ -77,6 +77,8 @@ struct ChainParams {
     int32_t n_regions, ntn_in_lds;
     int32_t region_base, n_launch; // regions [region_base, region_base + n_launch) run in this launch (a rank of a
                                    // sharded plan runs a slice of the regions)
+    int32_t cls_run;               // k_pass_chain_planes: S if every exclude class of the rule is an aligned run of S = 2^e <= 64
+                                   // leaves that all carry nodes (racks of equal size), else 0
     int32_t flat;                  // the whole cluster is ONE region and every node its own exclude class:
                                    // a state pass without hierarchy rules (leaf index = node id); a chain that
                                    // cannot go on stops, keeps what it did and reports the step in flags[4]

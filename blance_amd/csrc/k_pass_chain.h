@@ -998,25 +998,43 @@ __device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes]
     "s_lshl_b64 " T ", 1, s56\n\t"                               \
     "s_xor_b64 %[" #FROM "], %[" #FROM "], " T "\n\t"            \
     "s_or_b64 %[" #TO "], %[" #TO "], " T "\n\t"
-#define BLANCE_PL_CLASS(SET)                                     \
-    "v_readlane_b32 s48, %[lm" #SET "0], s56\n\t"                \
-    "v_readlane_b32 s49, %[lm" #SET "1], s56\n\t"                \
-    "v_readlane_b32 s50, %[lm" #SET "2], s56\n\t"                \
-    "v_readlane_b32 s51, %[lm" #SET "3], s56\n\t"                \
+// the picked leaf's exclude class joins the step's mask: its class mask read from the lanes (any classes) ...
+#define BLANCE_PL_CLASS_0                                        \
+    "v_readlane_b32 s48, %[lm00], s56\n\t"                       \
+    "v_readlane_b32 s49, %[lm01], s56\n\t"                       \
+    "v_readlane_b32 s50, %[lm02], s56\n\t"                       \
+    "v_readlane_b32 s51, %[lm03], s56\n\t"                       \
     "s_or_b64 s[44:45], s[44:45], s[48:49]\n\t"                  \
     "s_or_b64 s[46:47], s[46:47], s[50:51]\n\t"
+#define BLANCE_PL_CLASS_1                                        \
+    "v_readlane_b32 s48, %[lm10], s56\n\t"                       \
+    "v_readlane_b32 s49, %[lm11], s56\n\t"                       \
+    "v_readlane_b32 s50, %[lm12], s56\n\t"                       \
+    "v_readlane_b32 s51, %[lm13], s56\n\t"                       \
+    "s_or_b64 s[44:45], s[44:45], s[48:49]\n\t"                  \
+    "s_or_b64 s[46:47], s[46:47], s[50:51]\n\t"
+// ... or made by arithmetic when every class is an aligned run of S = 2^e <= 64 leaves (racks of equal size): the run
+// of the picked bit inside its own word -- 3 scalar instructions instead of 4 lane reads and 2 ors
+#define BLANCE_PL_CLASS_A0                                       \
+    "s_andn2_b32 s48, s56, %[sm1]\n\t"                           \
+    "s_lshl_b64 s[48:49], %[sones], s48\n\t"                     \
+    "s_or_b64 s[44:45], s[44:45], s[48:49]\n\t"
+#define BLANCE_PL_CLASS_A1                                       \
+    "s_andn2_b32 s48, s56, %[sm1]\n\t"                           \
+    "s_lshl_b64 s[48:49], %[sones], s48\n\t"                     \
+    "s_or_b64 s[46:47], s[46:47], s[48:49]\n\t"
 #define BLANCE_PL_TAIL                                           \
     "s_add_u32 %[r], %[r], 1\n\t"                                \
     "s_cmp_lt_u32 %[r], %[nb]\n\t"                               \
     "s_cbranch_scc1 0b\n\t"                                      \
     "s_branch 7f\n"
 // both words' paths of a pick from plane (PL, PH) into (QL, QH); CONT: what follows the pick
-#define BLANCE_PL_WORDS_MORE(SLOT, PL, PH, QL, QH, W1, CONT)     \
-    BLANCE_PL_TAKE("s[52:53]", PL, QL) BLANCE_PL_CLASS(0)        \
+#define BLANCE_PL_WORDS_MORE(SLOT, PL, PH, QL, QH, W1, CONT, C0, C1) \
+    BLANCE_PL_TAKE("s[52:53]", PL, QL) C0                        \
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
     "s_branch " CONT "\n"                                        \
     W1 ":\n\t"                                                   \
-    BLANCE_PL_TAKE("s[54:55]", PH, QH) BLANCE_PL_CLASS(1)        \
+    BLANCE_PL_TAKE("s[54:55]", PH, QH) C1                        \
     "s_or_b32 s56, s56, 64\n\t"                                  \
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"
 #define BLANCE_PL_WORDS_LAST(SLOT, PL, PH, QL, QH, W1)           \
@@ -1029,9 +1047,9 @@ __device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes]
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
     BLANCE_PL_TAIL
 // in the loop: a pick from plane 0 (labels 1<slot> .. 3<slot>); behind the loop: the same pick from plane 1
-#define BLANCE_PL_PICK_MORE(SLOT)                                \
+#define BLANCE_PL_PICK_MORE(SLOT, C0, C1)                        \
     BLANCE_PL_FIND(p0l, p0h, "5" #SLOT "f", "2" #SLOT "f")       \
-    BLANCE_PL_WORDS_MORE(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT, "3" #SLOT "f") \
+    BLANCE_PL_WORDS_MORE(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT, "3" #SLOT "f", C0, C1) \
     "3" #SLOT ":\n\t"
 #define BLANCE_PL_PICK_LAST(SLOT)                                \
     BLANCE_PL_FIND(p0l, p0h, "5" #SLOT "f", "2" #SLOT "f")       \
@@ -1041,9 +1059,9 @@ __device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes]
     "s_or_b64 s[48:49], %[p0l], %[p0h]\n\t"                      \
     "s_cbranch_scc0 9" #SLOT "f\n\t"                             \
     BLANCE_PL_FIND(p1l, p1h, "9" #SLOT "f", "6" #SLOT "f")
-#define BLANCE_PL_SLOW_MORE(SLOT)                                \
+#define BLANCE_PL_SLOW_MORE(SLOT, C0, C1)                        \
     BLANCE_PL_SLOW_HEAD(SLOT)                                    \
-    BLANCE_PL_WORDS_MORE(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT, "3" #SLOT "b") \
+    BLANCE_PL_WORDS_MORE(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT, "3" #SLOT "b", C0, C1) \
     "s_branch 3" #SLOT "b\n"                                     \
     "9" #SLOT ":\n\ts_mov_b32 %[slot], " #SLOT "\n\ts_branch 7f\n"
 #define BLANCE_PL_SLOW_LAST(SLOT)                                \
@@ -1057,32 +1075,46 @@ __device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes]
 #define BLANCE_PL_INPUTS                                                                                            \
     [nb] "s"(nb), [ex0] "v"(ex[0]), [ex1] "v"(ex[1]), [ex2] "v"(ex[2]), [ex3] "v"(ex[3]),                           \
     [lm00] "v"(lm[0][0]), [lm01] "v"(lm[0][1]), [lm02] "v"(lm[0][2]), [lm03] "v"(lm[0][3]),                         \
-    [lm10] "v"(lm[1][0]), [lm11] "v"(lm[1][1]), [lm12] "v"(lm[1][2]), [lm13] "v"(lm[1][3])
+    [lm10] "v"(lm[1][0]), [lm11] "v"(lm[1][1]), [lm12] "v"(lm[1][2]), [lm13] "v"(lm[1][3]),                         \
+    [sm1] "s"(cls_m1), [sones] "s"(cls_ones)
 #define BLANCE_PL_CLOBBER "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "m0", "scc"
 
-template <int K>
+// ARITH: the exclude classes are aligned runs of cls_m1 + 1 = 2^e leaves (cls_ones = that many one bits)
+template <int K, bool ARITH>
 __device__ __forceinline__ void planes_walk_w2(unsigned long long (&P)[kPlanes][2], unsigned long long (&E)[2], int& r, int nb,
-                                               int& slot, const unsigned (&ex)[4], const unsigned (&lm)[2][4], int (&my_w)[K]) {
-    if constexpr (K == 1) {
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_LAST(0) BLANCE_PL_SLOW_LAST(0) BLANCE_PL_EXIT
-                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
-    } else if constexpr (K == 2) {
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0) BLANCE_PL_PICK_LAST(1) BLANCE_PL_SLOW_MORE(0) BLANCE_PL_SLOW_LAST(1) BLANCE_PL_EXIT
-                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
-    } else if constexpr (K == 3) {
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0) BLANCE_PL_PICK_MORE(1) BLANCE_PL_PICK_LAST(2)
-                     BLANCE_PL_SLOW_MORE(0) BLANCE_PL_SLOW_MORE(1) BLANCE_PL_SLOW_LAST(2) BLANCE_PL_EXIT
-                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
-    } else {
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0) BLANCE_PL_PICK_MORE(1) BLANCE_PL_PICK_MORE(2) BLANCE_PL_PICK_LAST(3)
-                     BLANCE_PL_SLOW_MORE(0) BLANCE_PL_SLOW_MORE(1) BLANCE_PL_SLOW_MORE(2) BLANCE_PL_SLOW_LAST(3) BLANCE_PL_EXIT
-                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2]), [w3] "+v"(my_w[3])
-                     : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);
+                                               int& slot, const unsigned (&ex)[4], const unsigned (&lm)[2][4], int (&my_w)[K],
+                                               int cls_m1_in, unsigned long long cls_ones_in) {
+    // (wave-uniform by construction; the asm wants them in SGPRs)
+    const int cls_m1 = __builtin_amdgcn_readfirstlane(cls_m1_in);
+    const unsigned long long cls_ones = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cls_ones_in) |
+                                        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cls_ones_in >> 32)) << 32);
+#define BLANCE_PL_BODY(C0, C1)                                                                                                        \
+    if constexpr (K == 1) {                                                                                                           \
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_LAST(0) BLANCE_PL_SLOW_LAST(0) BLANCE_PL_EXIT                                      \
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);                                \
+    } else if constexpr (K == 2) {                                                                                                    \
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1) BLANCE_PL_PICK_LAST(1) BLANCE_PL_SLOW_MORE(0, C0, C1)              \
+                     BLANCE_PL_SLOW_LAST(1) BLANCE_PL_EXIT                                                                            \
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);            \
+    } else if constexpr (K == 3) {                                                                                                    \
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1) BLANCE_PL_PICK_MORE(1, C0, C1) BLANCE_PL_PICK_LAST(2)              \
+                     BLANCE_PL_SLOW_MORE(0, C0, C1) BLANCE_PL_SLOW_MORE(1, C0, C1) BLANCE_PL_SLOW_LAST(2) BLANCE_PL_EXIT              \
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2])                                 \
+                     : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);                                                                         \
+    } else {                                                                                                                          \
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1) BLANCE_PL_PICK_MORE(1, C0, C1) BLANCE_PL_PICK_MORE(2, C0, C1)      \
+                     BLANCE_PL_PICK_LAST(3) BLANCE_PL_SLOW_MORE(0, C0, C1) BLANCE_PL_SLOW_MORE(1, C0, C1)                             \
+                     BLANCE_PL_SLOW_MORE(2, C0, C1) BLANCE_PL_SLOW_LAST(3) BLANCE_PL_EXIT                                             \
+                     : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2]), [w3] "+v"(my_w[3])             \
+                     : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);                                                                         \
     }
+    if constexpr (ARITH) { BLANCE_PL_BODY(BLANCE_PL_CLASS_A0, BLANCE_PL_CLASS_A1) }
+    else { BLANCE_PL_BODY(BLANCE_PL_CLASS_0, BLANCE_PL_CLASS_1) }
+#undef BLANCE_PL_BODY
 }
 #endif
 
-template <int W, int K>
+template <int W, int K, bool ARITH>
 __global__ __launch_bounds__(64) void k_pass_chain_planes(ChainParams q) {
     BLANCE_DYN_LDS(lds);
     typedef unsigned long long u64;
@@ -1166,6 +1198,30 @@ __global__ __launch_bounds__(64) void k_pass_chain_planes(ChainParams q) {
     for (int u = 0; u < W; u++)
 #pragma unroll
         for (int x = 0; x < 2 * W; x++) lm[u][x] = cls[u] >= 0 ? cmL[cls[u] * 2 * W + x] : 0u;
+    // ARITH (chosen by the host from the rule's class table, q.cls_run = S): the exclude classes are aligned runs of
+    // S = 2^e <= 64 leaves, so a class mask is a shift, not a lane read.  Checked against the masks themselves.
+    int cls_m1 = 0;
+    u64 cls_ones = 0;
+    if (ARITH) {
+        const int S = q.cls_run;
+        bool okc = W == 2 && S >= 1 && S <= 64 && (S & (S - 1)) == 0;
+        cls_m1 = okc ? S - 1 : 0;
+        cls_ones = !okc ? 0ull : S == 64 ? ~0ull : ((1ull << S) - 1);
+#pragma unroll
+        for (int u = 0; u < W; u++) {
+            if (!((alive_m >> u) & 1)) continue;
+            const u64 want = cls_ones << (lane & ~cls_m1);
+#pragma unroll
+            for (int v = 0; v < W; v++) {
+                const u64 have = (u64)lm[u][2 * v] | ((u64)lm[u][2 * v + 1] << 32);
+                if (have != (v == u ? want : 0ull)) okc = false;
+            }
+        }
+        if (__ballot(!okc)) {
+            if (lane == 0) q.flags[1] = 1;
+            return;
+        }
+    }
     int shifts = 0;                                        // planes dropped below: plane j is level shifts + j
     bool failed = false;
     PH_DECL;
@@ -1221,7 +1277,7 @@ __global__ __launch_bounds__(64) void k_pass_chain_planes(ChainParams q) {
             bool resumed = false;
 #ifndef BLANCE_SIMT_EMU
             if constexpr (W == 2) {                        // the scalar loop; comes back where a pick needs more than plane 0
-                planes_walk_w2<K>(P, E, r, nb, slot0, ex, lm, my_w);
+                planes_walk_w2<K, ARITH>(P, E, r, nb, slot0, ex, lm, my_w, cls_m1, cls_ones);
                 PH(1);
                 if (r >= nb) break;
                 resumed = true;

@@ -56,14 +56,14 @@ void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size) 
 }
 
 
-template <int W>
+template <int W, bool ARITH>
 static bool launch_planes_w(hipStream_t stream, const ChainParams& q, size_t lds) {
     const int B = q.n_launch;
     switch (q.k) {
-    case 1: { auto kern = k_pass_chain_planes<W, 1>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
-    case 2: { auto kern = k_pass_chain_planes<W, 2>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
-    case 3: { auto kern = k_pass_chain_planes<W, 3>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
-    case 4: { auto kern = k_pass_chain_planes<W, 4>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
+    case 1: { auto kern = k_pass_chain_planes<W, 1, ARITH>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
+    case 2: { auto kern = k_pass_chain_planes<W, 2, ARITH>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
+    case 3: { auto kern = k_pass_chain_planes<W, 3, ARITH>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
+    case 4: { auto kern = k_pass_chain_planes<W, 4, ARITH>; BLANCE_LAUNCH(kern, B, 64, lds, stream, q); return true; }
     }
     return false;
 }
@@ -72,7 +72,7 @@ bool launch_chain_planes(hipStream_t stream, const ChainParams& q, int max_size)
     // two 64-bit words per plane: regions of up to 128 leaves (wider regions: k_pass_chain_blank)
     if (max_size > 128 || q.k > 4 || q.k < 1) return false;
     const size_t lds = sizeof(int32_t) * (64 * 2 + 64 * 2 * 2 * 2) + 64;
-    return launch_planes_w<2>(stream, q, lds);
+    return q.cls_run > 0 ? launch_planes_w<2, true>(stream, q, lds) : launch_planes_w<2, false>(stream, q, lds);
 }
 
 
