@@ -1242,10 +1242,10 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         COMMTRY(comm_allreduce(c, xb, (int64_t)(kXHead + cnt_words)));
         HIPTRY(hipMemcpyAsync(fl, xb, sizeof fl, hipMemcpyDeviceToHost, sm));
         launches++;
-    } else {
+    } else if (!lean) {                              // (the all-blank kernel's flags were read above: all clear)
         HIPTRY(hipMemcpyAsync(fl, scal + 4, 32, hipMemcpyDeviceToHost, sm));
     }
-    HIPTRY(hipStreamSynchronize(sm));
+    if (sharded || !lean) HIPTRY(hipStreamSynchronize(sm));
     if (fl[8]) return fail(BLANCE_ERR_COMM, "another rank of the sharded plan failed");
     if (c->trace)
         fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
@@ -1317,8 +1317,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 64, sm));
     if (P > 0) {
-        HIPTRY(hipMemcpyAsync(d.in_prev, c->part_in_prev.p, (size_t)P, hipMemcpyDeviceToDevice, sm));
-        HIPTRY(hipMemcpyAsync(d.never_equal, c->part_never_equal.p, (size_t)P, hipMemcpyDeviceToDevice, sm));
+        BLANCE_LAUNCH_NOSYNC(k_flags_init, cdiv(P, 256), 256, 0, sm, P, c->part_in_prev.as<uint8_t>(), c->part_never_equal.as<uint8_t>(),
+                             d.in_prev, d.never_equal);
     }
     int iterations = 0, converged = 0;
     for (int it = 0; it < h.max_iterations; it++) {                 // plan.go:32
@@ -1396,7 +1396,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 }
             }
             if (!done) {
-            BLANCE_LAUNCH_NOSYNC(k_gather, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, RW, c->order.as<int32_t>(),
+            BLANCE_LAUNCH(k_gather, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (RW | 1) + 64, sm, d, m, h.top_state, RW, c->order.as<int32_t>(),
                                  c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
             PassParams q;
             memset(&q, 0, sizeof q);

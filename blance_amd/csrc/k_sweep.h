@@ -39,6 +39,12 @@ __global__ void k_live_init(DevProblem d, const int32_t* a_off, const int32_t* a
     d.prv_kind[idx] = p_kind[idx];
 }
 
+// the two per-partition byte flags a plan starts from (in prevMap / never equal to its prevMap entry)
+__global__ void k_flags_init(int P, const uint8_t* in_prev0, const uint8_t* never0, uint8_t* in_prev, uint8_t* never) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) { in_prev[p] = in_prev0[p]; never[p] = never0[p]; }
+}
+
 // sweeps >= 2: every present key is a non-nil slice again (plan.go:418)
 __global__ void k_live_refresh(DevProblem d) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,29 +407,39 @@ __global__ void k_result_gather(DevProblem d, const int32_t* off, int32_t* nodes
     for (int i = 0; i < n; i++) nodes_out[off[idx] + i] = d.live[(size_t)idx * d.L + i];
 }
 
-// Step records in pass order: what findBestNodes needs to know about its partition.
+// Step records in pass order: what findBestNodes needs to know about its partition.  A thread builds its record in
+// LDS (row stride RW | 1: no bank conflicts), the workgroup writes its 256 records as one contiguous block (per-thread
+// rows written straight to HBM cost 3.6 times their bytes in write traffic, rocprofv3 WRITE_SIZE).
 __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
                          const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
                          int32_t* rec) {
-    int oi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (oi >= d.P) return;
-    int p = order[oi];
-    int32_t* r = rec + (size_t)oi * RW;
-    int w = 1;                                         // plan.go:269-275
-    double stick = 1.5;                                // plan.go:104-115
-    if (!d.weights_nil) {
-        if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
-        else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
+    BLANCE_DYN_LDS(lds);
+    const int tid = threadIdx.x, ST = RW | 1;
+    const int oi = blockIdx.x * blockDim.x + tid;
+    int32_t* r = (int32_t*)lds + tid * ST;
+    if (oi < d.P) {
+        int p = order[oi];
+        int w = 1;                                         // plan.go:269-275
+        double stick = 1.5;                                // plan.go:104-115
+        if (!d.weights_nil) {
+            if (d.part_has_weight[p]) { w = d.part_weight[p]; stick = (double)w; }
+            else if (state_has_stickiness[m]) stick = (double)state_stickiness[m];
+        }
+        r[0] = p; r[1] = w;
+        r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
+        for (int t = 0; t < d.M; t++) {
+            int idx = p * d.M + t;
+            int32_t* rs = r + kRecHead + t * (1 + d.L);
+            int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
+            rs[0] = len | ((int)d.live_kind[idx] << 16);
+            for (int i = 0; i < d.L; i++) rs[1 + i] = i < len ? d.live[(size_t)idx * d.L + i] : -1;
+        }
     }
-    r[0] = p; r[1] = w;
-    r[2] = __double2loint(stick); r[3] = __double2hiint(stick);
-    for (int t = 0; t < d.M; t++) {
-        int idx = p * d.M + t;
-        int32_t* rs = r + kRecHead + t * (1 + d.L);
-        int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
-        rs[0] = len | ((int)d.live_kind[idx] << 16);
-        for (int i = 0; i < d.L; i++) rs[1 + i] = i < len ? d.live[(size_t)idx * d.L + i] : -1;
-    }
+    __syncthreads();
+    const int first = blockIdx.x * blockDim.x;
+    const int n_here = d.P - first < (int)blockDim.x ? d.P - first : (int)blockDim.x;
+    for (int j = tid; j < n_here * RW; j += blockDim.x)
+        rec[(size_t)first * RW + j] = ((const int32_t*)lds)[(j / RW) * ST + j % RW];
 }
 
 // Apply the pass's choices to the live lists (plan.go:290-299); list edits only

@@ -76,9 +76,9 @@ int main() {
     const char* name[] = {"s_add dependent", "salu 8-op pick-like group (per op)", "readlane->s_add->writelane(+5 nop) (per group of 8)", "4 readlane + 4 salu (per op)",
                           "taken branch pair (per cmp+branch)", "not-taken branch pair (per cmp+branch)", "dpp min stage incl s_nop (per stage)", "v_add dependent", "salu b64 dependent"};
     const double per[] = {64, 64, 8, 64, 32, 32, 32, 64, 64};
-    // s_memtime counts at a fixed 100 MHz?  print raw too
+    // s_memtime: shader cycles
     for (int i = 0; i < 9; i++) printf("%-55s raw %llu  per-unit %.2f ticks\n", name[i], h[i], (double)h[i] / (iters * per[i]));
     int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-    printf("clock rate kHz %d (readcyclecounter = s_memtime, constant 100 MHz on gfx9: ticks x clk/100MHz = cycles)\n", clk);
+    printf("clock rate kHz %d (ticks = shader cycles: a dependent scalar add every 4.5 ticks)\n", clk);
     return 0;
 }
