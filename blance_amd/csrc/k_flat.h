@@ -216,6 +216,7 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
         n_hw[i] = n_on[i] ? q.node_has_weight[n] : 0;
         n_nw[i] = n_on[i] ? q.node_weight[n] : 0;
     }
+    int probe = 0;
     while (lo < hi) {
         unsigned long long mid = lo + (hi - lo) / 2;
         long long sum = 0;
@@ -237,12 +238,14 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
             const int lo32 = __shfl_xor((int)(unsigned)sum, off, 64), hi32 = __shfl_xor((int)(sum >> 32), off, 64);
             sum += (long long)(((unsigned long long)(unsigned)hi32 << 32) | (unsigned)lo32);
         }
-        if ((tid & 63) == 0) part[tid >> 6] = sum;
+        // (partials alternate between two LDS rows: one barrier per probe is enough)
+        long long* row = part + (probe & 1) * 16;
+        probe++;
+        if ((tid & 63) == 0) row[tid >> 6] = sum;
         __syncthreads();
         long long total = 0;
 #pragma unroll
-        for (int wv = 0; wv < 16; wv++) total += part[wv];
-        __syncthreads();
+        for (int wv = 0; wv < 16; wv++) total += row[wv];
         if (total >= R) {
             hi = mid;
 #pragma unroll
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
             for (int i = 0; i < kPer; i++) c_lo[i] = c_mid[i];
         }
     }
+    __syncthreads();                                 // (the last probe's partials are read; part is reused below)
     const unsigned long long tau = lo;
     // picks strictly below tau, then the ties at tau in node order
     const int per = (q.N + 1023) / 1024;
