@@ -444,3 +444,36 @@ def test_stays_verified_per_top_priority_node():
             fp = synth.config_flat(3, P=P, N=N)
             _same(pl.plan(fp), _oracle(fp), ("cfg3", mode, P, N))
         pl.close()
+
+
+@pytest.mark.parametrize("k_rep", [1, 2, 3, 4])
+def test_all_blank_pass_plane_automaton(k_rep):
+    """k_pass_chain_planes (the first replica pass of a fresh plan as a scalar bit-plane automaton, hand-written
+    assembly) over its envelope: zones of 40 .. 128 leaves (one and two 64-bit words per plane), racks that are
+    aligned power-of-two runs (class masks by arithmetic) and racks of 5 / 7 / 12 (class masks by lane reads),
+    k = 1 .. 4 picks per step, leaves without a node (names of the tree that are not in nodesAll), one partition weight
+    other than 1 for every partition, a rule that excludes only the anchor itself; and the same plans with the
+    kernel switched off (k_pass_chain_blank) -- all against the oracle."""
+    import random
+    shapes = [(16, 8, 3), (8, 16, 2), (4, 10, 3), (5, 9, 4), (7, 11, 2), (12, 10, 2), (16, 5, 3), (2, 30, 2), (32, 4, 2)]
+    for planes in (True, False):
+        pl = hip.Planner(device_id=0, chain_min_parts=1, planes=planes)
+        for si, (rack, racks_per_zone, n_zones) in enumerate(shapes):
+            if rack * racks_per_zone > 128 or racks_per_zone <= k_rep + 1:
+                continue
+            rnd = random.Random(1000 * k_rep + si)
+            N = rack * racks_per_zone * n_zones
+            c = synth.config_case(3, P=rnd.choice([3000, 9000]), N=N)
+            c["nodeHierarchy"] = synth.hierarchy_names(N, rack=rack, racks_per_zone=racks_per_zone, zones_per_dc=2)
+            c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k_rep}}
+            if si % 3 == 1:
+                c["hierarchyRules"] = {"replica": [{"includeLevel": 2, "excludeLevel": 0}]}
+            if si % 2 == 0:                                   # leaves of the tree that carry no node of nodesAll
+                gone = set(rnd.sample(c["nodesAll"], max(1, N // 17)))
+                c["nodesAll"] = [n for n in c["nodesAll"] if n not in gone]
+                c["nodesToAdd"] = list(c["nodesAll"])
+            if si % 4 == 3:
+                c["partitionWeights"] = {p: 3 for p in c["partitionsToAssign"]}
+            fp = synth.case_to_flat(c)
+            _same(pl.plan(fp), _oracle(fp), ("planes" if planes else "lanes", k_rep, rack, racks_per_zone, n_zones))
+        pl.close()
