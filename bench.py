@@ -278,8 +278,9 @@ def main():
             kernels.append(kernel_line("k_pass_chain_planes (all-blank replica pass of the first sweep: scalar bit-plane automaton, one "
                                        "wave64 per hierarchy region)", ("k_pass_chain_planes", "k_pass_chain_blank"),
                                        K_CW + 1 + kmax, acc["blank_ms"], acc["blank_launches"], zones))
-            kernels.append(kernel_line("k_pass_chain (replica passes of the later sweeps: verified stays, one wave64 per hierarchy region)",
-                                       ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"],
+            kernels.append(kernel_line("k_pass_chain / k_stay_by_top (replica passes of the later sweeps: verified stays -- one wave64 per "
+                                       "hierarchy region, or, in a converged sweep, one thread per top priority node incl. its grouping)",
+                                       ("k_pass_chainI", "k_stay_by_top"), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"],
                                        acc["pass_launches"] - acc["blank_launches"], zones))
         kernels.append(kernel_line("flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)",
                                    ("k_flat", "k_fresh", "k_sort"), RW + 2, acc["flat_ms"], acc["flat_passes"], None))
