@@ -79,6 +79,7 @@ struct blance_ctx {
     DevBuf cnt_base, xbuf, gath;    // sharded pass: loads at pass start, [flags | load change], gathered output slices
     std::vector<int32_t> h_reg_off; // host copy of the chain offsets (slice sizes of the all-gather)
     bool trace = false;             // BLANCE_TRACE, read once at context creation
+    int dump_sweep = -1;            // BLANCE_DUMP_SWEEP (developer aid), likewise
     DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
     DevBuf mv[11];                  // blance_calc_moves: inputs, per-partition slices, offsets, compacted outputs (kept between calls)
     int64_t comm_calls = 0, comm_bytes = 0;
@@ -303,6 +304,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->trace = getenv("BLANCE_TRACE") != nullptr;
+    if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -817,8 +819,7 @@ static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size) {
 
 // developer aid: BLANCE_DUMP_SWEEP=<i> prints every step's choice of sweep i (pass order)
 static int dump_pass(blance_ctx* c, int sweep, int state, int P, int OW, const int32_t* idx_dev /* or null */) {
-    const char* e = getenv("BLANCE_DUMP_SWEEP");
-    if (!e || atoi(e) != sweep) return 0;
+    if (c->dump_sweep != sweep) return 0;
     std::vector<int32_t> out((size_t)P * OW), idx((size_t)P);
     HIPTRY(hipMemcpyAsync(out.data(), c->out.p, sizeof(int32_t) * out.size(), hipMemcpyDeviceToHost, c->stream));
     if (idx_dev) HIPTRY(hipMemcpyAsync(idx.data(), idx_dev, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));

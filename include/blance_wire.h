@@ -100,7 +100,10 @@ typedef struct blance_wire_buffers {
     int32_t* entry_nodes;
 } blance_wire_buffers;
 
-/* json.Unmarshal into the caller's arrays; *view then points into them. */
+/* json.Unmarshal into the caller's arrays; *view then points into them.  Cost: the document is parsed into a map
+ * of the library's first and copied over (peak memory: both), and a BLANCE_WIRE_ERR_SPACE answer means a second
+ * parse after the caller has grown its arrays to the sizes reported -- callers that can take a handle
+ * (blance_wire_decode) pay for one parse and no copy.  No exception crosses any entry point of this header. */
 int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* buffers, blance_wire_view* view);
 /* json.Marshal into the caller's buffer; *need = the document's length, also with BLANCE_WIRE_ERR_SPACE. */
 int blance_wire_encode_into(const blance_wire_view* view, char* buf, size_t cap, size_t* need);
