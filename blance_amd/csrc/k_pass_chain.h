@@ -972,26 +972,29 @@ __device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes]
 // are two code paths (one branch) instead of selects, the last pick's paths each carry their own loop
 // tail, picks from plane 1 (a quarter of the steps at BASELINE config 3: the end of every round, when
 // the lowest level is left in excluded racks only) sit behind the loop and jump back.
-// Per step: 4 v_readlane (the step's exclude mask), per pick 6 + 4 scalar instructions, 4 v_readlane
+// Per step: 4 v_readlane (the step's exclude mask), per pick 3 + 4 scalar instructions, 4 v_readlane
 // (the picked leaf's class mask) and 2 s_or unless it is the step's last pick, 1 v_writelane.
 // Leaves the loop (a) at r == nb; (b) before a pick that has no candidate on planes 0 and 1, or finds
 // plane 0 empty: `slot` = its index, E = the exclude mask so far -- the caller finishes that step with
 // planes_pick_from, drops an empty plane 0, and comes back.
+// (the step counter lives in M0 inside the loop: it is the lane select of every v_readlane / v_writelane of the step)
 #define BLANCE_PL_HEAD                                           \
+    "s_mov_b32 m0, %[r]\n"                                       \
     "0:\n\t"                                                     \
-    "v_readlane_b32 s44, %[ex0], %[r]\n\t"                       \
-    "v_readlane_b32 s45, %[ex1], %[r]\n\t"                       \
-    "v_readlane_b32 s46, %[ex2], %[r]\n\t"                       \
-    "v_readlane_b32 s47, %[ex3], %[r]\n\t"                       \
-    "s_mov_b32 m0, %[r]\n\t"
-// candidates of plane (PL, PH) in s[52:53] / s[54:55]; none: to label NONE; else word 1 only: to label W1
-#define BLANCE_PL_FIND(PL, PH, NONE, W1)                         \
-    "s_andn2_b64 s[52:53], %[" #PL "], s[44:45]\n\t"             \
+    "v_readlane_b32 s44, %[ex0], m0\n\t"                         \
+    "v_readlane_b32 s45, %[ex1], m0\n\t"                         \
+    "v_readlane_b32 s46, %[ex2], m0\n\t"                         \
+    "v_readlane_b32 s47, %[ex3], m0\n\t"
+// candidates of plane (PL, PH) in s[52:53] / s[54:55]; word 0 has one: fall through (s_andn2 leaves SCC = result != 0,
+// so the expected case costs two instructions and a branch not taken); else to label W1, which checks word 1
+#define BLANCE_PL_FIND(PL, PH, W1)                               \
     "s_andn2_b64 s[54:55], %[" #PH "], s[46:47]\n\t"             \
-    "s_or_b64 s[48:49], s[52:53], s[54:55]\n\t"                  \
-    "s_cbranch_scc0 " NONE "\n\t"                                \
-    "s_cmp_lg_u64 s[52:53], 0\n\t"                               \
+    "s_andn2_b64 s[52:53], %[" #PL "], s[44:45]\n\t"             \
     "s_cbranch_scc0 " W1 "\n\t"
+// (at label W1) word 1 has a candidate: fall through; else to label NONE
+#define BLANCE_PL_FIND_W1(NONE)                                  \
+    "s_cmp_lg_u64 s[54:55], 0\n\t"                               \
+    "s_cbranch_scc0 " NONE "\n\t"
 // lowest candidate of word T (s56 = its bit index) leaves plane word FROM for plane word TO
 #define BLANCE_PL_TAKE(T, FROM, TO)                              \
     "s_ff1_i32_b64 s56, " T "\n\t"                               \
@@ -1024,51 +1027,64 @@ __device__ __forceinline__ int planes_pick_from(unsigned long long (&P)[kPlanes]
     "s_lshl_b64 s[48:49], %[sones], s48\n\t"                     \
     "s_or_b64 s[46:47], s[46:47], s[48:49]\n\t"
 #define BLANCE_PL_TAIL                                           \
-    "s_add_u32 %[r], %[r], 1\n\t"                                \
-    "s_cmp_lt_u32 %[r], %[nb]\n\t"                               \
+    "s_add_u32 m0, m0, 1\n\t"                                    \
+    "s_cmp_lt_u32 m0, %[nb]\n\t"                                 \
     "s_cbranch_scc1 0b\n\t"                                      \
     "s_branch 7f\n"
 // both words' paths of a pick from plane (PL, PH) into (QL, QH); CONT: what follows the pick
-#define BLANCE_PL_WORDS_MORE(SLOT, PL, PH, QL, QH, W1, CONT, C0, C1) \
+#define BLANCE_PL_WORDS_MORE(SLOT, PL, PH, QL, QH, W1, NONE, CONT, C0, C1) \
     BLANCE_PL_TAKE("s[52:53]", PL, QL) C0                        \
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
     "s_branch " CONT "\n"                                        \
     W1 ":\n\t"                                                   \
+    BLANCE_PL_FIND_W1(NONE)                                      \
     BLANCE_PL_TAKE("s[54:55]", PH, QH) C1                        \
     "s_or_b32 s56, s56, 64\n\t"                                  \
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"
-#define BLANCE_PL_WORDS_LAST(SLOT, PL, PH, QL, QH, W1)           \
+#define BLANCE_PL_WORDS_LAST(SLOT, PL, PH, QL, QH, W1, NONE)     \
     BLANCE_PL_TAKE("s[52:53]", PL, QL)                           \
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
     BLANCE_PL_TAIL                                               \
     W1 ":\n\t"                                                   \
+    BLANCE_PL_FIND_W1(NONE)                                      \
     BLANCE_PL_TAKE("s[54:55]", PH, QH)                           \
     "s_or_b32 s56, s56, 64\n\t"                                  \
     "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
     BLANCE_PL_TAIL
-// in the loop: a pick from plane 0 (labels 1<slot> .. 3<slot>); behind the loop: the same pick from plane 1
-#define BLANCE_PL_PICK_MORE(SLOT, C0, C1)                        \
-    BLANCE_PL_FIND(p0l, p0h, "5" #SLOT "f", "2" #SLOT "f")       \
-    BLANCE_PL_WORDS_MORE(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT, "3" #SLOT "f", C0, C1) \
+// in the loop: a pick from plane 0 (labels 2<slot>, 3<slot>); behind the loop: the same pick from plane 1.  A pick that
+// is not the step's last carries, on its word-0 path, its OWN copy of the rest of the step (REST: it ends in loop tails
+// and never falls through) instead of a taken branch over the word-1 path; the word-1 path and the plane-1 picks
+// continue at 3<slot>.  (Numeric labels repeat across the copies: a reference binds to the nearest definition in its
+// direction, and every copy of a continuation is the same code.)
+#define BLANCE_PL_PICK_MORE(SLOT, C0, C1, REST)                  \
+    BLANCE_PL_FIND(p0l, p0h, "2" #SLOT "f")                      \
+    BLANCE_PL_TAKE("s[52:53]", p0l, p1l) C0                      \
+    "v_writelane_b32 %[w" #SLOT "], s56, m0\n\t"                 \
+    REST                                                         \
+    "2" #SLOT ":\n\t"                                            \
+    BLANCE_PL_FIND_W1("5" #SLOT "f")                             \
+    BLANCE_PL_TAKE("s[54:55]", p0h, p1h) C1                      \
+    "s_or_b32 s56, s56, 64\n\t"                                  \
+    "v_writelane_b32 %[w" #SLOT "], s56, m0\n"                   \
     "3" #SLOT ":\n\t"
 #define BLANCE_PL_PICK_LAST(SLOT)                                \
-    BLANCE_PL_FIND(p0l, p0h, "5" #SLOT "f", "2" #SLOT "f")       \
-    BLANCE_PL_WORDS_LAST(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT)
+    BLANCE_PL_FIND(p0l, p0h, "2" #SLOT "f")                      \
+    BLANCE_PL_WORDS_LAST(SLOT, p0l, p0h, p1l, p1h, "2" #SLOT, "5" #SLOT "f")
 #define BLANCE_PL_SLOW_HEAD(SLOT)                                \
     "5" #SLOT ":\n\t"                                            \
     "s_or_b64 s[48:49], %[p0l], %[p0h]\n\t"                      \
     "s_cbranch_scc0 9" #SLOT "f\n\t"                             \
-    BLANCE_PL_FIND(p1l, p1h, "9" #SLOT "f", "6" #SLOT "f")
+    BLANCE_PL_FIND(p1l, p1h, "6" #SLOT "f")
 #define BLANCE_PL_SLOW_MORE(SLOT, C0, C1)                        \
     BLANCE_PL_SLOW_HEAD(SLOT)                                    \
-    BLANCE_PL_WORDS_MORE(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT, "3" #SLOT "b", C0, C1) \
+    BLANCE_PL_WORDS_MORE(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT, "9" #SLOT "f", "3" #SLOT "b", C0, C1) \
     "s_branch 3" #SLOT "b\n"                                     \
     "9" #SLOT ":\n\ts_mov_b32 %[slot], " #SLOT "\n\ts_branch 7f\n"
 #define BLANCE_PL_SLOW_LAST(SLOT)                                \
     BLANCE_PL_SLOW_HEAD(SLOT)                                    \
-    BLANCE_PL_WORDS_LAST(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT)    \
+    BLANCE_PL_WORDS_LAST(SLOT, p1l, p1h, p2l, p2h, "6" #SLOT, "9" #SLOT "f") \
     "9" #SLOT ":\n\ts_mov_b32 %[slot], " #SLOT "\n\ts_branch 7f\n"
-#define BLANCE_PL_EXIT "7:\n\ts_mov_b64 %[elo], s[44:45]\n\ts_mov_b64 %[ehi], s[46:47]\n"
+#define BLANCE_PL_EXIT "7:\n\ts_mov_b32 %[r], m0\n\ts_mov_b64 %[elo], s[44:45]\n\ts_mov_b64 %[ehi], s[46:47]\n"
 #define BLANCE_PL_OPERANDS                                                                                          \
     [p0l] "+s"(P[0][0]), [p0h] "+s"(P[0][1]), [p1l] "+s"(P[1][0]), [p1h] "+s"(P[1][1]), [p2l] "+s"(P[2][0]),         \
     [p2h] "+s"(P[2][1]), [r] "+s"(r), [slot] "=&s"(slot), [elo] "=&s"(E[0]), [ehi] "=&s"(E[1])
@@ -1088,22 +1104,27 @@ __device__ __forceinline__ void planes_walk_w2(unsigned long long (&P)[kPlanes][
     const int cls_m1 = __builtin_amdgcn_readfirstlane(cls_m1_in);
     const unsigned long long cls_ones = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cls_ones_in) |
                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cls_ones_in >> 32)) << 32);
+#define BLANCE_PL_R3(C0, C1) BLANCE_PL_PICK_LAST(3)
+#define BLANCE_PL_R2(C0, C1) BLANCE_PL_PICK_MORE(2, C0, C1, BLANCE_PL_R3(C0, C1)) BLANCE_PL_R3(C0, C1)
+#define BLANCE_PL_R1(C0, C1) BLANCE_PL_PICK_MORE(1, C0, C1, BLANCE_PL_R2(C0, C1)) BLANCE_PL_R2(C0, C1)
 #define BLANCE_PL_BODY(C0, C1)                                                                                                        \
     if constexpr (K == 1) {                                                                                                           \
         asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_LAST(0) BLANCE_PL_SLOW_LAST(0) BLANCE_PL_EXIT                                      \
                      : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);                                \
     } else if constexpr (K == 2) {                                                                                                    \
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1) BLANCE_PL_PICK_LAST(1) BLANCE_PL_SLOW_MORE(0, C0, C1)              \
-                     BLANCE_PL_SLOW_LAST(1) BLANCE_PL_EXIT                                                                            \
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1, BLANCE_PL_PICK_LAST(1)) BLANCE_PL_PICK_LAST(1)                     \
+                     BLANCE_PL_SLOW_MORE(0, C0, C1) BLANCE_PL_SLOW_LAST(1) BLANCE_PL_EXIT                                             \
                      : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]) : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);            \
     } else if constexpr (K == 3) {                                                                                                    \
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1) BLANCE_PL_PICK_MORE(1, C0, C1) BLANCE_PL_PICK_LAST(2)              \
+        asm volatile(BLANCE_PL_HEAD                                                                                                   \
+                     BLANCE_PL_PICK_MORE(0, C0, C1, BLANCE_PL_PICK_MORE(1, C0, C1, BLANCE_PL_PICK_LAST(2)) BLANCE_PL_PICK_LAST(2))    \
+                     BLANCE_PL_PICK_MORE(1, C0, C1, BLANCE_PL_PICK_LAST(2)) BLANCE_PL_PICK_LAST(2)                                    \
                      BLANCE_PL_SLOW_MORE(0, C0, C1) BLANCE_PL_SLOW_MORE(1, C0, C1) BLANCE_PL_SLOW_LAST(2) BLANCE_PL_EXIT              \
                      : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2])                                 \
                      : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);                                                                         \
     } else {                                                                                                                          \
-        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1) BLANCE_PL_PICK_MORE(1, C0, C1) BLANCE_PL_PICK_MORE(2, C0, C1)      \
-                     BLANCE_PL_PICK_LAST(3) BLANCE_PL_SLOW_MORE(0, C0, C1) BLANCE_PL_SLOW_MORE(1, C0, C1)                             \
+        asm volatile(BLANCE_PL_HEAD BLANCE_PL_PICK_MORE(0, C0, C1, BLANCE_PL_R1(C0, C1)) BLANCE_PL_R1(C0, C1)                         \
+                     BLANCE_PL_SLOW_MORE(0, C0, C1) BLANCE_PL_SLOW_MORE(1, C0, C1)                                                    \
                      BLANCE_PL_SLOW_MORE(2, C0, C1) BLANCE_PL_SLOW_LAST(3) BLANCE_PL_EXIT                                             \
                      : BLANCE_PL_OPERANDS, [w0] "+v"(my_w[0]), [w1] "+v"(my_w[1]), [w2] "+v"(my_w[2]), [w3] "+v"(my_w[3])             \
                      : BLANCE_PL_INPUTS : BLANCE_PL_CLOBBER);                                                                         \
@@ -1111,6 +1132,9 @@ __device__ __forceinline__ void planes_walk_w2(unsigned long long (&P)[kPlanes][
     if constexpr (ARITH) { BLANCE_PL_BODY(BLANCE_PL_CLASS_A0, BLANCE_PL_CLASS_A1) }
     else { BLANCE_PL_BODY(BLANCE_PL_CLASS_0, BLANCE_PL_CLASS_1) }
 #undef BLANCE_PL_BODY
+#undef BLANCE_PL_R1
+#undef BLANCE_PL_R2
+#undef BLANCE_PL_R3
 }
 #endif
 
