@@ -72,6 +72,7 @@ struct blance_ctx {
     blance_comm comm{0, 1, nullptr, nullptr, nullptr};
     void* rccl_comm = nullptr;      // ncclComm_t of blance_comm_init_rccl
     DevBuf scan_sums;               // tile totals of launch_scan_excl
+    DevBuf scan_part;               // k_flat_scan's per-wave results
     DevBuf topkey, top_counts, top_off, top_order;   // k_stay_by_top: steps grouped by the leaf of their top priority node
     std::vector<int64_t> last_stays; // [state] steps the last chain pass of that state committed as verified stays
     bool no_stay_top = false;       // test knob (& 64): never k_stay_by_top
@@ -146,7 +147,7 @@ struct blance_ctx {
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
         rule_regions.clear();
         topkey.release(); top_counts.release(); top_off.release(); top_order.release();
-        cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release();
+        cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release();
         dl_off.release(); dl_nodes.release();
         for (DevBuf& b : mv) b.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &n_ev, &chain_oi,
@@ -740,9 +741,12 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             dirty = false;
             *launches += 1;
         }
-        int32_t init[2] = {INT_MAX, INT_MAX};
-        HIPTRY(hipMemcpyAsync(scal + 8, init, sizeof init, hipMemcpyHostToDevice, sm));
-        BLANCE_LAUNCH(k_flat_scan, cdiv(P - pos, 256), 256, 0, sm, fq, pos, P);
+        const int scan_blocks = cdiv(P - pos, 256);
+        fq.scan_waves = scan_blocks * 4;
+        if (c->scan_part.reserve(sizeof(int32_t) * 2 * ((size_t)fq.scan_waves + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+        fq.scan_part = c->scan_part.as<int32_t>();
+        BLANCE_LAUNCH(k_flat_scan, scan_blocks, 256, 0, sm, fq, pos, P);
+        BLANCE_LAUNCH(k_flat_scan_min, 1, 1024, 256, sm, fq.scan_waves, (const int32_t*)fq.scan_part, scal + 8);
         int32_t got[2] = {0, 0};
         HIPTRY(hipMemcpyAsync(got, scal + 8, sizeof got, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipStreamSynchronize(sm));

@@ -152,6 +152,8 @@ struct FlatParams {
     const int32_t* rec;
     int32_t* out;
     int32_t* scan;                 // [0] first step that is not a certain stay, [1] first not fresh-identical
+    int32_t* scan_part;            // [2][scan_waves] per wave of k_flat_scan: its first such step, reduced by k_flat_scan_min
+    int32_t scan_waves;
 };
 
 }  // namespace blance

@@ -81,10 +81,39 @@ __global__ void k_flat_row_count(FlatParams q, int32_t* row_count) {
 
 // Classify the steps [beg, end): record the first one that is not a certain
 // stay and the first one that is not "fresh identical" to step beg.
-// first lane of the wave for which `flag` holds publishes its step index (pass order rises with the lane)
-__device__ __forceinline__ void scan_note_first(bool flag, int oi, int* slot) {
+// The first step of the range for which a flag holds: every WAVE leaves the smallest such step of its 64 in
+// part[flag kind][wave] (INT_MAX if none) -- no atomics: when every step is flagged (a fresh pass: nothing is a stay),
+// thousands of waves would otherwise hit one word at once -- and k_flat_scan_min reduces the two rows.
+__device__ __forceinline__ void scan_note_first(bool flag, int oi, int32_t* part_row) {
     const unsigned long long m = __ballot(flag);
-    if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1 && oi < *(volatile int*)slot) atomicMin(slot, oi);
+    const int first = m ? __ffsll((long long)m) - 1 : -1;
+    if ((int)(threadIdx.x & 63) == (first < 0 ? 0 : first))
+        part_row[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = first < 0 ? INT_MAX : oi;
+}
+
+__global__ __launch_bounds__(1024) void k_flat_scan_min(int n_waves, const int32_t* part /* [2][n_waves] */, int32_t* scan) {
+    BLANCE_DYN_LDS(lds);
+    int* red = (int*)lds;                            // [2][16]
+    const int tid = threadIdx.x;
+    int m0 = INT_MAX, m1 = INT_MAX;
+    for (int i = tid; i < n_waves; i += 1024) {
+        const int a = part[i], b = part[n_waves + i];
+        m0 = a < m0 ? a : m0;
+        m1 = b < m1 ? b : m1;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int a = __shfl_xor(m0, off, 64), b = __shfl_xor(m1, off, 64);
+        m0 = a < m0 ? a : m0;
+        m1 = b < m1 ? b : m1;
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = m0; red[16 + (tid >> 6)] = m1; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 0; w < 16; w++) { m0 = red[w] < m0 ? red[w] : m0; m1 = red[16 + w] < m1 ? red[16 + w] : m1; }
+        scan[0] = m0;                                // first step that is not a certain stay (INT_MAX: none)
+        scan[1] = m1;                                // first step that is not fresh-identical to the range's first
+    }
 }
 
 __global__ void k_flat_scan(FlatParams q, int beg, int end) {
@@ -115,7 +144,7 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
         // (k_fresh_excl), and the top priority node does not matter.
         bool fresh = w > 0 && w == r0[1] &&
                      (q.NP == 0 ? (q.k <= 2 && all_len == high_len && high_len <= 1) : (q.k == 1 && all_len == 0 && top < 0));
-        scan_note_first(in_range && !fresh, oi, &q.scan[1]);
+        scan_note_first(in_range && !fresh, oi, q.scan_part + q.scan_waves);
     }
     // ---- certain stay?
     bool stay = false;
@@ -149,7 +178,7 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
             }
         }
     }
-    scan_note_first(in_range && !stay, oi, &q.scan[0]);
+    scan_note_first(in_range && !stay, oi, q.scan_part);
 }
 
 // commit a run of certain stays: the lists do not change; nodeToNodeCounts does (plan.go:238-245)
