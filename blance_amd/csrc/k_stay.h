@@ -18,30 +18,6 @@ namespace blance {
 // the host runs the pass with k_pass_chain from the same (untouched) state.
 // Work list: steps grouped by the GLOBAL leaf index of their top priority node, pass order inside a
 // group (stable counting sort by the driver): top_off[leaf] .. top_off[leaf + 1] into top_order.
-// nodeSorter.Score (plan.go:634-689) with the two NumPartitions quotients computed in place (k_pass_chain reads them
-// from tables filled by these very expressions)
-__device__ __forceinline__ double stay_score(int cnt, int ntn, int tot, int hasw, int w, int NP, double cf, int booster) {
-    double lp = 0.0, ff = 0.0;
-    if (NP > 0) {
-        lp = (double)ntn / (double)NP;
-        ff = (0.001 * (double)tot) / (double)NP;
-    }
-    double r = (double)cnt;
-    r = r + lp;
-    r = r + ff;
-    if (hasw) {
-        if (w > 0) {
-            r = r / (double)w;
-        } else if (w < 0 && booster == BLANCE_BOOSTER_CBGT) {
-            double b = (double)(-w);
-            if (b < cf) b = cf;
-            r = r + b;
-        }
-    }
-    r = r - cf;
-    return r;
-}
-
 template <int KM>
 __global__ __launch_bounds__(64) void k_stay_by_top(StayParams q) {
     BLANCE_DYN_LDS(lds);
@@ -58,6 +34,12 @@ __global__ __launch_bounds__(64) void k_stay_by_top(StayParams q) {
     int* clsL = flgL + size;
     int* cszL = clsL + size;
     int* rowL = cszL + size;                         // [size][64]
+    // the two NumPartitions quotients of the score from tables, by k_pass_chain's own chain_score (plan.go:638-652)
+    double* lp_tab = (double*)(rowL + size * 64 + ((size * 71) & 1));     // 8-byte aligned: 71 ints per leaf before it
+    double* ff_tab = lp_tab + kLpTab;
+    for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = NP > 0 ? (double)i / (double)NP : 0.0;
+    for (int i = lane; i < kFfTab; i += 64) ff_tab[i] = NP > 0 ? (0.001 * (double)i) / (double)NP : 0.0;
+    __syncthreads();
     double ms = pos_inf();
     int mn = INT_MAX;
     for (int i = lane; i < size; i += 64) {
@@ -70,7 +52,7 @@ __global__ __launch_bounds__(64) void k_stay_by_top(StayParams q) {
             fl = ((n < q.N && q.alive[n]) ? 1 : 0) | (q.node_has_weight[n] ? 2 : 0);
             cl = q.leaf_cls[pos];
             if (fl & 1) {                            // partition-independent score of a candidate
-                const double g = stay_score(c, 0, t, (fl >> 1) & 1, w, NP, 0.0, q.booster_kind);
+                const double g = chain_score(c, 0, t, (fl >> 1) & 1, w, NP, 0.0, q.booster_kind, lp_tab, ff_tab);
                 if (better(g, n, ms, mn)) { ms = g; mn = n; }
             }
         }
@@ -135,7 +117,8 @@ __global__ __launch_bounds__(64) void k_stay_by_top(StayParams q) {
                 on[j] = nidL[li];
                 oc[j + 1] = clsL[li];
                 if (!(flgL[li] & 1)) bad = true;
-                so[j] = stay_score(cntL[li], rowL[li * 64 + lane], totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick, q.booster_kind);
+                so[j] = chain_score(cntL[li], rowL[li * 64 + lane], totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick, q.booster_kind,
+                                    lp_tab, ff_tab);
             }
         }
         // what a stay emits: its nodes in (score, position) order (plan.go:185-226)
