@@ -477,3 +477,16 @@ def test_all_blank_pass_plane_automaton(k_rep):
             fp = synth.case_to_flat(c)
             _same(pl.plan(fp), _oracle(fp), ("planes" if planes else "lanes", k_rep, rack, racks_per_zone, n_zones))
         pl.close()
+
+
+@pytest.mark.parametrize("rack,racks_per_zone,k_rep", [(12, 8, 2), (8, 16, 3), (16, 8, 1)])
+def test_config3_shapes_at_scale(planner, rack, racks_per_zone, k_rep):
+    """Config 3's generator with other trees at 131,072 partitions x 3,072 / 4,096 nodes: racks of 12 (class masks by
+    lane reads, zones of 96 leaves), racks of 8 in zones of 128 (class masks by arithmetic, k = 3), k = 1 -- every
+    chain of thousands of steps, all three sweeps, against the oracle."""
+    N = rack * racks_per_zone * 32
+    c = synth.config_case(3, P=131072, N=N)
+    c["nodeHierarchy"] = synth.hierarchy_names(N, rack=rack, racks_per_zone=racks_per_zone, zones_per_dc=8)
+    c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k_rep}}
+    fp = synth.case_to_flat(c)
+    _same(planner.plan(fp), _oracle(fp), ("config 3 at scale", rack, racks_per_zone, k_rep))
