@@ -47,9 +47,26 @@ def main():
     for c in re.findall(r"C\.(blance_[a-z_]+)\(", plan + moves):
         if not re.search(r"\b%s\(" % c, header):
             bad.append("the Go shim calls %s, which the header does not declare" % c)
+    # the two host mirrors refuse the same inputs: every refusal of the compiled, tested C++ mirror (blance_api.cpp:
+    # Unsupported{"..."}) has a counterpart among intern.go's unsupported("...") -- matched on the words of the message
+    # (the Go text adds names with %q and range checks for its 64-bit ints)
+    def words(msg):
+        msg = re.sub(r"%[qdsv]", "", msg.lower())
+        msg = re.sub(r"\(.*?\)", "", msg)
+        return set(w for w in re.findall(r"[a-z*]+", msg) if w not in ("a", "the", "of", "for", "is", "in", "to", "that", "but", "with"))
+    intern = open(os.path.join(ROOT, "go", "blance", "intern.go")).read()
+    cpp = open(os.path.join(ROOT, "blance_amd", "csrc", "host", "blance_api.cpp")).read()
+    go_msgs = re.findall(r'unsupported\("((?:[^"\\]|\\.)+)"', intern)
+    for msg in set(re.findall(r'Unsupported\{"((?:[^"\\]|\\.)+)"', cpp)):
+        w = words(msg)
+        if not w:
+            continue
+        best = max((len(w & words(g)) / float(len(w | words(g))) for g in go_msgs), default=0.0)
+        if best < 0.75:
+            bad.append("the C++ mirror refuses %r; intern.go has no such refusal" % msg)
     for line in bad:
         print(line)
-    print("go shim vs include/blance_hip.h: %s" % ("IN STEP" if not bad else "%d problems" % len(bad)))
+    print("go shim vs include/blance_hip.h and blance_api.cpp: %s" % ("IN STEP" if not bad else "%d problems" % len(bad)))
     return 1 if bad else 0
 
 
