@@ -424,14 +424,25 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
             nums[(size_t)i] = {wk, v, i};
         }
         if (simple) {
-            std::sort(nums.begin(), nums.end(), [&](const Num& a, const Num& b) {
-                if (a.w != b.w) return a.w < b.w;
-                if (a.n != b.n) return a.n < b.n;
-                if (a.i == b.i) return false;
-                return *pnames[a.i] < *pnames[b.i];            // "7" and "007": equal padded keys, then by Name
-            });
-            f.part_order.reserve((size_t)P);
-            for (auto& k : nums) f.part_order.push_back(k.i);
+            // stable LSD radix sorts, name key first, weight key second: partitions with equal keys ("7" and "007") keep
+            // the order they were taken from the map in -- ascending Name, the reference's last tie-break
+            std::vector<int32_t> idx((size_t)P), tmp((size_t)P);
+            for (int i = 0; i < P; i++) idx[(size_t)i] = i;
+            auto radix = [&](auto key) {
+                long long mx = 0, mn = P > 0 ? key(0) : 0;
+                for (int i = 0; i < P; i++) { mx = std::max(mx, key(i)); mn = std::min(mn, key(i)); }
+                if (mx == mn) return;                      // one key for all (no weights): nothing to order
+                for (int shift = 0; shift < 63 && (mx >> shift) != 0; shift += 11) {
+                    size_t cnt[2049] = {0};
+                    for (int i = 0; i < P; i++) cnt[((key(idx[(size_t)i]) >> shift) & 2047) + 1]++;
+                    for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
+                    for (int i = 0; i < P; i++) tmp[cnt[(key(idx[(size_t)i]) >> shift) & 2047]++] = idx[(size_t)i];
+                    idx.swap(tmp);
+                }
+            };
+            radix([&](int i) { return nums[(size_t)i].n; });
+            radix([&](int i) { return nums[(size_t)i].w - 0; });
+            f.part_order.assign(idx.begin(), idx.end());
         } else {
             struct Key { std::string w, n; const std::string* name; int i; };
             std::vector<Key> keys;
@@ -594,12 +605,13 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // plan.go:49-52: every non-converged sweep stores its partitions into both input maps;
     // the last such store has the final map's content
     if ((res.iterations > 1 || !res.converged) && prevMap) {
-        auto store = [&](PartitionMap& dst) {              // both ordered by name: one walk, no lookups
-            auto id = dst.begin();
-            for (auto& kv : out.nextMap) {
-                while (id != dst.end() && id->first < kv.first) ++id;
-                if (id != dst.end() && id->first == kv.first) id->second = kv.second;
-                else id = dst.emplace_hint(id, kv.first, kv.second);
+        auto store = [&](PartitionMap& dst) {              // both ordered by name: one walk, no lookups; the source
+            auto id = dst.begin();                         // side is walked as the contiguous arrays, not as a tree
+            for (int p = 0; p < P; p++) {
+                const std::string& name = f.part_names[(size_t)p];
+                while (id != dst.end() && id->first < name) ++id;
+                if (id != dst.end() && id->first == name) id->second = parts[(size_t)p];
+                else id = dst.emplace_hint(id, name, parts[(size_t)p]);
             }
         };
         const auto t_st = std::chrono::steady_clock::now();
