@@ -12,6 +12,8 @@
 // a wave64 runs in lockstep: LDS writes of one lane are seen by the other lanes'
 // later reads without a barrier; this only pins the compiler's schedule
 #define BLANCE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt 7 and lgkmcnt 15 = no wait)
+#define BLANCE_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
 
 #include <limits.h>

@@ -111,6 +111,23 @@ constexpr int kKeyBias = 1 << 17;
 constexpr unsigned kKeyNone = 0xffffffffu;
 constexpr int kCompactMax = 8000;    // |count| bound of the compact keys of the blank-run loop
 
+constexpr int kStageVec = kChainStage * (kCW / 4) / 64;      // 16-byte words of a stage per lane
+static_assert(kCW % 4 == 0 && kStageVec == 24 && kChainStage * (kCW / 4) % 64 == 0, "BLANCE_STAGE_EACH lists 24 words per lane");
+// the 24 words as 24 named values: as an array the compiler keeps them in scratch memory, and a store to scratch
+// waits for the load it stores
+#define BLANCE_STAGE_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+    X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
+#define BLANCE_STAGE_DECL(t) int4 pre##t = {0, 0, 0, 0};
+#define BLANCE_STAGE_FETCH(t) { const int i_ = lane + 64 * t; pre##t = src_[i_ < n4_ ? i_ : lane]; }
+#define BLANCE_STAGE_COMMIT(t) dst_[lane + 64 * t] = pre##t;      /* the whole stage area: words past a short stage are never read */
+// (lane < n4 whenever a stage has a step; a record is 96 bytes: 16-byte aligned)
+#define BLANCE_STAGE_FETCH_ALL(crec, base_, cend_)                                                               \
+    {                                                                                                             \
+        const int n4_ = ((cend_) - (base_) < kChainStage ? (cend_) - (base_) : kChainStage) * (kCW / 4);          \
+        const int4* src_ = (const int4*)((crec) + (size_t)(base_) * kCW);                                         \
+        BLANCE_STAGE_EACH(BLANCE_STAGE_FETCH)                                                                     \
+    }
+
 template <int NPTC, int KM, bool FAST>
 __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     BLANCE_DYN_LDS(lds);
@@ -134,7 +151,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     int* flgL = wgtL + size;                         // bit 0 alive (in nodesNext), bit 1 has weight
     int* clsL = flgL + size;                         // exclude class of the leaf's node, -1 if none
     int* cszL = clsL + size;                         // leaves covered by class c
-    int* recbuf = cszL + size;                       // [kChainStage][kCW]
+    // [kChainStage][kCW], 16-byte aligned (inside the launch's slack; by offset, so that the pointer stays an LDS pointer)
+    int* recbuf = cszL + size + ((4 - (int)(((unsigned char*)(cszL + size) - lds) >> 2)) & 3);
     int* outbuf = recbuf + kChainStage * kCW;        // [kChainStage][OW]
     int* markL = outbuf + kChainStage * q.OW;                 // [size + 1] first lane of a batch per top priority node
     int* ntn_l = markL + size + 1;                   // [size][ST] nodeToNodeCounts rows, padded stride
@@ -230,14 +248,27 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         gmin_dirty = true;
         ev_cur++;
         next_ev_oi = ev_cur < ev_end ? q.ev_oi[q.ev_perm[ev_cur]] : INT_MAX;
+        // nothing of an event is in flight when the steps go on: otherwise the compiler guards every later write to a
+        // register one of these loads used with a wait for ALL loads -- the next stage's records among them
+        BLANCE_WAIT_VMEM();
     };
     PH_DECL;
 
+    // A stage's records (24 KB) travel as 24 16-byte loads per lane, ALL in flight at once, and a stage ahead: they are
+    // issued when the previous stage starts and land in LDS when it ends -- one wave per CU has nothing else to hide the
+    // HBM round trip behind (a copy loop of dword loads, 16 in flight, paid six round trips per stage: more than the
+    // stage's steps).
+    BLANCE_STAGE_EACH(BLANCE_STAGE_DECL)
+    if (cbeg < cend) BLANCE_STAGE_FETCH_ALL(q.crec, cbeg, cend)
     for (int base = cbeg; base < cend && !escaped; base += kChainStage) {
       const int nb = cend - base < kChainStage ? cend - base : kChainStage;
       PH(0);
-      for (int i = lane; i < nb * kCW; i += 64) recbuf[i] = q.crec[(size_t)base * kCW + i];
-      __syncthreads();
+      {
+          int4* dst_ = (int4*)recbuf;
+          BLANCE_STAGE_EACH(BLANCE_STAGE_COMMIT)
+      }
+      if (base + kChainStage < cend) BLANCE_STAGE_FETCH_ALL(q.crec, base + kChainStage, cend)
+      BLANCE_WAVE_SYNC();                            // one wave per workgroup: LDS is in order; a __syncthreads() would wait for the loads just issued
       int b = 0;
       while (b < nb) {
         while (next_ev_oi < recbuf[b * kCW]) apply_event();      // due before this step (pass order)
@@ -726,7 +757,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         b++;
         if (__ballot(range_bad)) { escaped = true; stop_range = true; break; }
       }
-      __syncthreads();
+      BLANCE_WAVE_SYNC();
       stop_at = base + b;
       // flat mode keeps the steps done before a stop; a region chain's pass is redone as a whole
       const int n_done = (!escaped || q.flat) ? b : 0;

@@ -32,6 +32,8 @@
 #define __restrict__
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 
+struct int4 { int x, y, z, w; };                    // (used for 16-byte copies only)
+
 struct dim3 {
     unsigned x, y, z;
     constexpr dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
@@ -185,6 +187,7 @@ void launch_serial(dim3 grid, dim3 block, F body) {
     emu::launch_serial(dim3(grid), dim3(block), [&]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::block_barrier(); }
+#define BLANCE_WAIT_VMEM() ((void)0)
 #define BLANCE_WAVE_SYNC() emu::wave_barrier()   /* fibers are not in lockstep: model it */
 
 inline int __shfl_xor(int v, int mask, int = 64) {
