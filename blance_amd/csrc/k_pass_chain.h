@@ -118,9 +118,10 @@ static_assert(kCW % 4 == 0 && kStageVec == 24 && kChainStage * (kCW / 4) % 64 ==
 #define BLANCE_STAGE_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
     X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
 #define BLANCE_STAGE_DECL(t) int4 pre##t = {0, 0, 0, 0};
-#define BLANCE_STAGE_FETCH(t) { const int i_ = lane + 64 * t; pre##t = src_[i_ < n4_ ? i_ : lane]; }
+#define BLANCE_STAGE_FETCH(t) { const int i_ = lane + 64 * t; pre##t = src_[i_ < n4_ ? i_ : 0]; }
 #define BLANCE_STAGE_COMMIT(t) dst_[lane + 64 * t] = pre##t;      /* the whole stage area: words past a short stage are never read */
-// (lane < n4 whenever a stage has a step; a record is 96 bytes: 16-byte aligned)
+// (words past a short stage re-read its first one: nothing outside the stage's records is touched; a record is 96 bytes,
+// 16-byte aligned)
 #define BLANCE_STAGE_FETCH_ALL(crec, base_, cend_)                                                               \
     {                                                                                                             \
         const int n4_ = ((cend_) - (base_) < kChainStage ? (cend_) - (base_) : kChainStage) * (kCW / 4);          \
