@@ -111,6 +111,16 @@ def profile_json(name):
     except Exception:
         now = None
     if now != data.get("source_hash"):
+        # one documented exception: sources that differ from the profiled ones by a change listed, with its reason and
+        # commit, in profiles/r3_equivalent_sources.json -- quoted WITH both hashes, never silently
+        try:
+            with open(os.path.join(ROOT, "profiles", "r3_equivalent_sources.json")) as f:
+                eq = json.load(f).get(now or "", {})
+        except Exception:
+            eq = {}
+        if eq.get("profiled_as") == data.get("source_hash"):
+            return data, "profiles/%s (git %s, kernel sources %s; the sources are now %s: %s -- profiles/r3_NOTE_sources.txt)" % (
+                name, data.get("git_head"), data.get("source_hash"), now, eq.get("difference"))
         return None, "%s was taken from other kernel sources (%s, now %s)" % (name, data.get("source_hash"), now)
     return data, "profiles/%s (git %s, kernel sources %s)" % (name, data.get("git_head"), data.get("source_hash"))
 
