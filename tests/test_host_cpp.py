@@ -190,6 +190,39 @@ def test_cpp_mirror_on_random_cases_emulated():
     assert _check_random(cases, run_cli(build_emu(), cases)) > 100
 
 
+def _sparse_miss_cases(lo, hi):
+    """Larger maps in which prevMap lacks one or two of the partitions to assign (and has one of its own): the store of
+    plan.go:49-52 then fills recorded slots for most names and inserts the few others (blance_api.cpp: store)."""
+    import random as _random
+    from randgen import random_case
+    cases = []
+    for seed in range(lo, hi):
+        c = random_case(seed, max_nodes=10, max_parts=72)
+        if not c["partitionsToAssign"] or len(c["partitionsToAssign"]) < 34:
+            continue
+        rng = _random.Random(seed)
+        prev = {}
+        for name, part in c["partitionsToAssign"].items():
+            old = (c["prevMap"] or {}).get(name)
+            prev[name] = copy.deepcopy(old if old is not None else part)
+        for name in rng.sample(sorted(prev), rng.choice([1, 2])):
+            del prev[name]
+        prev["only-in-prev"] = {"name": "only-in-prev", "nodesByState": {}}
+        c["prevMap"] = prev
+        c["aliased"] = False
+        c["nodesToRemove"] = []
+        c["source"] = "sparse-miss seed %d" % seed
+        cases.append(c)
+    return cases
+
+
+def test_cpp_mirror_store_with_few_missing_names_emulated():
+    from test_simt_emulated import build_emu
+    cases = _sparse_miss_cases(5000, 5120)
+    assert len(cases) > 20
+    assert _check_random(cases, run_cli(build_emu(), cases)) > 15
+
+
 @pytest.mark.gpu
 def test_cpp_mirror_on_random_cases_gpu():
     from blance_amd import hip
