@@ -1,0 +1,73 @@
+"""The bench line contract, checked on the line committed from the last device run (profiles/r3_bench_default.json):
+the keys the driver parses, BASELINE.json's metric and headline workload, a roofline object that follows from its own
+inputs, a CPU baseline with its sample stated -- and the bookkeeping that ties the quoted counters to kernel sources."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r3_bench_default.json")) as f:
+        return json.load(f)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = _line()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
+    assert d["dtype"] == "f64" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert d["metric"].split(" at ")[0] in base["metric"]          # "partition-state assignments/sec"
+    assert "1048576" in d["config"]["workload"].replace(",", "") and "4096" in d["config"]["workload"].replace(",", "")
+    # value is whole-job throughput of the timed region: 3 sweeps x 1,048,576 partitions x 3 state slots ... per call
+    assert d["matches_oracle_digest"] is True
+    per_call = d["value"] * d["ms_per_step"] * 1e-3
+    assert abs(per_call - round(per_call)) < 1e-3 * per_call and per_call >= 1048576
+
+
+def test_roofline_follows_from_its_inputs():
+    r = _line()["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] <= 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    for k in _line()["roofline_per_kernel"]:
+        assert abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-9 and k["frac"] <= 1.0
+        # achieved = algorithmic bytes per launch / average launch duration
+        assert abs(k["achieved"] - k["algorithmic_bytes_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * k["achieved"]
+
+
+def test_cpu_baseline_states_its_sample():
+    c = _line()["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+    assert c["unit"] == _line()["unit"]
+
+
+def test_quoted_counters_are_tied_to_kernel_sources():
+    """bench.py quotes a committed PMC profile only for the kernel sources it was taken from, or for sources listed --
+    with the reason -- in profiles/r3_equivalent_sources.json; anything else gives traffic null."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import profile_summary
+    now = profile_summary.source_hash()
+    data, src = bench.profile_json("r3_pmc_hbm_config3.json")
+    with open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_config3.json")) as f:
+        profiled = json.load(f)["source_hash"]
+    if now == profiled:
+        assert data is not None and profiled in src
+    else:
+        with open(os.path.join(ROOT, "profiles", "r3_equivalent_sources.json")) as f:
+            eq = json.load(f)
+        if eq.get(now, {}).get("profiled_as") == profiled:
+            assert data is not None and now in src and profiled in src and "r3_NOTE_sources.txt" in src
+            assert os.path.exists(os.path.join(ROOT, "profiles", "r3_NOTE_sources.txt"))
+        else:
+            assert data is None and "other kernel sources" in src
