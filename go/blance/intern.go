@@ -99,6 +99,96 @@ func stateLess(model PartitionModel, a, b string) bool {
 	return a < b
 }
 
+// radixOrder sorts idx (stable, least significant digit first, 11 bits a pass) by key[idx[i]]; max is the largest key.
+func radixOrder(idx []int32, key []uint64, max uint64) []int32 {
+	tmp := make([]int32, len(idx))
+	for shift := uint(0); shift < 64 && (max>>shift) != 0; shift += 11 {
+		var cnt [2049]int
+		for _, i := range idx {
+			cnt[((key[i]>>shift)&2047)+1]++
+		}
+		for d := 0; d < 2048; d++ {
+			cnt[d+1] += cnt[d]
+		}
+		for _, i := range idx {
+			d := (key[i] >> shift) & 2047
+			tmp[cnt[d]] = i
+			cnt[d]++
+		}
+		idx, tmp = tmp, idx
+	}
+	return idx
+}
+
+// staticOrder returns the partitions' indices in the order of the static part of partitionSorter's key
+// (plan.go:519-540): ("%10d" of 999999999 - weight, "%10d" of the name if it is a non-negative number else the name,
+// Name), compared as strings.  "%10d" renderings of values in [0, 9999999999] compare like the values (digits
+// right-aligned behind spaces), so such keys are sorted as integers -- the common case, partitions named "0", "1", ...;
+// any other key takes the reference's string comparison literally.  weight[i] is 1 where PartitionWeights has no entry.
+func staticOrder(names []string, weight []int32) []int32 {
+	P := len(names)
+	idx := make([]int32, P)
+	for i := range idx {
+		idx[i] = int32(i)
+	}
+	num, wk := make([]uint64, P), make([]uint64, P)
+	var maxNum, maxWk uint64
+	simple := true
+	for i, name := range names {
+		v, err := strconv.Atoi(name)
+		k := int64(999999999) - int64(weight[i])
+		if err != nil || v < 0 || int64(v) > 9999999999 || k < 0 || k > 9999999999 {
+			simple = false
+			break
+		}
+		num[i], wk[i] = uint64(v), uint64(k)
+		if num[i] > maxNum {
+			maxNum = num[i]
+		}
+		if wk[i] > maxWk {
+			maxWk = wk[i]
+		}
+	}
+	if simple {
+		idx = radixOrder(idx, num, maxNum) // name key first, weight key second: the weight key decides
+		idx = radixOrder(idx, wk, maxWk)
+		for a := 0; a < P; { // equal keys ("7" and "007"): by Name, the reference's last tie-break
+			b := a + 1
+			for b < P && num[idx[b]] == num[idx[a]] && wk[idx[b]] == wk[idx[a]] {
+				b++
+			}
+			if b-a > 1 {
+				run := idx[a:b]
+				sort.Slice(run, func(x, y int) bool { return names[run[x]] < names[run[y]] })
+			}
+			a = b
+		}
+		return idx
+	}
+	type key struct {
+		w, n string
+	}
+	keys := make([]key, P)
+	for i, name := range names {
+		nkey := name
+		if v, err := strconv.Atoi(name); err == nil && v >= 0 {
+			nkey = fmt.Sprintf("%10d", v)
+		}
+		keys[i] = key{fmt.Sprintf("%10d", 999999999-int(weight[i])), nkey}
+	}
+	sort.Slice(idx, func(a, b int) bool {
+		ka, kb := keys[idx[a]], keys[idx[b]]
+		if ka.w != kb.w {
+			return ka.w < kb.w
+		}
+		if ka.n != kb.n {
+			return ka.n < kb.n
+		}
+		return names[idx[a]] < names[idx[b]]
+	})
+	return idx
+}
+
 // internProblem flattens the arguments of planNextMapEx (plan.go:23-31).
 func internProblem(
 	prevMap PartitionMap,
@@ -181,9 +271,15 @@ func internProblem(
 	}
 	N := len(nodes.names)
 
-	// ---- partitions
+	// ---- partitions.  One walk of the map (no second lookup per name); the ids are the RANKS in partitionSorter's
+	// static order (plan.go:519-540), so partOrder is the identity and no list of a million names is sorted as strings
+	// when the names are numbers.
 	weightsNil := options.PartitionWeights == nil
-	pnames := make([]string, 0, len(partitionsToAssign))
+	P := len(partitionsToAssign)
+	pnames := make([]string, 0, P)
+	pparts := make([]*Partition, 0, P)
+	f.partWeight = make([]int32, 0, P)
+	f.partHasWeight = make([]uint8, 0, P)
 	for key, p := range partitionsToAssign {
 		if p == nil {
 			return nil, unsupported("nil *Partition in partitionsToAssign")
@@ -191,32 +287,41 @@ func internProblem(
 		if p.Name != key {
 			return nil, unsupported("partition key %q != Partition.Name %q", key, p.Name)
 		}
-		pnames = append(pnames, key)
-	}
-	sort.Strings(pnames)
-	P := len(pnames)
-	f.partWeight = make([]int32, P)
-	f.partHasWeight = make([]uint8, P)
-	f.partInPrev = make([]uint8, P)
-	f.partPrevNeverEqual = make([]uint8, P)
-	for i, name := range pnames {
-		f.partWeight[i] = 1
+		w, has := int32(1), uint8(0)
 		if !weightsNil {
-			if w, ok := options.PartitionWeights[name]; ok {
-				if int64(w) > 2147483647 || int64(w) < -2147483648 {
+			if pw, ok := options.PartitionWeights[key]; ok {
+				if int64(pw) > 2147483647 || int64(pw) < -2147483648 {
 					return nil, unsupported("partition weight outside int32")
 				}
-				f.partWeight[i] = int32(w)
-				f.partHasWeight[i] = 1
+				w, has = int32(pw), 1
 			}
 		}
+		pnames = append(pnames, key)
+		pparts = append(pparts, p)
+		f.partWeight = append(f.partWeight, w)
+		f.partHasWeight = append(f.partHasWeight, has)
 	}
+	{
+		order := staticOrder(pnames, f.partWeight)
+		n2, p2 := make([]string, P), make([]*Partition, P)
+		w2, h2 := make([]int32, P), make([]uint8, P)
+		for r, i := range order {
+			n2[r], p2[r], w2[r], h2[r] = pnames[i], pparts[i], f.partWeight[i], f.partHasWeight[i]
+		}
+		pnames, pparts, f.partWeight, f.partHasWeight = n2, p2, w2, h2
+	}
+	f.partOrder = make([]int32, P)
+	for i := range f.partOrder {
+		f.partOrder[i] = int32(i)
+	}
+	f.partInPrev = make([]uint8, P)
+	f.partPrevNeverEqual = make([]uint8, P)
 	removed := StringsToMap(nodesToRemove)
 	f.assignOff = append(f.assignOff, 0)
 	f.prevOff = append(f.prevOff, 0)
 	var absLoad int64
 	for i, name := range pnames {
-		pa := partitionsToAssign[name]
+		pa := pparts[i]
 		for st := range pa.NodesByState {
 			if _, ok := sid[st]; !ok {
 				return nil, unsupported("partition %q carries state %q that is not in the model", name, st)
@@ -231,12 +336,12 @@ func internProblem(
 				f.assignKind = append(f.assignKind, listNil)
 			default:
 				f.assignKind = append(f.assignKind, listSet)
-				seen := make(map[string]bool, len(lst))
-				for _, x := range lst {
-					if seen[x] {
-						return nil, unsupported("duplicate node inside a state list of %q", name)
+				for a, x := range lst { // (lists are a handful of names: no set per list)
+					for _, y := range lst[:a] {
+						if x == y {
+							return nil, unsupported("duplicate node inside a state list of %q", name)
+						}
 					}
-					seen[x] = true
 					f.assignNodes = append(f.assignNodes, nodes.add(x))
 				}
 			}
@@ -488,40 +593,6 @@ func internProblem(
 		}
 	}
 
-	// ---- the static part of partitionSorter's key (plan.go:519-540), compared as the reference's strings
-	{
-		type key struct {
-			w, n, name string
-			i          int32
-		}
-		keys := make([]key, P)
-		for i, name := range pnames {
-			nkey := name
-			if v, err := strconv.Atoi(name); err == nil && v >= 0 {
-				nkey = fmt.Sprintf("%10d", v)
-			}
-			w := 1
-			if !weightsNil {
-				if pw, ok := options.PartitionWeights[name]; ok {
-					w = pw
-				}
-			}
-			keys[i] = key{fmt.Sprintf("%10d", 999999999-w), nkey, name, int32(i)}
-		}
-		sort.Slice(keys, func(a, b int) bool {
-			if keys[a].w != keys[b].w {
-				return keys[a].w < keys[b].w
-			}
-			if keys[a].n != keys[b].n {
-				return keys[a].n < keys[b].n
-			}
-			return keys[a].name < keys[b].name
-		})
-		f.partOrder = make([]int32, P)
-		for r, k := range keys {
-			f.partOrder[r] = k.i
-		}
-	}
 	if P*M == 0 {
 		f.assignOff, f.prevOff = []int32{0}, []int32{0}
 	}
