@@ -6,8 +6,9 @@ checked on a machine without a GPU (tests/test_planes_asm.py).
 
 Only what that loop uses is implemented: SALU moves / logic / shifts / compares / add with their SCC results, the two
 cross-lane moves v_readlane_b32 / v_writelane_b32, s_branch / s_cbranch_scc0 / s_cbranch_scc1, GNU-as numeric local
-labels ("20f": the next definition of 20 below, "0b": the nearest above).  Named operands %[x] are looked up in a dict:
-an int for an SGPR operand (32 or 64 bits wide, as the instruction says), a list of 64 ints for a VGPR."""
+labels ("20f": the next definition of 20 below, "0b": the nearest above) -- and v_min_u32_dpp with the DPP controls of
+the lane minima of dev_common.h (wave_min_u32_bcast, row_min_u32), which the emulator likewise replaces by builtins.
+Named operands %[x] are looked up in a dict: an int for an SGPR operand (32 or 64 bits wide, as the instruction says), a list of 64 ints for a VGPR."""
 import os
 import re
 import subprocess
@@ -65,7 +66,18 @@ class Program:
                 self.ins.append(("label", m.group(1)))
                 continue
             mn, _, rest = line.partition(" ")
-            self.ins.append((mn, [o.strip() for o in rest.split(",")] if rest else []))
+            ops, depth, cur = [], 0, ""
+            for ch in rest:                                   # commas inside quad_perm:[..] do not separate operands
+                depth += ch == "["
+                depth -= ch == "]"
+                if ch == "," and depth == 0:
+                    ops.append(cur.strip())
+                    cur = ""
+                else:
+                    cur += ch
+            if cur.strip():
+                ops.append(cur.strip())
+            self.ins.append((mn, ops))
 
     def target(self, pc, ref):
         name, direction = ref[:-1], ref[-1]
@@ -170,5 +182,44 @@ class Machine:
             elif mn == "s_cbranch_scc1":
                 if self.scc:
                     pc = prog.target(pc - 1, a[0])
+            elif mn == "s_nop":
+                pass
+            elif mn == "v_min_u32_dpp":
+                self.dpp_min(a)
             else:
                 raise NotImplementedError(mn)
+
+    def dpp_min(self, a):
+        """v_min_u32_dpp vdst, vsrc0, vsrc1 <ctrl> row_mask:m bank_mask:m -- vdst = min(vsrc0 of the lane the control names,
+        vsrc1) in the lanes whose row and bank are enabled and whose source lane exists (bound_ctrl is not set: the others
+        keep vdst).  Controls: quad_perm:[a,b,c,d], row_half_mirror, row_mirror, row_bcast:15, row_bcast:31."""
+        tail = a[2].split()
+        dst, src0, src1 = self.vreg_n(a[0]), list(self.vreg_n(a[1])), list(self.vreg_n(tail[0]))
+        ctrl = " ".join(tail[1:] + a[3:]) if len(a) > 3 else " ".join(tail[1:])
+        ctrl = ctrl.replace(" ,", ",")
+        row_mask = int(re.search(r"row_mask:(0x[0-9a-f]+|\d+)", ctrl).group(1), 0)
+        bank_mask = int(re.search(r"bank_mask:(0x[0-9a-f]+|\d+)", ctrl).group(1), 0)
+        q = re.search(r"quad_perm:\[(\d),(\d),(\d),(\d)\]", ctrl.replace(" ", ""))
+        for lane in range(64):
+            if not (row_mask >> (lane >> 4)) & 1 or not (bank_mask >> ((lane & 15) >> 2)) & 1:
+                continue
+            if q:
+                src = (lane & ~3) + int(q.group(1 + (lane & 3)))
+            elif "row_half_mirror" in ctrl:
+                src = (lane & ~7) + 7 - (lane & 7)
+            elif "row_mirror" in ctrl:
+                src = (lane & ~15) + 15 - (lane & 15)
+            elif "row_bcast:15" in ctrl:
+                src = (lane & ~15) - 1 if lane >= 16 else None
+            elif "row_bcast:31" in ctrl:
+                src = 31 if lane >= 32 else None
+            else:
+                raise NotImplementedError(ctrl)
+            if src is None:
+                continue
+            dst[lane] = min(src0[src], src1[lane])
+
+    def vreg_n(self, o):
+        """a VGPR operand: %[name] or a positional %0 of the asm statement"""
+        m = re.match(r"^%\[(\w+)\]$", o) or re.match(r"^%(\d+)$", o)
+        return self.ops[m.group(1)]

@@ -185,3 +185,36 @@ def test_word0_path_length_of_the_headline_instantiation(programs):
     got = with_asm(programs[(2, True)], 2, P, ex, cls_mask, 16, S - 1, (1 << S) - 1)
     assert got[4] == 0 and not got[3]
     assert got[5] == 1 + 26 * 16 + 1 + 3, got[5]                 # s_mov m0 | 16 steps | s_branch 7f | the three moves at 7:
+
+
+def _dpp_programs():
+    wave = rows4 = rows16 = None
+    for text, operands in preprocessed_asm_templates():
+        if "v_min_u32_dpp" not in text:
+            continue
+        if "row_bcast:31" in text:
+            wave = wave or Program(text)
+        elif "row_mirror" in text:
+            rows16 = rows16 or Program(text)                     # the second half of row_min_u32<16>
+        elif "quad_perm" in text:
+            rows4 = rows4 or Program(text)
+    assert wave and rows4 and rows16
+    return wave, rows4, rows16
+
+
+def test_dpp_minima_of_dev_common():
+    """wave_min_u32_bcast and row_min_u32 (dev_common.h) are inline assembly on the device and builtins in the emulator: the
+    assembly text, executed under the documented DPP semantics, leaves the wave's minimum in lane 63 and each group's
+    minimum in all of its lanes."""
+    wave, rows4, rows16 = _dpp_programs()
+    rng = random.Random(7)
+    for it in range(200):
+        v = [rng.choice([rng.getrandbits(32), rng.getrandbits(8), 0xffffffff]) for _ in range(64)]
+        ops = {"0": list(v)}
+        Machine(ops).run(wave)
+        assert ops["0"][63] == min(v)
+        ops = {"0": list(v)}
+        Machine(ops).run(rows4)
+        assert ops["0"] == [min(v[l & ~3:(l & ~3) + 4]) for l in range(64)]
+        Machine(ops).run(rows16)                                 # row_min_u32<16> = the quad part, then the row part
+        assert ops["0"] == [min(v[l & ~15:(l & ~15) + 16]) for l in range(64)]
