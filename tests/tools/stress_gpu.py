@@ -2,7 +2,9 @@
 """One-off GPU stress: mid-size random problems (thousands of partitions, up to a
 thousand nodes; regular and ragged hierarchies, weights, removals, rebalances)
 through the HIP planner vs the CPU oracle, bit for bit.  Run on the GPU box:
-    python tests/tools/stress_gpu.py [n_cases] [seed0] [--flat-heavy]"""
+    python tests/tools/stress_gpu.py [n_cases] [seed0] [--flat-heavy]
+With --emulated the same generator, at a tenth of the partitions, runs the kernels under the SIMT emulator on the CPU
+(tests/simt): hours of idle CPU find what the fixed seeds of the test-suite do not."""
 import os
 import random
 import sys
@@ -18,6 +20,9 @@ from oracle import loader                            # noqa: E402
 FLAT_HEAVY = "--flat-heavy" in sys.argv
 if FLAT_HEAVY:
     sys.argv.remove("--flat-heavy")
+EMULATED = "--emulated" in sys.argv
+if EMULATED:
+    sys.argv.remove("--emulated")
 
 
 def case(seed):
@@ -26,7 +31,7 @@ def case(seed):
     rpz = rng.choice([2, 3, 4, 8])
     zones = rng.choice([2, 3, 4, 8, 16])
     N = rack * rpz * zones - rng.choice([0, 0, 1, 3])
-    P = rng.choice([2500, 4000, 9000, 20000])
+    P = rng.choice([257, 520, 900, 2100]) if EMULATED else rng.choice([2500, 4000, 9000, 20000])
     nodes = ["n%04d" % i for i in range(N)]
     hier = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=4)
     k = rng.choice([1, 2, 2, 3])
@@ -35,10 +40,10 @@ def case(seed):
     if FLAT_HEAVY:                                  # the workgroup pass: flat, weighted, up to 8 nodes per thread
         rule = rng.choice([None, None, (2, 1)])
         if rng.random() < 0.3:
-            N = rng.choice([1500, 3000, 5000])
+            N = rng.choice([300, 700]) if EMULATED else rng.choice([1500, 3000, 5000])
             nodes = ["n%04d" % i for i in range(N)]
             hier = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=4)
-            P = rng.choice([2500, 4000])
+            P = rng.choice([200, 400]) if EMULATED else rng.choice([2500, 4000])
     rules = None if rule is None else {"replica": [{"includeLevel": rule[0], "excludeLevel": rule[1]}]}
     opts = dict(node_hierarchy=hier if rules else None, hierarchy_rules=rules)
     if rng.random() < (0.7 if FLAT_HEAVY else 0.4):
@@ -56,7 +61,11 @@ def case(seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    pl = hip.Planner(device_id=0)
+    if EMULATED:
+        from test_simt_emulated import build_emu
+        pl = hip.Planner(lib_path=build_emu())
+    else:
+        pl = hip.Planner(device_id=0)
     bad = 0
     t0 = time.time()
     for seed in range(s0, s0 + n):
