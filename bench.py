@@ -166,15 +166,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    # BLANCE_BENCH_REHEARSAL=<emulated library>: the multi-rank control flow of this file on a machine without a GPU (gloo,
+    # kernels under the SIMT emulator, the collectives over host memory) -- tests/test_dist.py runs it so that the first
+    # 8-GPU run is not the first execution of these lines.  Its line says "rehearsal": true; its numbers mean nothing.
+    rehearsal = os.environ.get("BLANCE_BENCH_REHEARSAL")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()               # what RCCL's communicator reports
 
     from blance_amd import dist_util, hip, synth
-    pl = hip.Planner(device_id=local_rank)          # raises without the HIP library / a device
+    if rehearsal:
+        pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8)
+    else:
+        pl = hip.Planner(device_id=local_rank)      # raises without the HIP library / a device
     if args.config == 5:                            # the rebalance starts from a plan over the old nodes (setup, untimed)
         fp1 = synth.config5_initial(args.parts or 1 << 20, args.nodes or 4096)
         fp = synth.config5_rebalance(fp1, pl.plan(fp1), args.parts or 1 << 20, args.nodes or 4096)
@@ -189,7 +199,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     def timed(steps, warmup):
         for _ in range(warmup):
@@ -369,7 +380,11 @@ def main():
                 # configs 2 and 5 have no hierarchy rule: their passes are flat -- one dependency chain per pass, nothing to shard
                 sharded = "not applicable: flat passes are one chain (DESIGN.md 7); only config 3's region chains shard"
             else:
-                dist_util.shard_plan_rccl(pl, dist)
+                if rehearsal:
+                    ar, ag = dist_util.gloo_collectives(pl, dist)
+                    pl.comm_set_callback(rank, world, ar, ag)
+                else:
+                    dist_util.shard_plan_rccl(pl, dist)
                 calls0, words0 = pl.comm_stats()
                 sdt, sacc, sr = timed(args.steps, args.warmup)
                 calls1, words1 = pl.comm_stats()
@@ -394,6 +409,9 @@ def main():
     if rank == 0:
         if sharded:
             out["sharded"] = sharded
+        if rehearsal:
+            out["rehearsal"] = True
+            out["data"] = "REHEARSAL on the CPU (emulated kernels, gloo): not a measurement"
         print(json.dumps(out), flush=True)
     pl.close()
     if dist is not None:

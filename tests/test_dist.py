@@ -128,3 +128,30 @@ def test_max_over_ranks_world_size_2(tmp_path):
         print("rank", rank, "ok")
     """ % ROOT, 29517)
     assert out.count("ok") == 2
+
+
+def test_bench_multi_rank_flow_rehearsal():
+    """bench.py's N > 1 path -- the lines the driver's 8-GPU run executes -- rehearsed with two gloo ranks and the
+    emulated kernels (BLANCE_BENCH_REHEARSAL): replicas timed between barriers with the maximum over ranks, then the
+    sharded plan with its two collectives per chain pass, one JSON line from rank 0."""
+    import json
+    from test_simt_emulated import build_emu
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BLANCE_BENCH_REHEARSAL=build_emu())
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--parts", "600", "--nodes", "256"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                                   # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["rehearsal"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and "replicas x2" in d["config"]["parallelism"]
+    # the whole job: both replicas' assignments over the slower rank's time
+    per_call = d["value"] * d["ms_per_step"] * 1e-3 / 2
+    assert abs(per_call - round(per_call)) < 1e-6 * per_call
+    s = d["sharded"]
+    assert "error" not in s, s
+    assert s["rccl_world_size"] == 2 and s["same_digest_on_every_rank"] and s["same_digest_as_single_rank_plan"]
+    assert s["scaling"] == "strong" and s["comm_calls_per_plan"] >= 2 and s["comm_bytes_per_plan"] > 0
+    assert "cpu_baseline" not in d                                       # rank 0 at N = 1 only
