@@ -71,3 +71,26 @@ def test_quoted_counters_are_tied_to_kernel_sources():
             assert os.path.exists(os.path.join(ROOT, "profiles", "r3_NOTE_sources.txt"))
         else:
             assert data is None and "other kernel sources" in src
+
+
+def test_live_line_of_a_rehearsal_has_the_same_fields():
+    """bench.py itself, N = 1, on the CPU (BLANCE_BENCH_REHEARSAL: emulated kernels; the numbers mean nothing): the line it
+    prints carries the contract's fields, so an edit of bench.py cannot drop one unnoticed until the next device run."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_simt_emulated import build_emu
+    env = dict(os.environ, BLANCE_BENCH_REHEARSAL=build_emu())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--parts", "600", "--nodes", "256", "--steps", "2",
+                          "--warmup", "1", "--no-sharded"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    committed = _line()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["rehearsal"] is True and d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
+    assert d["metric"] == committed["metric"] and d["unit"] == committed["unit"] and d["dtype"] == committed["dtype"]
+    assert set(committed["roofline"]) <= set(d["roofline"]) | {"traffic_from", "critical_path", "occupancy"}
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["sample"]

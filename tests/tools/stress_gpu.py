@@ -61,11 +61,13 @@ def case(seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import json
+    kw = json.loads(os.environ.get("STRESS_PLANNER_KW", "{}"))     # e.g. '{"planes": false}', '{"stay_top": "force"}'
     if EMULATED:
         from test_simt_emulated import build_emu
-        pl = hip.Planner(lib_path=build_emu())
+        pl = hip.Planner(lib_path=build_emu(), **kw)
     else:
-        pl = hip.Planner(device_id=0)
+        pl = hip.Planner(device_id=0, **kw)
     bad = 0
     t0 = time.time()
     for seed in range(s0, s0 + n):
