@@ -32,6 +32,8 @@ def case(seed):
     zones = rng.choice([2, 3, 4, 8, 16])
     N = rack * rpz * zones - rng.choice([0, 0, 1, 3])
     P = rng.choice([257, 520, 900, 2100]) if EMULATED else rng.choice([2500, 4000, 9000, 20000])
+    if os.environ.get("STRESS_P"):                  # e.g. STRESS_P=5,23,70,130: chains with short last stages
+        P = rng.choice([int(x) for x in os.environ["STRESS_P"].split(",")])
     nodes = ["n%04d" % i for i in range(N)]
     hier = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=4)
     k = rng.choice([1, 2, 2, 3])
