@@ -258,3 +258,29 @@ def config5_rebalance(fp1, res1, P=1048576, N=4096, hierarchy=False):
     plan1, _ = problem.decode_result(fp1, res1)
     return problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"],
                                  **_config5_opts(c))
+
+
+def replan_problem(fp, res):
+    """The call PlanNextMap(prevMap = partitionsToAssign = the result `res` of `fp`, same nodes, nodesToRemove = nil,
+    nodesToAdd = nil, same model / options) as a flat problem, without going through strings: the result's lists ARE
+    the two input maps (plan.go:49-52 stores exactly them).  For problems whose partitions are all in
+    partitionsToAssign and that carry no prevMap-only loads (the generators of this file)."""
+    if int(fp.n_loads) != 0:
+        raise ValueError("replan_problem: problems with prevMap-only partitions are not handled")
+    P, M = int(fp.n_parts), int(fp.n_states)
+    fp2 = abi.FlatProblem()
+    fp2.scalars = dict(fp.scalars)
+    for name, a in fp.arrays.items():
+        fp2.set(name, a.copy())
+    fp2.node_names, fp2.state_names, fp2.part_names = fp.node_names, fp.state_names, fp.part_names
+    total = int(res.out_off[P * M]) if P * M else 0
+    for pre in ("assign", "prev"):
+        fp2.set(pre + "_off", np.asarray(res.out_off[:P * M + 1]))
+        fp2.set(pre + "_nodes", np.asarray(res.out_nodes[:total]))
+        fp2.set(pre + "_kind", np.asarray(res.out_kind[:P * M]))
+    fp2.set("part_in_prev", np.ones(P, dtype=np.uint8))
+    fp2.set("part_prev_never_equal", np.zeros(P, dtype=np.uint8))
+    fp2.set("node_removed", np.zeros(len(fp.node_removed), dtype=np.uint8))
+    fp2.set("node_added", np.zeros(len(fp.node_added), dtype=np.uint8))
+    fp2.scalars.update(n_prev=P, nodes_to_add_nil=1)
+    return fp2

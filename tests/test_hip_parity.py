@@ -272,6 +272,11 @@ def test_config5_full_size_digest(planner):
     fp2 = synth.config5_rebalance(fp1, r1, P, N)
     r2 = planner.plan(fp2)
     assert (r2.iterations, r2.digest()) == (want["rebalance"]["iterations"], want["rebalance"]["digest"])
+    # and what holds at any size without an oracle (tests/properties.py): list lengths, no removed node, no node twice
+    # in a partition, the weighted load of every state adds up
+    import properties
+    properties.plan_properties(fp1, r1)
+    properties.plan_properties(fp2, r2)
 
 
 def test_edge_shapes(planner, eager_planner):
