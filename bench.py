@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=0, help="override node count (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="skip the 8-contexts-on-one-GPU leg of N = 1")
+    ap.add_argument("--periodic", action="store_true", help="OPT-IN, not the headline: the all-blank chain pass in its periodic "
+                    "form (blance_amd/csrc/k_period.h); the line then carries config.opt_in and no committed counters apply")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -184,7 +186,7 @@ def main():
     if rehearsal:
         pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8)
     else:
-        pl = hip.Planner(device_id=local_rank)      # raises without the HIP library / a device
+        pl = hip.Planner(device_id=local_rank, periodic=args.periodic)      # raises without the HIP library / a device
     if args.config == 5:                            # the rebalance starts from a plan over the old nodes (setup, untimed)
         fp1 = synth.config5_initial(args.parts or 1 << 20, args.nodes or 4096)
         fp = synth.config5_rebalance(fp1, pl.plan(fp1), args.parts or 1 << 20, args.nodes or 4096)
@@ -331,7 +333,10 @@ def main():
                        "partitions": P, "nodes": N, "assignments_per_call": assignments,
                        "sweeps_per_call": iterations, "parallelism": "replicas x%d" % world,
                        "steps_bulk": int(batched), "steps_one_by_one": int(sequential),
-                       "headline": bool(args.config == 3 and headline_shape)},
+                       "headline": bool(args.config == 3 and headline_shape and not args.periodic),
+                       **({"opt_in": "periodic all-blank chain pass (k_period.h): two periods walked per region, the periodic "
+                                     "stretch copied; the roofline blocks below describe the default kernels, not this run's"}
+                          if args.periodic else {})},
             "roofline": dict(dom, **{
                 "reference_dense_scan_equivalent_GBps": dense,
                 "whole_call": whole,

@@ -16,6 +16,7 @@
 
 #include "k_flat.h"
 #include "k_sweep.h"
+#include "k_period.h"
 #ifdef BLANCE_SIMT_EMU          /* the emulator build is one translation unit */
 #include "tu_seq.hip"
 #include "tu_tree.hip"
@@ -77,6 +78,9 @@ struct blance_ctx {
     std::vector<int64_t> last_stays; // [state] steps the last chain pass of that state committed as verified stays
     bool no_stay_top = false;       // test knob (& 64): never k_stay_by_top
     bool force_stay_top = false;    // test knob (& 128): try k_stay_by_top in every chain pass with NumPartitions > 0
+    bool periodic = false;          // opt-in (& 256, or BLANCE_PERIODIC=1): an all-blank chain pass with periodic records walks two periods (k_period.h)
+    int64_t periodic_passes = 0;
+    int periodic_cut = 0;           // test knob BLANCE_PERIODIC_CUT (k_period_clamp)
     DevBuf cnt_base, xbuf, gath;    // sharded pass: loads at pass start, [flags | load change], gathered output slices
     std::vector<int32_t> h_reg_off; // host copy of the chain offsets (slice sizes of the all-gather)
     bool trace = false;             // BLANCE_TRACE, read once at context creation
@@ -108,6 +112,7 @@ struct blance_ctx {
     };
     std::vector<RuleRegions> rule_regions;
     DevBuf leaf_node, regid, chain_order, bucket_counts, reg_off, cnt_save, crec;
+    DevBuf period, cnt_p1;          // k_period.h: per-region period tables, the counters after the first period
     DevBuf fl_iota, fl_zero, fl_one, fl_reglo, fl_reghi;   // the whole cluster as one region (flat single chain)
     DevBuf n_ev, chain_oi, ev_key, ev_oi, ev_leaf, ev_w, ev_perm, ev_off, ev_counts;   // chain events
     bool flat_chain_ok = false;
@@ -150,7 +155,7 @@ struct blance_ctx {
         cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release();
         dl_off.release(); dl_nodes.release();
         for (DevBuf& b : mv) b.release();
-        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &n_ev, &chain_oi,
+        DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &period, &cnt_p1, &n_ev, &chain_oi,
                           &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
                           &fl_one, &fl_reglo, &fl_reghi, &f_tot, &f_g,
                           &f_top_g, &f_top_n, &f_row_count, &f_m, &f_moff, &f_keys_a, &f_keys_b, &f_vals_a,
@@ -304,6 +309,8 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->no_planes = opt && (opt->reserved[2] & 32);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
+    c->periodic = (opt && (opt->reserved[2] & 256)) || getenv("BLANCE_PERIODIC") != nullptr;
+    if (const char* pc = getenv("BLANCE_PERIODIC_CUT")) c->periodic_cut = atoi(pc);
     c->trace = getenv("BLANCE_TRACE") != nullptr;
     if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
@@ -1077,7 +1084,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     // plan reads the chain offsets in the same round trip (the slice sizes of collective B)
     int32_t n_events = 0, cfl[8] = {0};
     HIPTRY(hipMemcpyAsync(cfl, scal + 4, sizeof cfl, hipMemcpyDeviceToHost, sm));
-    if (sharded) {
+    if (sharded || c->periodic) {
         c->h_reg_off.resize((size_t)B + 1);
         HIPTRY(hipMemcpyAsync(c->h_reg_off.data(), c->reg_off.p, sizeof(int32_t) * ((size_t)B + 1), hipMemcpyDeviceToHost, sm));
     }
@@ -1211,7 +1218,56 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     // kernel makes the same choices)
     bool lean = false;
     if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4 && !cfl[0]) {
-        if (c->no_planes || !launch_chain_planes(sm, cq, rr.max_size)) launch_chain_blank(sm, cq, rr.max_size);
+        bool walked = false;
+        if (c->periodic && !sharded && !c->no_planes && rr.max_size <= 128 && n_events == 0 && !cfl[6] && !cfl[7]) {
+            // k_period.h: regions whose records repeat are walked for two periods; the rest of the periodic stretch is
+            // copied, what lies behind it is walked -- all decided on the device, region by region
+            int max_len = 0;
+            for (int r = 0; r < B; r++) max_len = std::max(max_len, (int)(c->h_reg_off[r + 1] - c->h_reg_off[r]));
+            if (max_len >= kPeriodMinRounds * 2) {
+                RESERVE(period, sizeof(int32_t) * ((size_t)kPWords * B + 1));
+                RESERVE(cnt_p1, sizeof(int32_t) * (cnt_words + 1));
+                int32_t* pb = c->period.as<int32_t>();
+                const int gx = cdiv(max_len, 256), gl = cdiv(rr.max_size, 64);
+                BLANCE_LAUNCH_NOSYNC(k_period_init, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
+                const int gf = cdiv(std::min(max_len, kPeriodCap + 1), 256);
+                BLANCE_LAUNCH_NOSYNC(k_period_find, gf * B, 256, 0, sm, B, gf, cq.reg_off, cq.crec, pb);
+                BLANCE_LAUNCH_NOSYNC(k_period_verify, gx * B, 256, 0, sm, B, gx, cq.reg_off, cq.crec, pb);
+                if (c->periodic_cut > 0) BLANCE_LAUNCH_NOSYNC(k_period_clamp, cdiv(B, 64), 64, 0, sm, B, c->periodic_cut, pb);
+                BLANCE_LAUNCH_NOSYNC(k_period_segments, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
+                ChainParams sq = cq;
+                sq.seg_beg = pb + (size_t)kPBeg1 * B; sq.seg_end = pb + (size_t)kPEnd1 * B;
+                if (launch_chain_planes(sm, sq, rr.max_size)) {
+                    walked = true;
+                    HIPTRY(hipMemcpyAsync(c->cnt_p1.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+                    sq.seg_beg = pb + (size_t)kPBeg2 * B; sq.seg_end = pb + (size_t)kPEnd2 * B;
+                    launch_chain_planes(sm, sq, rr.max_size);
+                    BLANCE_LAUNCH_NOSYNC(k_period_state_max, gl * B, 64, 0, sm, B, gl, m, N, NX, cq.reg_lo, cq.reg_hi, cq.leaf_node,
+                                         cq.alive, c->cnt_p1.as<int32_t>(), cq.cnt, pb);
+                    BLANCE_LAUNCH_NOSYNC(k_period_state_check, gl * B, 64, 0, sm, B, gl, m, N, NX, cq.reg_lo, cq.reg_hi, cq.leaf_node,
+                                         cq.alive, c->cnt_p1.as<int32_t>(), cq.cnt, pb);
+                    BLANCE_LAUNCH_NOSYNC(k_period_verdict, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
+                    BLANCE_LAUNCH_NOSYNC(k_period_replicate, gx * B, 256, 0, sm, B, gx, OW, cq.reg_off, pb, cq.out);
+                    BLANCE_LAUNCH(k_period_counts, B, 256, 0, sm, B, m, N, NX, OW, cq.reg_off, cq.reg_lo, cq.reg_hi, cq.leaf_node,
+                                  cq.alive, cq.crec, cq.out, pb, cq.cnt);
+                    sq.seg_beg = pb + (size_t)kPBeg3 * B; sq.seg_end = pb + (size_t)kPEnd3 * B;
+                    launch_chain_planes(sm, sq, rr.max_size);
+                    launches += 11;
+                    c->periodic_passes++;
+                    if (c->trace) {
+                        std::vector<int32_t> hp((size_t)kPWords * B);
+                        HIPTRY(hipMemcpyAsync(hp.data(), pb, sizeof(int32_t) * hp.size(), hipMemcpyDeviceToHost, sm));
+                        HIPTRY(hipStreamSynchronize(sm));
+                        int64_t copied = 0; int n_ok = 0;
+                        for (int r = 0; r < B; r++)
+                            if (hp[(size_t)kPOk * B + r]) { n_ok++; copied += hp[(size_t)kPLimit * B + r] - 2 * hp[(size_t)kPT * B + r]; }
+                        fprintf(stderr, "[blance] chain pass state %d: periodic records in %d of %d regions (period %d in the first), %lld of %d steps copied\n",
+                                m, n_ok, B, hp[(size_t)kPT * B], (long long)copied, P);
+                    }
+                }
+            }
+        }
+        if (!walked && (c->no_planes || !launch_chain_planes(sm, cq, rr.max_size))) launch_chain_blank(sm, cq, rr.max_size);
         int32_t fl[2] = {0, 0};
         HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipStreamSynchronize(sm));

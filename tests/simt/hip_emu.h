@@ -254,6 +254,11 @@ inline int atomicMin(int* p, int v) {
     while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
 }
+inline int atomicMax(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 
 // ---- host runtime: device memory is host memory -----------------------------
 typedef int hipError_t;

@@ -495,3 +495,4 @@ def test_config3_shapes_at_scale(planner, rack, racks_per_zone, k_rep):
     c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k_rep}}
     fp = synth.case_to_flat(c)
     _same(planner.plan(fp), _oracle(fp), ("config 3 at scale", rack, racks_per_zone, k_rep))
+
