@@ -23,6 +23,22 @@ def check_shapes(pl, shapes=SHAPES):
         assert (got.digest(), got.iterations) == (want.digest(), want.iterations), (P, N)
 
 
+TREES = [(12, 8, 2), (8, 16, 3), (16, 8, 1), (4, 4, 2), (16, 8, 4), (2, 8, 2)]      # rack, racks per zone, replicas
+
+
+def check_trees(pl, P=16384, zones=4):
+    """Other trees and replica counts (periods of 96, 128 and 16 steps; class masks by lane reads and by arithmetic)."""
+    from oracle import loader
+    for rack, rpz, k in TREES:
+        N = rack * rpz * zones
+        c = synth.config_case(3, P=P, N=N)
+        c["nodeHierarchy"] = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=8)
+        c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
+        fp = synth.case_to_flat(c)
+        got, want = pl.plan(fp), loader.plan(fp)
+        assert (got.digest(), got.iterations) == (want.digest(), want.iterations), (rack, rpz, k)
+
+
 def check_random(pl, seeds):
     from oracle import loader
     for seed in seeds:
@@ -35,6 +51,7 @@ def test_periodic_pass_equals_the_oracle():
     from test_simt_emulated import build_emu
     pl = hip.Planner(lib_path=build_emu(), chain_min_parts=8, periodic=True)
     check_shapes(pl)
+    check_trees(pl)
     pl.close()
     pl = hip.Planner(lib_path=build_emu(), chain_min_parts=1, periodic=True)      # tiny chains, odd trees: mostly the ways out
     check_random(pl, range(7000, 7080))

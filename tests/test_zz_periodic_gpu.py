@@ -30,6 +30,7 @@ def test_periodic_all_blank_pass():
     got = pl.plan(synth.config_flat(3))
     assert (got.iterations, got.digest()) == (want["iterations"], want["digest"])
     T.check_shapes(pl)
+    T.check_trees(pl, P=131072, zones=32)
     pl.close()
     os.environ["BLANCE_PERIODIC_CUT"] = "1000"
     try:
