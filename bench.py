@@ -184,7 +184,7 @@ def main():
 
     from blance_amd import dist_util, hip, synth
     if rehearsal:
-        pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8)
+        pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8, periodic=args.periodic)
     else:
         pl = hip.Planner(device_id=local_rank, periodic=args.periodic)      # raises without the HIP library / a device
     if args.config == 5:                            # the rebalance starts from a plan over the old nodes (setup, untimed)
