@@ -39,6 +39,25 @@ def check_trees(pl, P=16384, zones=4):
         assert (got.digest(), got.iterations) == (want.digest(), want.iterations), (rack, rpz, k)
 
 
+def check_weights_and_gaps(pl, P=8192, N=512):
+    """One partition weight for all (copied in units of that weight), two weights (the stretch ends where the weight
+    changes; the chain kernel refuses the rest and the pass is redone in full), nodes missing from the tree (period 120)."""
+    from oracle import loader
+    for mode in ("w3", "mixed", "gaps"):
+        c = synth.config_case(3, P=P, N=N)
+        if mode == "w3":
+            c["partitionWeights"] = {p: 3 for p in c["partitionsToAssign"]}
+        if mode == "mixed":
+            c["partitionWeights"] = {p: (3 if int(p) % 2 else 1) for p in c["partitionsToAssign"]}
+        if mode == "gaps":
+            gone = set(c["nodesAll"][5::17])
+            c["nodesAll"] = [n for n in c["nodesAll"] if n not in gone]
+            c["nodesToAdd"] = list(c["nodesAll"])
+        fp = synth.case_to_flat(c)
+        got, want = pl.plan(fp), loader.plan(fp)
+        assert (got.digest(), got.iterations) == (want.digest(), want.iterations), mode
+
+
 def check_random(pl, seeds):
     from oracle import loader
     for seed in seeds:
@@ -52,6 +71,7 @@ def test_periodic_pass_equals_the_oracle():
     pl = hip.Planner(lib_path=build_emu(), chain_min_parts=8, periodic=True)
     check_shapes(pl)
     check_trees(pl)
+    check_weights_and_gaps(pl)
     pl.close()
     pl = hip.Planner(lib_path=build_emu(), chain_min_parts=1, periodic=True)      # tiny chains, odd trees: mostly the ways out
     check_random(pl, range(7000, 7080))

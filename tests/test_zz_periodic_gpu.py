@@ -31,6 +31,7 @@ def test_periodic_all_blank_pass():
     assert (got.iterations, got.digest()) == (want["iterations"], want["digest"])
     T.check_shapes(pl)
     T.check_trees(pl, P=131072, zones=32)
+    T.check_weights_and_gaps(pl, P=131072, N=4096)
     pl.close()
     os.environ["BLANCE_PERIODIC_CUT"] = "1000"
     try:
