@@ -1219,7 +1219,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     bool lean = false;
     if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4 && !cfl[0]) {
         bool walked = false;
-        if (c->periodic && !sharded && !c->no_planes && rr.max_size <= 128 && n_events == 0 && !cfl[6] && !cfl[7]) {
+        if (c->periodic && !sharded && n_events == 0 && !cfl[6] && !cfl[7]) {
             // k_period.h: regions whose records repeat are walked for two periods; the rest of the periodic stretch is
             // copied, what lies behind it is walked -- all decided on the device, region by region
             int max_len = 0;
@@ -1237,11 +1237,16 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                 BLANCE_LAUNCH_NOSYNC(k_period_segments, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
                 ChainParams sq = cq;
                 sq.seg_beg = pb + (size_t)kPBeg1 * B; sq.seg_end = pb + (size_t)kPEnd1 * B;
-                if (launch_chain_planes(sm, sq, rr.max_size)) {
+                // (the plane automaton for regions of up to 128 leaves, the lane-minimum kernel for wider ones)
+                auto walk = [&](const ChainParams& p) {
+                    if (c->no_planes || !launch_chain_planes(sm, p, rr.max_size)) launch_chain_blank(sm, p, rr.max_size);
+                };
+                {
+                    walk(sq);
                     walked = true;
                     HIPTRY(hipMemcpyAsync(c->cnt_p1.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
                     sq.seg_beg = pb + (size_t)kPBeg2 * B; sq.seg_end = pb + (size_t)kPEnd2 * B;
-                    launch_chain_planes(sm, sq, rr.max_size);
+                    walk(sq);
                     BLANCE_LAUNCH_NOSYNC(k_period_state_max, gl * B, 64, 0, sm, B, gl, m, N, NX, cq.reg_lo, cq.reg_hi, cq.leaf_node,
                                          cq.alive, c->cnt_p1.as<int32_t>(), cq.cnt, pb);
                     BLANCE_LAUNCH_NOSYNC(k_period_state_check, gl * B, 64, 0, sm, B, gl, m, N, NX, cq.reg_lo, cq.reg_hi, cq.leaf_node,
@@ -1251,7 +1256,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                     BLANCE_LAUNCH(k_period_counts, B, 256, 0, sm, B, m, N, NX, OW, cq.reg_off, cq.reg_lo, cq.reg_hi, cq.leaf_node,
                                   cq.alive, cq.crec, cq.out, pb, cq.cnt);
                     sq.seg_beg = pb + (size_t)kPBeg3 * B; sq.seg_end = pb + (size_t)kPEnd3 * B;
-                    launch_chain_planes(sm, sq, rr.max_size);
+                    walk(sq);
                     launches += 11;
                     c->periodic_passes++;
                     if (c->trace) {

@@ -85,7 +85,7 @@ struct ChainParams {
     const int32_t* reg_lo;         // [n_regions] leaf interval of the region
     const int32_t* reg_hi;
     const int32_t* reg_off;        // [n_regions + 1] step range of the region in chain order
-    const int32_t* seg_beg;        // k_pass_chain_planes, optional (k_period.h): [n_regions] the launch walks steps
+    const int32_t* seg_beg;        // k_pass_chain_planes / k_pass_chain_blank, optional (k_period.h): [n_regions] the launch walks steps
     const int32_t* seg_end;        // [seg_beg[r], seg_end[r]) of region r's chain instead of all of it
     const int32_t* leaf_node;      // [n_leaves] node id at a leaf position, -1 if none
     const int32_t* leaf_cls;       // [n_leaves] exclude class of the leaf's node inside its region, -1 if none

@@ -801,7 +801,7 @@ __global__ __launch_bounds__(64) void k_pass_chain_blank(ChainParams q) {
     const int lane = threadIdx.x;
     const int rg = q.region_base + blockIdx.x;
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
-    const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
+    const int cbeg = q.seg_beg ? q.seg_beg[rg] : q.reg_off[rg], cend = q.seg_end ? q.seg_end[rg] : q.reg_off[rg + 1];
     if (cbeg >= cend) return;
     const int k = q.k;
     int* nidL = (int*)lds;                           // [size]

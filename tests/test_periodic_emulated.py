@@ -58,6 +58,21 @@ def check_weights_and_gaps(pl, P=8192, N=512):
         assert (got.digest(), got.iterations) == (want.digest(), want.iterations), mode
 
 
+def check_wide_regions(make_planner, P=12288):
+    """Regions of 192 and 256 leaves (k_pass_chain_blank walks the segments), and the same kernel forced on a narrow tree."""
+    from oracle import loader
+    for planes, (rack, rpz, k, zones) in ((True, (16, 12, 2, 2)), (True, (16, 16, 3, 2)), (False, (16, 8, 2, 4)), (False, (12, 8, 2, 4))):
+        pl = make_planner(planes)
+        N = rack * rpz * zones
+        c = synth.config_case(3, P=P, N=N)
+        c["nodeHierarchy"] = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=8)
+        c["model"] = {"primary": {"priority": 0, "constraints": 1}, "replica": {"priority": 1, "constraints": k}}
+        fp = synth.case_to_flat(c)
+        got, want = pl.plan(fp), loader.plan(fp)
+        pl.close()
+        assert (got.digest(), got.iterations) == (want.digest(), want.iterations), (planes, rack, rpz, k)
+
+
 def check_random(pl, seeds):
     from oracle import loader
     for seed in seeds:
@@ -76,6 +91,11 @@ def test_periodic_pass_equals_the_oracle():
     pl = hip.Planner(lib_path=build_emu(), chain_min_parts=1, periodic=True)      # tiny chains, odd trees: mostly the ways out
     check_random(pl, range(7000, 7080))
     pl.close()
+
+
+def test_periodic_pass_on_the_lane_minimum_kernel():
+    from test_simt_emulated import build_emu
+    check_wide_regions(lambda planes: hip.Planner(lib_path=build_emu(), chain_min_parts=8, periodic=True, planes=planes))
 
 
 def test_periodic_stretch_is_taken(capfd):

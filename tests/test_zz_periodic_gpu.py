@@ -40,6 +40,7 @@ def test_periodic_all_blank_pass():
         pl.close()
     finally:
         del os.environ["BLANCE_PERIODIC_CUT"]
+    T.check_wide_regions(lambda planes: hip.Planner(device_id=0, periodic=True, planes=planes), P=131072)
     pl = hip.Planner(device_id=0, chain_min_parts=1, periodic=True)
     T.check_random(pl, range(7000, 7200))
     pl.close()
