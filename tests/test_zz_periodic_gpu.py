@@ -30,8 +30,8 @@ def test_periodic_all_blank_pass():
     got = pl.plan(synth.config_flat(3))
     assert (got.iterations, got.digest()) == (want["iterations"], want["digest"])
     T.check_shapes(pl)
-    T.check_trees(pl, P=131072, zones=32)
-    T.check_weights_and_gaps(pl, P=131072, N=4096)
+    T.check_trees(pl, P=65536, zones=32)
+    T.check_weights_and_gaps(pl, P=65536, N=4096)
     pl.close()
     os.environ["BLANCE_PERIODIC_CUT"] = "1000"
     try:
@@ -40,7 +40,7 @@ def test_periodic_all_blank_pass():
         pl.close()
     finally:
         del os.environ["BLANCE_PERIODIC_CUT"]
-    T.check_wide_regions(lambda planes: hip.Planner(device_id=0, periodic=True, planes=planes), P=131072)
+    T.check_wide_regions(lambda planes: hip.Planner(device_id=0, periodic=True, planes=planes), P=65536)
     pl = hip.Planner(device_id=0, chain_min_parts=1, periodic=True)
     T.check_random(pl, range(7000, 7200))
     pl.close()
