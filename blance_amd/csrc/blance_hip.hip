@@ -20,6 +20,7 @@
 #ifdef BLANCE_SIMT_EMU          /* the emulator build is one translation unit */
 #include "tu_seq.hip"
 #include "tu_tree.hip"
+#include "tu_queue.hip"
 #include "tu_chain.hip"
 #endif
 
@@ -78,7 +79,7 @@ struct blance_ctx {
     std::vector<int64_t> last_stays; // [state] steps the last chain pass of that state committed as verified stays
     bool no_stay_top = false;       // test knob (& 64): never k_stay_by_top
     bool force_stay_top = false;    // test knob (& 128): try k_stay_by_top in every chain pass with NumPartitions > 0
-    bool periodic = false;          // opt-in (& 256, or BLANCE_PERIODIC=1): an all-blank chain pass with periodic records walks two periods (k_period.h)
+    bool periodic = true;           // an all-blank chain pass with periodic records walks two periods (k_period.h); off: & 256, or BLANCE_PERIODIC=0
     int64_t periodic_passes = 0;
     int periodic_cut = 0;           // test knob BLANCE_PERIODIC_CUT (k_period_clamp)
     DevBuf cnt_base, xbuf, gath;    // sharded pass: loads at pass start, [flags | load change], gathered output slices
@@ -102,6 +103,11 @@ struct blance_ctx {
     bool tree_always = false;       // test knob (& 8): k_pass_tree even when a k_pass_seq workgroup size is forced
     bool tree_long = false;         // test knob (& 16): k_pass_tree decodes the record in every general step
     bool no_planes = false;         // test knob (& 32): the all-blank chain pass on k_pass_chain_blank, not k_pass_chain_planes
+    bool no_queue = false;          // test knob (& 512): flat passes with k <= 2 on k_pass_tree, never on k_pass_queue
+    bool queue_general = false;     // test knob (& 1024): k_pass_queue without its lean walk
+    DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
+    bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
+    int64_t queue_launches = 0, queue_stops = 0, queue_moved = 0, queue_exact = 0, queue_rebuilds = 0, queue_dense = 0;
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
         int n_regions = 0, max_size = 0;
@@ -152,7 +158,7 @@ struct blance_ctx {
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
         rule_regions.clear();
         topkey.release(); top_counts.release(); top_off.release(); top_order.release();
-        cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release();
+        cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release(); ntn_bits.release();
         dl_off.release(); dl_nodes.release();
         for (DevBuf& b : mv) b.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &period, &cnt_p1, &n_ev, &chain_oi,
@@ -307,9 +313,12 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->tree_always = opt && (opt->reserved[2] & 8);
     c->tree_long = opt && (opt->reserved[2] & 16);
     c->no_planes = opt && (opt->reserved[2] & 32);
+    c->no_queue = opt && (opt->reserved[2] & 512);
+    c->queue_general = opt && (opt->reserved[2] & 1024);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
-    c->periodic = (opt && (opt->reserved[2] & 256)) || getenv("BLANCE_PERIODIC") != nullptr;
+    c->periodic = !(opt && (opt->reserved[2] & 256));
+    if (const char* pe = getenv("BLANCE_PERIODIC")) c->periodic = atoi(pe) != 0;      // BLANCE_PERIODIC=0: the way out
     if (const char* pc = getenv("BLANCE_PERIODIC_CUT")) c->periodic_cut = atoi(pc);
     c->trace = getenv("BLANCE_TRACE") != nullptr;
     if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
@@ -550,7 +559,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     RESERVE(out, sizeof(int32_t) * ((size_t)P * (1 + kmax) + 1));
     RESERVE(warn_part, sizeof(int32_t) * (size_t)(PM + 1));
     RESERVE(warn_state, sizeof(int32_t) * (size_t)(PM + 1));
-    RESERVE(scalars, 64);
+    RESERVE(scalars, 256);           // [16..17] k_pass_queue's stop words, [18..25] its statistics (long long x 4)
+    RESERVE(ntn_bits, sizeof(uint32_t) * (queue_bits_words(NX) + 4));
     {
         int maxB = 1;
         for (auto& rr : c->rule_regions) if (rr.ok && rr.n_regions > maxB) maxB = rr.n_regions;
@@ -609,7 +619,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
 // A state pass (or a sub-range of one) in order.  Flat passes (no hierarchy rule for the state) of up
 // to kTreeMaxNodes node names: one wave64 with bound-ordered candidates (k_pass_tree.h) -- the cost
 // of a step does not grow with the cluster; everything else: the workgroup pass k_pass_seq.
-static int dispatch_pass(blance_ctx* c, const PassParams& q) {
+static int dispatch_pass_tree_or_seq(blance_ctx* c, const PassParams& q) {
+    c->bits_stale = true;
     const bool tree = !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always);
     if (tree && launch_pass_tree(c->stream, q, (c->tree_dense ? 1 : 0) | (c->tree_long ? 2 : 0))) {
         if (c->trace) fprintf(stderr, "[blance] k_pass_tree state %d steps [%d, %d) k %d\n", q.s, q.beg, q.end, q.k);
@@ -617,6 +628,47 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q) {
     }
     if (launch_pass_seq(c->stream, q, c->force_threads, !c->no_seq_spec && c->engine != BLANCE_ENGINE_SEQUENTIAL))
         return fail(BLANCE_ERR_UNSUPPORTED, "too many nodes for the register-resident pass");
+    return 0;
+}
+
+// Flat passes with k <= 2 first go to k_pass_queue (k_pass_queue.h: the candidates as a sorted window over the lanes of
+// one wave64).  It stops at a step it does not take (q.stop); k_pass_tree / k_pass_seq then do a few steps -- more after
+// every stop that comes soon after the last one -- and the queue kernel takes over again.
+static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
+    const bool queue = !c->no_queue && !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always) &&
+                       !c->tree_dense && !c->tree_long && q0.k <= 2 && q0.rule_begin >= q0.rule_end && q0.NX >= 1 && q0.NX <= 4096;
+    if (!queue) return dispatch_pass_tree_or_seq(c, q0);
+    PassParams q = q0;
+    int32_t* scal = c->scalars.as<int32_t>();
+    q.ntn_bits = c->ntn_bits.as<uint32_t>();
+    q.stop = scal + 16;
+    q.qstats = (long long*)(scal + 18);
+    q.spec = c->queue_general ? 8 : 0;
+    int pos = q0.beg, chunk = 64;
+    while (pos < q0.end) {
+        q.beg = pos; q.end = q0.end;
+        if (q.NP > 0 && c->bits_stale) {
+            const long long words = (long long)queue_bits_words(q.NX);
+            BLANCE_LAUNCH_NOSYNC(k_ntn_bits, cdiv(words, 256), 256, 0, c->stream, q.N, q.NX + 1, (int)(words / (q.NX + 1)), q.ntn, q.ntn_bits);
+            c->bits_stale = false;
+        }
+        if (!launch_pass_queue(c->stream, q)) { q.beg = pos; return dispatch_pass_tree_or_seq(c, q); }
+        int32_t st[2] = {0, 0};
+        HIPTRY(hipMemcpyAsync(st, scal + 16, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipStreamSynchronize(c->stream));
+        c->queue_launches++;
+        if (c->trace) fprintf(stderr, "[blance] k_pass_queue state %d steps [%d, %d) k %d: stopped at %d (%d)\n", q.s, pos, q0.end, q.k, st[0], st[1]);
+        if (st[0] < pos || st[0] > q0.end) return fail(BLANCE_ERR_DEVICE, "k_pass_queue returned a position outside its range");
+        if (st[0] >= q0.end) break;
+        c->queue_stops++;
+        chunk = st[0] - pos < 4096 ? (chunk < 65536 ? chunk * 2 : chunk) : 64;
+        PassParams t = q0;
+        t.beg = st[0];
+        t.end = q0.end - st[0] < chunk ? q0.end : st[0] + chunk;
+        const int e = dispatch_pass_tree_or_seq(c, t);
+        if (e) return e;
+        pos = t.end;
+    }
     return 0;
 }
 
@@ -679,6 +731,7 @@ static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size);
 static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool lds_rows, int32_t* scal,
                           int64_t* launches) {
     hipStream_t sm = c->stream;
+    c->bits_stale = true;
     ChainParams cq;
     memset(&cq, 0, sizeof cq);
     cq.N = q.N; cq.NX = q.NX; cq.M = q.M; cq.L = q.L; cq.s = q.s; cq.k = q.k; cq.NP = q.NP; cq.OW = q.OW;
@@ -721,6 +774,7 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
 static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
                          bool chain_ok) {
     hipStream_t sm = c->stream;
+    c->bits_stale = true;                           // (the bulk kernels below bump nodeToNodeCounts, not k_pass_queue's bit maps)
     const int P = q.P;
     FlatParams fq;
     memset(&fq, 0, sizeof fq);
@@ -742,6 +796,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     int pos = 0, seq_batch = 256;
     bool dirty = true;
     while (pos < P) {
+        c->bits_stale = true;                       // (conservative: a bulk commit may have run since the last k_pass_queue)
         if (dirty) {
             BLANCE_LAUNCH(k_flat_prepare, 1, 1024, sizeof(RedSlot) * 32 + 64, sm, fq, c->f_tot.as<int32_t>(),
                           c->f_g.as<double>(), c->f_top_g.as<double>(), c->f_top_n.as<int32_t>());
@@ -1379,9 +1434,10 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
 
     DevProblem d = dev_problem(c);
     c->last_stays.assign((size_t)(M > 0 ? M : 1), 0);
+    c->queue_launches = c->queue_stops = 0;
 
     HIPTRY(hipEventRecord(c->ev0, sm));
-    HIPTRY(hipMemsetAsync(scal, 0, 64, sm));
+    HIPTRY(hipMemsetAsync(scal, 0, 256, sm));
     if (P > 0) {
         BLANCE_LAUNCH_NOSYNC(k_flags_init, cdiv(P, 256), 256, 0, sm, P, c->part_in_prev.as<uint8_t>(), c->part_never_equal.as<uint8_t>(),
                              d.in_prev, d.never_equal);
@@ -1434,8 +1490,11 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 // static order itself
                 HIPTRY(hipMemcpyAsync(c->order.p, c->part_order.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToDevice, sm));
             }
-            if (NP > 0)                                             // nodeToNodeCounts := fresh, plan.go:266
+            if (NP > 0) {                                           // nodeToNodeCounts := fresh, plan.go:266
                 HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
+                HIPTRY(hipMemsetAsync(c->ntn_bits.p, 0, sizeof(uint32_t) * queue_bits_words(NX), sm));
+                c->bits_stale = false;
+            }
             const int OW = 1 + k;
             int higher_mask = 0;
             for (int t = 0; t < M; t++)
@@ -1555,6 +1614,12 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         HIPTRY(hipMemcpyAsync(&spec, scal + 12, sizeof spec, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipEventSynchronize(c->ev1));
         HIPTRY(hipStreamSynchronize(sm));
+        long long qs[4] = {0, 0, 0, 0};
+        HIPTRY(hipMemcpy(qs, scal + 18, sizeof qs, hipMemcpyDeviceToHost));
+        c->queue_moved = qs[0]; c->queue_exact = qs[1]; c->queue_rebuilds = qs[2]; c->queue_dense = qs[3];
+        if (c->trace || getenv("BLANCE_QUEUE_STATS"))
+            fprintf(stderr, "[blance] k_pass_queue: %lld launches, %lld stops, %lld moving steps (%lld with matrix reads, %lld scoring every node), %lld window rebuilds\n",
+                    (long long)c->queue_launches, (long long)c->queue_stops, qs[0], qs[1], qs[3], qs[2]);
         batched += spec;
         if (batched > steps) batched = steps;     // the flat chain counts its whole pass already
         if (c->trace) fprintf(stderr, "[blance] sequential passes: %lld verified stays\n", spec);

@@ -48,6 +48,10 @@ struct PassParams {
     int32_t* err;                  // device error word (interval overflow ...)
     int32_t spec;                  // try verified-stay speculation (flat passes; LDS mirrors sized by the host)
     long long* spec_count;         // steps committed as verified stays (statistics, may be null)
+    // k_pass_queue (k_pass_queue.h) only:
+    uint32_t* ntn_bits;            // [(NX + 1) * BW] one bit per nodeToNodeCounts entry: "is not zero" (BW = words per row, 16-byte rows)
+    int32_t* stop;                 // out: [0] first step of [beg, end) NOT done (end: all done), [1] why (kQStop*)
+    long long* qstats;             // out, may be null: [0] moving steps, [1] with matrix reads, [2] window rebuilds, [3] dense steps
 };
 
 // Parameters of a state pass run as independent per-region chains (DESIGN.md

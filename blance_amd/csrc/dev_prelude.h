@@ -33,6 +33,9 @@ namespace blance {
 int launch_pass_seq(hipStream_t stream, PassParams q, int force_threads, bool allow_spec);
 // k_pass_tree (tu_tree.hip): false when the pass is outside its envelope (nothing launched)
 bool launch_pass_tree(hipStream_t stream, PassParams q, int knobs);
+// k_pass_queue (tu_queue.hip): flat passes with k <= 2 on one wave64, candidates as a sorted window; false: outside its envelope
+bool launch_pass_queue(hipStream_t stream, PassParams q);
+size_t queue_bits_words(int NX);   // words of PassParams::ntn_bits for a cluster of NX node names
 // k_pass_chain (tu_chain.hip): one wave64 per region; false when the shape has no variant
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
 // k_pass_chain_blank (tu_chain.hip): the lean first-sweep kernel

@@ -1,0 +1,939 @@
+// k_pass_queue: the exact sequential state pass of a state WITHOUT hierarchy rules on one wave64, the
+// candidates kept as a SORTED WINDOW across the lanes (a systolic priority queue) -- new in round 4.
+// Part of tu_queue.hip; see DESIGN.md section 4.3a.
+#pragma once
+
+namespace blance {
+
+// ============================================================================
+// assignStateToPartitions (plan.go:253-303) with findBestNodes (plan.go:98-248) for a state that has no
+// hierarchy rule and k <= 2.  Same facts as k_pass_tree.h: a node n that is not one
+// of the partition's own has exact score (plan.go:634-689) >= g[n], its partition-independent score, with
+// equality bit for bit when the partition's nodeToNodeCounts entry is 0; a step changes g of at most
+// (old + chosen) nodes.  What differs is the structure that orders the candidates:
+//
+//  * The WINDOW: lane i holds the i-th smallest (g, node) over all nodes -- the <= 64 nodes below a bound
+//    THETA, sorted.  Invariant: the window holds exactly the nodes whose (g, node) is below THETA.  A node
+//    whose g changed is removed (lanes above it move down one: one DPP wave shift per register) and, if
+//    its new key is below THETA, inserted at its place (lanes at and above move up one); a 65th entry is
+//    dropped and becomes THETA.  The smallest candidate is lane 0, no reduction over the wave -- k_pass_tree
+//    paid three to four wave minima (two DPP chains each) and a group rescan per moving step.  On BASELINE
+//    config 5 the window never runs dry (simulated on the oracle's trajectory: 0 rebuilds per pass after
+//    the first sweep; a taken node rises above THETA, a released node comes in below it).
+//  * ROW BIT MAPS: "is nodeToNodeCounts[row][n] zero" for the 64 rows of a batch sits in LDS (ntn_bits:
+//    one bit per matrix entry, maintained next to the matrix), so a candidate whose bit is clear has its
+//    exact score = its window key without touching the matrix -- k_pass_tree waited ~1 us for an entry
+//    in half of its moving steps.  Only candidates with the bit set, in front of the k-th clean one, are
+//    read from the matrix and scored exactly.
+//  * A step that keeps its nodes is validated by its lane against the front of the window, as in
+//    k_pass_tree; every other step resolves as: k best of (own nodes with their exact scores, the first
+//    eligible window entries), valid if all of them lie below THETA -- otherwise the window is rebuilt
+//    (from the g keys kept in LDS) and the step repeated.
+//
+// What the kernel does not do it does not guess: a step that needs the general machinery of k_pass_tree
+// (a node held in two lists, promotions / demotions, more higher-priority nodes than it keeps, fewer
+// candidates than constraints) STOPS the
+// launch there -- everything before it is committed, q.stop[0] says where -- and the host lets
+// k_pass_tree do a few steps before it relaunches this kernel.
+// ============================================================================
+constexpr int kQueueMaxNodes = 4096;
+constexpr int kQStopNone = 0, kQStopShape = 1, kQStopShort = 3, kQStopPromote = 4;
+
+#ifndef BLANCE_SIMT_EMU
+#define BLANCE_QLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define BLANCE_QFENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent")
+#else
+#define BLANCE_QLD(p) (*(p))
+#define BLANCE_QFENCE()
+#endif
+
+// lane i takes lane i - 1's value (lane 0: fill) / lane i + 1's value (lane 63: fill): DPP wave shifts
+__device__ __forceinline__ int wave_from_prev(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);       // wave_shr:1
+}
+__device__ __forceinline__ int wave_from_next(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);       // wave_shl:1
+}
+
+__device__ __forceinline__ bool qless(unsigned long long a, int an, unsigned long long b, int bn) {
+    return a < b || (a == b && an < bn);              // nodeSorter.Less on sortable images, plan.go:617-628
+}
+
+// nodeSorter.Score (plan.go:634-689): the reference's operations in the reference's order; the two NumPartitions
+// quotients from LDS tables filled by the same expressions, the division by a power-of-two weight as an exponent shift
+__device__ __forceinline__ double queue_score(int cnt, int nt, int tot, int hasw, int w, int NP, double cf,
+                                              int booster, const double* lpT, const double* ffT) {
+    double r = (double)cnt;                           // plan.go:664-670
+    if (NP > 0) {
+        const double lp = (unsigned)nt < (unsigned)kLpTab ? lpT[nt] : (double)nt / (double)NP;      // :638-644
+        const double ff = (unsigned)tot < (unsigned)kFfTab ? ffT[tot] : (0.001 * (double)tot) / (double)NP;   // :647-652
+        r = r + lp;
+        r = r + ff;
+    }
+    if (hasw) {                                       // plan.go:675-684
+        if (w > 0) {
+            if ((w & (w - 1)) == 0) r = ldexp(r, -__builtin_ctz((unsigned)w));
+            else r = r / (double)w;
+        } else if (w < 0 && booster == BLANCE_BOOSTER_CBGT) {
+            double b = (double)(-w);                  // control_test.go:19-26
+            if (b < cf) b = cf;
+            r = r + b;
+        }
+    }
+    r = r - cf;                                       // plan.go:686
+    return r;
+}
+
+// the compiler's divergence analysis gives up on values carried around the step loop: say that they are wave uniform
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+
+struct QMin { unsigned hi, lo; int node; };
+
+// minimum of (key, node) over the wave (lanes that pass ~0 / INT_MAX never win): three v_min_u32 DPP chains
+__device__ __forceinline__ QMin wave_min_key_node(unsigned long long key, int node) {
+    QMin r;
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    r.hi = wave_min_u32_bcast(hi);
+    const bool a = hi == r.hi;
+    r.lo = wave_min_u32_bcast(a ? lo : kKeyNoneV);
+    const bool b = a && lo == r.lo;
+    r.node = (int)wave_min_u32_bcast(b ? (unsigned)node : 0x7fffffffu);
+    return r;
+}
+
+template <int KM>
+__global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
+    static_assert(KM == 2, "k <= 2");
+    typedef unsigned long long u64;
+    constexpr int KH = 2;                            // higher priority nodes a step may carry
+    BLANCE_DYN_LDS(lds);
+    const int lane = threadIdx.x;
+    const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k, RW = q.RW;
+    const int SW = 1 + L;
+    const int G = (NX + 63) >> 6, NXp = G << 6, BW = ((NXp >> 5) + 3) & ~3;     // words per row bit map (16-byte rows)
+    const int OWs = q.OW;
+
+    u64* gB = (u64*)lds;                             // [NXp] sortable image of g; ~0: no candidate
+    int* cntL = (int*)(gB + NXp);                    // [NXp] stateNodeCounts[s]
+    int* totL = cntL + NXp;                          // [NXp] nodePartitionCounts (plan.go:118-124)
+    int* wL = totL + NXp;                            // [NXp] node weights
+    double* lpT = (double*)(wL + NXp);               // [kLpTab] c / NP
+    double* ffT = lpT + kLpTab;                      // [kFfTab] (0.001 * t) / NP
+    int* recS = (int*)(ffT + kFfTab);                // [64 * RW] step records of the batch
+    int* outS = recS + 64 * RW;                      // [64 * (KM + 1)] the batch's outputs
+    unsigned* bitsL = (unsigned*)(outS + 64 * (KM + 1));   // [64 * BW] row bit maps of the batch's steps
+    unsigned char* flL = (unsigned char*)(bitsL + 64 * BW);       // [NXp] 1: in nodesNext, 2: has a weight
+    unsigned char* rowTag = flL + NXp;               // [NXp + 64] a lane of the batch with this row (any of them)
+    unsigned char* shL = rowTag + NXp + 64;          // [NXp] e when the node's score is divided by 2^e (no weight, weight 0: e = 0)
+    unsigned short* ntL = (unsigned short*)(shL + NXp);      // [NXp] folded mode: row "" of nodeToNodeCounts
+
+    for (int i = lane; i < kLpTab; i += 64) lpT[i] = NP > 0 ? (double)i / (double)NP : 0.0;
+    for (int i = lane; i < kFfTab; i += 64) ffT[i] = NP > 0 ? (0.001 * (double)i) / (double)NP : 0.0;
+    BLANCE_WAVE_SYNC();
+    // Folded mode (as in k_pass_tree): while every step of a batch is a partition that holds nothing in this state and has
+    // no top priority node -- the steps all read and bump row "" of nodeToNodeCounts (plan.go:134-138, :238-245) -- that
+    // row lives in LDS and is part of the window keys: a candidate's exact score is its key, the matrix is not read.
+    bool fold = false;
+    auto gkey = [&](int n) -> u64 {
+        return (flL[n] & 1) ? sortable_bits(queue_score(cntL[n], fold ? (int)ntL[n] : 0, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                        q.booster_kind, lpT, ffT)) : ~0ull;
+    };
+    bool odd_weight = false;
+    for (int i = 0; i < G; i++) {
+        const int n = i * 64 + lane;
+        int c = 0, t = 0, w = 0, fl = 0;
+        if (n < NX) {
+            c = q.cnt[s * NX + n];
+            for (int tt = 0; tt <= M; tt++) t += q.cnt[tt * NX + n];
+            w = q.node_weight[n];
+            fl = ((n < N && q.alive[n]) ? 1 : 0) | (q.node_has_weight[n] ? 2 : 0);
+        }
+        cntL[n] = c; totL[n] = t; wL[n] = w; flL[n] = (unsigned char)fl;
+        // the lean walk divides by a power of two only (plan.go:675-684; node weights 1 / 2 / 4 ... and none at all)
+        int sh = 0;
+        if ((fl & 2) && w > 0) sh = (w & (w - 1)) == 0 ? __builtin_ctz((unsigned)w) : 255;
+        if ((fl & 2) && w < 0 && q.booster_kind != BLANCE_BOOSTER_NONE) sh = 255;
+        shL[n] = (unsigned char)sh;
+        if ((fl & 1) && sh == 255) odd_weight = true;
+    }
+    const bool lean_ok = __ballot(odd_weight) == 0 && !(q.spec & 8);      // (q.spec & 8: test knob, every step through the general code)
+    BLANCE_WAVE_SYNC();
+    for (int i = 0; i < G; i++) gB[i * 64 + lane] = gkey(i * 64 + lane);
+    BLANCE_WAVE_SYNC();
+
+    // ---- the window: lane i = the i-th smallest (g, node); lanes >= wcnt hold (~0, INT_MAX)
+    u64 wk = ~0ull;
+    int wn = INT_MAX;
+    int wcnt = 0;
+    u64 thK = ~0ull;                                 // THETA: every node outside the window has (g, node) >= it
+    int thN = INT_MAX;
+    long long n_rebuild = 0;
+    auto rebuild = [&]() {
+        // 64 + 1 successive minima of the keys in LDS; lane l owns nodes l, 64 + l, ... (bit i of `taken`: node 64 i + l)
+        // and keeps its two smallest untaken keys, so that a column is scanned again only when both are gone
+        u64 taken = 0;
+        wk = ~0ull; wn = INT_MAX; wcnt = 0; thK = ~0ull; thN = INT_MAX;
+        u64 a1 = ~0ull, a2 = ~0ull;
+        int m1 = INT_MAX, m2 = INT_MAX;
+        bool exhausted = false;
+        auto scan2 = [&]() {
+            a1 = ~0ull; a2 = ~0ull; m1 = INT_MAX; m2 = INT_MAX;
+            for (int i = 0; i < G; i++) {
+                const u64 v = gB[i * 64 + lane];
+                if ((taken >> i) & 1) continue;
+                if (v < a1) { a2 = a1; m2 = m1; a1 = v; m1 = i * 64 + lane; }      // ascending i: ties keep the lower node
+                else if (v < a2) { a2 = v; m2 = i * 64 + lane; }
+            }
+            if (m1 == INT_MAX) exhausted = true;
+        };
+        scan2();
+        for (int e = 0; e <= 64; e++) {
+            const QMin m = wave_min_key_node(a1, m1);
+            if (m.node == INT_MAX) break;            // fewer than 65 candidates: THETA stays infinite
+            const u64 mk = ((u64)m.hi << 32) | m.lo;
+            if (e < 64) {
+                if (lane == e) { wk = mk; wn = m.node; }
+                wcnt = uni(e + 1);
+            } else { thK = uni64(mk); thN = uni(m.node); }
+            if (m1 == m.node) { taken |= 1ull << (m.node >> 6); a1 = a2; m1 = m2; a2 = ~0ull; m2 = INT_MAX; }
+            const bool dry = m1 == INT_MAX && !exhausted;
+            if (__ballot(dry)) { if (dry) scan2(); }
+        }
+        n_rebuild++;
+    };
+    rebuild();
+    // remove node x from the window if it is there; insert (key, x) if below THETA
+    auto win_remove = [&](int x) {
+        const u64 hit = __ballot(wn == x);
+        if (hit) {
+            const int r = __ffsll((long long)hit) - 1;
+            const int nh = wave_from_next((int)(unsigned)(wk >> 32), (int)kKeyNoneV);
+            const int nl = wave_from_next((int)(unsigned)wk, (int)kKeyNoneV);
+            const int nn = wave_from_next(wn, INT_MAX);
+            if (lane >= r) { wk = ((u64)(unsigned)nh << 32) | (unsigned)nl; wn = nn; }
+            wcnt = uni(wcnt - 1);
+        }
+    };
+    auto win_insert = [&](u64 key, int x) {
+        if (!qless(key, x, thK, thN)) return;        // stays outside: still >= THETA
+        const u64 before = __ballot(lane < wcnt && qless(wk, wn, key, x));      // sorted: a prefix of the lanes
+        const int p = __popcll(before);
+        if (p >= 64) { thK = uni64(key); thN = uni(x); return; }   // full, and behind every entry: it is the bound now
+        if (wcnt == 64) {                            // the largest entry falls off and becomes THETA
+            const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), 63);
+            const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, 63);
+            thK = ((u64)h << 32) | l;
+            thN = __builtin_amdgcn_readlane(wn, 63);
+            wcnt = uni(wcnt - 1);
+        }
+        const int ph = wave_from_prev((int)(unsigned)(wk >> 32), (int)kKeyNoneV);
+        const int pl = wave_from_prev((int)(unsigned)wk, (int)kKeyNoneV);
+        const int pn = wave_from_prev(wn, INT_MAX);
+        if (lane > p) { wk = ((u64)(unsigned)ph << 32) | (unsigned)pl; wn = pn; }
+        if (lane == p) { wk = key; wn = x; }
+        wcnt = uni(wcnt + 1);
+    };
+
+    PH_DECL;
+    long long n_bulk = 0, n_moved = 0, n_exact = 0, n_dense = 0, n_bound = 0;
+    int stop_pos = q.end, stop_why = kQStopNone;
+
+    PH(11);
+    for (int oi = q.beg; ; oi += 64) {
+        oi = uni(oi); wcnt = uni(wcnt); stop_why = uni(stop_why);
+        if (oi >= q.end || stop_why != kQStopNone) break;
+        const int B = q.end - oi < 64 ? q.end - oi : 64;
+        BLANCE_QFENCE();                             // earlier bumps of nodeToNodeCounts / its bit maps are visible below
+        for (int r = 0; r < RW; r++) {
+            const int idx = r * 64 + lane;
+            if (idx < B * RW) recS[idx] = q.rec[(size_t)oi * RW + idx];
+        }
+        BLANCE_WAVE_SYNC();
+
+        PH(0);
+        // ---- lane j looks at step oi + j
+        const bool act = lane < B;
+        const int* rj = recS + (act ? lane : 0) * RW;
+        int row = NX;
+        const int wj = rj[1];
+        int ownv[KM], ntn_own[KM], hv[KH];
+        u64 oK[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) { ownv[j] = -1; ntn_own[j] = 0; oK[j] = ~0ull; }
+#pragma unroll
+        for (int j = 0; j < KH; j++) hv[j] = -1;
+        const double vstick = __hiloint2double(rj[3], rj[2]);
+        int nown = 0;
+        // simple: at most k own nodes, all candidates, held once and in no other list; at most KH higher priority
+        // nodes; no node in a lower priority list that could be promoted is ... (checked when it is taken)
+        bool simple = act;
+        bool has_other = false;                      // the partition holds nodes in lower priority states
+        int ov0 = -1, ov1 = -1, n_o = 0;             // ... the first two of them (a taken one would be promoted: not the lean walk's business)
+        {
+            const int hT = rj[kRecHead + q.top_state * SW];
+            if ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) row = rj[kRecHead + q.top_state * SW + 1];   // plan.go:134-138
+            const int hs = rj[kRecHead + s * SW];
+            nown = (hs >> 16) == kListAbsent ? 0 : (hs & 0xffff);
+            if (nown > k) { simple = false; nown = 0; }
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                if (j < nown) {
+                    const int o = rj[kRecHead + s * SW + 1 + j];
+                    ownv[j] = o;
+                    if (o >= N || !(flL[o < NXp ? o : 0] & 1)) simple = false;
+#pragma unroll
+                    for (int jj = 0; jj < KM; jj++) if (jj < j && ownv[jj] == o) simple = false;
+                }
+            }
+            int n_h = 0;
+            for (int t = 0; t < M; t++) {
+                if (t == s) continue;
+                const int h = rj[kRecHead + t * SW];
+                if ((h >> 16) == kListAbsent) continue;
+                const bool higher = (q.higher_mask >> t) & 1;
+                for (int jj = 0; jj < (h & 0xffff); jj++) {
+                    const int x = rj[kRecHead + t * SW + 1 + jj];
+#pragma unroll
+                    for (int j = 0; j < KM; j++) if (ownv[j] == x) simple = false;   // excluded or demoted: not a plain step
+                    if (higher) {
+                        if (n_h >= KH) simple = false;
+#pragma unroll
+                        for (int e = 0; e < KH; e++) if (e == n_h) hv[e] = x;
+                        n_h++;
+                    } else {
+                        has_other = true;
+                        if (n_o == 0) ov0 = x;
+                        if (n_o == 1) ov1 = x;
+                        n_o++;
+                    }
+                }
+            }
+            if (!simple) {
+                nown = 0;
+#pragma unroll
+                for (int j = 0; j < KM; j++) ownv[j] = -1;
+            }
+        }
+        PH(1);
+        // ---- folded mode on / off
+        {
+            const bool want = NP > 0 && lean_ok && __ballot(act && !(simple && row == NX && nown == 0 && n_o <= 2 && hv[1] < 0)) == 0;
+            if (want != fold) {
+                bool can = true;
+                if (want) {                          // row "" into LDS (16-bit entries; a larger one: no folding)
+                    bool big = false;
+                    for (int i = 0; i < G; i++) {
+                        const int n = i * 64 + lane;
+                        const int v = n < N ? BLANCE_QLD(q.ntn + (size_t)NX * N + n) : 0;
+                        if (v >= 60000) big = true;
+                        ntL[n] = (unsigned short)(v < 60000 ? v : 0);
+                    }
+                    can = __ballot(big) == 0;
+                }
+                if (can) {
+                    fold = want;
+                    BLANCE_WAVE_SYNC();
+                    for (int i = 0; i < G; i++) gB[i * 64 + lane] = gkey(i * 64 + lane);
+                    BLANCE_WAVE_SYNC();
+                    rebuild();
+                }
+            }
+        }
+        // ---- the row bit maps of the batch's steps: lanes 0..31 / 32..63 copy one 4 BW-byte row each per round
+        // (plain 16-byte loads: the fence above invalidated this CU's L1, and nothing bumps the maps before the batch ends)
+        if (NP > 0 && !fold) {
+            const int BQ = BW >> 2;
+            if (BQ <= 32) {
+                // (8 rounds' loads in flight at once: one round trip to the L2 per 16 rows, not per 2)
+                for (int r8 = 0; r8 < B; r8 += 16) {
+                    int4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int r2 = r8 + 2 * u;
+                        const int ra = r2 < 64 ? r2 : 63, rb = r2 + 1 < 64 ? r2 + 1 : 63;
+                        const int row_r = __builtin_amdgcn_readlane(row, ra), row_r1 = __builtin_amdgcn_readlane(row, rb);
+                        const int myrow = (lane >> 5) ? row_r1 : row_r;
+                        const int c = lane & 31;
+                        v[u] = (r2 + (lane >> 5) < B && c < BQ) ? ((const int4*)q.ntn_bits)[(size_t)myrow * BQ + c] : int4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int rr = r8 + 2 * u + (lane >> 5), c = lane & 31;
+                        if (rr < B && c < BQ) ((int4*)bitsL)[rr * BQ + c] = v[u];
+                    }
+                }
+            } else {
+                for (int r2 = 0; r2 < B; r2 += 2) {
+                    const int rr = r2 + (lane >> 5);
+                    const int row_r = __builtin_amdgcn_readlane(row, r2), row_r1 = __builtin_amdgcn_readlane(row, r2 + 1 < 64 ? r2 + 1 : r2);
+                    const int myrow = (lane >> 5) ? row_r1 : row_r;
+                    for (int c = (lane & 31); c < BQ; c += 32)
+                        if (rr < B) ((int4*)bitsL)[rr * BQ + c] = ((const int4*)q.ntn_bits)[(size_t)myrow * BQ + c];
+                }
+            }
+        }
+        PH(2);
+        // an earlier step of the batch with my row bumps entries I read: "dirty" (re-read at my turn)
+        // (one of the lanes that share a row wins the tag; all the others -- and, conservatively, possibly the first of
+        // them -- re-read at their turn)
+        bool dirty = false;
+        if (NP > 0 && act) rowTag[row] = (unsigned char)lane;
+        BLANCE_WAVE_SYNC();
+        if (NP > 0 && act) dirty = rowTag[row] != (unsigned char)lane;
+        {   // the lane that won may be the LAST of its row: it is dirty too unless it is the first -- decide by a second round
+            const u64 losers = __ballot(dirty);
+            BLANCE_WAVE_SYNC();
+            if (NP > 0 && act && dirty) rowTag[row] = 64;          // mark rows that more than one lane has
+            BLANCE_WAVE_SYNC();
+            if (NP > 0 && act && !dirty && rowTag[row] == 64) dirty = true;
+            (void)losers;
+        }
+        if (fold) dirty = false;                     // (the shared row is in LDS, kept exactly by the walk itself)
+        BLANCE_WAVE_SYNC();
+        if (NP > 0) {
+#pragma unroll
+            for (int j = 0; j < KM; j++)
+                if (simple && j < nown) ntn_own[j] = BLANCE_QLD(q.ntn + (size_t)row * N + ownv[j]);
+        }
+        // exact keys of the own nodes, sorted: what a stay emits (keeping the same nodes in another order changes no counter)
+        u64 lastK = 0;
+        int lastN = -1;
+        int sortv[KM];
+        u64 sKv[KM];                                 // the own nodes' exact keys in the order of sortv
+#pragma unroll
+        for (int j = 0; j < KM; j++) { sortv[j] = -1; sKv[j] = ~0ull; }
+        bool sfail = true;
+        auto own_keys = [&]() {
+#pragma unroll
+            for (int j = 0; j < KM; j++) { sortv[j] = -1; oK[j] = ~0ull; }
+            u64 sK[KM];
+#pragma unroll
+            for (int j = 0; j < KM; j++) sK[j] = ~0ull;
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                if (j < nown) {
+                    const int o = ownv[j];
+                    const u64 b = sortable_bits(queue_score(cntL[o], ntn_own[j], totL[o], (flL[o] >> 1) & 1, wL[o], NP,
+                                                            vstick, q.booster_kind, lpT, ffT));
+                    oK[j] = b;
+                    u64 cb = b;
+                    int cn = o;
+#pragma unroll
+                    for (int e = 0; e < KM; e++) {
+                        if (e <= j) {
+                            const bool first = e == j || qless(cb, cn, sK[e], sortv[e]);
+                            if (first) {
+                                const u64 tb = sK[e]; const int tn = sortv[e];
+                                sK[e] = cb; sortv[e] = cn;
+                                cb = tb; cn = tn;
+                            }
+                        }
+                    }
+                }
+            }
+            lastK = 0; lastN = -1;
+#pragma unroll
+            for (int j = 0; j < KM; j++) { if (j == k - 1) { lastK = sK[j]; lastN = sortv[j]; } sKv[j] = sK[j]; }
+            sfail = !simple || nown != k;            // fewer nodes than constraints: never a stay
+        };
+        if (simple) own_keys();
+        // what a stay emits sits in outS from the start (plan.go:299-301 leaves everything as it is); a step that moves
+        // overwrites its slot
+        auto emit_stay = [&]() {
+            int* o = outS + lane * OWs;
+            o[0] = k;
+#pragma unroll
+            for (int j = 0; j < KM; j++) if (j < k) o[1 + j] = sortv[j];
+        };
+        if (act && !sfail) emit_stay();
+        u64 stalemask = 0;                           // lanes whose own nodes' counters an earlier step of the batch changed
+        BLANCE_WAVE_SYNC();
+
+        PH(3);
+        int bumped_upto = 0;                         // steps [0, bumped_upto) of the batch have their rows bumped
+        auto flush_bumps = [&](int upto) {
+            if (NP > 0 && lane >= bumped_upto && lane < upto) {
+                const int n = outS[lane * OWs] & 0xffff;
+                for (int j = 0; j < n; j++) {
+                    const int x = outS[lane * OWs + 1 + j];
+                    if (x >= 0 && x < N) {
+                        atomicAdd(q.ntn + (size_t)row * N + x, 1);
+                        atomicOr((int*)q.ntn_bits + (size_t)row * BW + (x >> 5), (int)(1u << (x & 31)));
+                    }
+                }
+            }
+            bumped_upto = upto > bumped_upto ? upto : bumped_upto;
+        };
+
+        int cur = 0;
+        // lanes that can only be resolved by the general code when they do not stay
+        const u64 slowmask = __ballot(!simple || dirty || n_o > 2 || hv[1] >= 0) | (lean_ok ? 0ull : ~0ull);
+        const u64 actmask = B >= 64 ? ~0ull : ((1ull << B) - 1);
+        const u64 sfailmask = __ballot(sfail), dirtymask = __ballot(dirty);
+        const int own_a = sortv[0], own_b = sortv[1];
+        for (;;) {
+            cur = uni(cur); wcnt = uni(wcnt); thK = uni64(thK); thN = uni(thN); stalemask = uni64(stalemask);
+            if (cur >= B) break;
+#ifdef BLANCE_QDEBUG3
+            if (lane == 0) printf("[q3] outer cur %d B %d wcnt %d\n", cur, B, wcnt);
+#endif
+            int f = B;
+            bool retried = false;
+            // ================= the lean walk: steps in order as long as they stay or move the plain way =================
+            // (a step whose two best candidates are the first eligible entries of the window, none of them with a
+            // nodeToNodeCounts entry, all nodes' weights powers of two: one pass of straight-line code per step)
+            for (;;) {
+                cur = uni(cur); wcnt = uni(wcnt); thK = uni64(thK); thN = uni(thN); stalemask = uni64(stalemask);
+                if (cur >= B) { f = B; break; }
+                u64 frontK = thK;
+                int frontN = thN;
+                if (wcnt > 0) {
+                    frontK = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), 0) << 32) |
+                             (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, 0);
+                    frontN = __builtin_amdgcn_readlane(wn, 0);
+                }
+                const u64 fm = (__ballot(!qless(lastK, lastN, frontK, frontN)) | sfailmask | dirtymask | stalemask) & actmask & (~0ull << cur);
+                f = uni(fm ? __ffsll((long long)fm) - 1 : B);
+#ifdef BLANCE_QDEBUG3
+                if (lane == 0) printf("[q3]  lean cur %d f %d fm %llx slow %llx stale %llx\n", cur, f, fm, slowmask, stalemask);
+#endif
+                n_bulk += f - cur;
+                if (f >= B) break;
+                if (((slowmask | stalemask) >> f) & 1) break;
+                const int w = __builtin_amdgcn_readlane(wj, f);
+                const int oa = __builtin_amdgcn_readlane(own_a, f), ob = __builtin_amdgcn_readlane(own_b, f);   // -1: none
+                const int hh = __builtin_amdgcn_readlane(hv[0], f);
+                const u64 ka = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(sKv[0] >> 32), f) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)sKv[0], f);
+                const u64 kb = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(sKv[1] >> 32), f) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)sKv[1], f);
+                const int na = oa < 0 ? INT_MAX : oa, nb = ob < 0 ? INT_MAX : ob;
+                bool lean_done = true;
+                u64 t1 = ~0ull, t2 = ~0ull;
+                int n1 = INT_MAX, n2 = INT_MAX;
+                {
+                    const bool elig = lane < wcnt && wn != oa && wn != ob && wn != hh;
+                    const bool bit = NP > 0 && !fold && elig && ((bitsL[f * BW + (wn >> 5)] >> (wn & 31)) & 1) != 0;
+                    const u64 em = __ballot(elig), dm = __ballot(bit);
+                    u64 cm = em & ~dm;
+                    u64 ck = k == 2 ? (cm & (cm - 1)) : cm;
+                    if (ck == 0) lean_done = false;                   // fewer than k clean candidates in the window
+                    else {
+                        const int cutoff = __ffsll((long long)ck) - 1;
+                        const u64 upto = cutoff >= 63 ? ~0ull : ((2ull << cutoff) - 1);
+                        const u64 dl = dm & upto;
+                        if (dl) {
+                            // entries with their bit set in front of the k-th clean one: scored with an entry of 1 -- a lower
+                            // bound of their exact score (plan.go:638-644 is monotone in the entry) -- they are out of the
+                            // race if even that lies above the k-th clean candidate; else the matrix has to be read
+                            n_bound++;
+                            const u64 ckey = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), cutoff) << 32) |
+                                             (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, cutoff);
+                            bool keep = false;
+                            if ((dl >> lane) & 1) {
+                                const int tt = totL[wn];
+                                double r = (double)cntL[wn];
+                                r = r + lpT[1];
+                                r = r + ((unsigned)tt < (unsigned)kFfTab ? ffT[tt] : (0.001 * (double)tt) / (double)NP);
+                                r = ldexp(r, -(int)shL[wn]);
+                                r = r - 0.0;
+                                keep = !(sortable_bits(r) > ckey);
+                            }
+                            if (__ballot(keep)) lean_done = false;
+                        }
+                        if (lean_done) {
+                            const int c1 = __ffsll((long long)cm) - 1;
+                            t1 = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), c1) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, c1);
+                            n1 = __builtin_amdgcn_readlane(wn, c1);
+                            if (k == 2) {
+                                const int c2 = cutoff;
+                                t2 = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), c2) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, c2);
+                                n2 = __builtin_amdgcn_readlane(wn, c2);
+                            }
+                        }
+                    }
+                }
+                if (!lean_done) {
+                    // the window ran dry (few entries, none of them a candidate): rebuild it once and look again
+                    if (wcnt < 32 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
+                    break;
+                }
+                // the k smallest of the sorted pairs (ka, kb) and (t1, t2): which nodes leave, which enter
+                int r1n, r2n = INT_MAX, lv1 = -1, lv2 = -1, en1 = -1, en2 = -1;
+                u64 rlast;
+                if (qless(ka, na, t1, n1)) {                          // the best own node stays in front
+                    r1n = na; rlast = ka;
+                    if (k == 2) {
+                        if (qless(kb, nb, t1, n1)) { r2n = nb; rlast = kb; }               // both stay (another order at most)
+                        else { r2n = n1; rlast = t1; en1 = n1; lv1 = ob; }
+                    }
+                } else {
+                    r1n = n1; rlast = t1; en1 = n1;
+                    if (k == 2) {
+                        if (qless(ka, na, t2, n2)) { r2n = na; rlast = ka; lv1 = ob; }
+                        else { r2n = n2; rlast = t2; en2 = n2; lv1 = oa; lv2 = ob; }
+                    } else lv1 = oa;
+                }
+                {   // a taken node that the partition holds in a lower priority state would be promoted (plan.go:294-297)
+                    const int l0 = __builtin_amdgcn_readlane(ov0, f), l1 = __builtin_amdgcn_readlane(ov1, f);
+                    if ((en1 >= 0 && (en1 == l0 || en1 == l1)) || (en2 >= 0 && (en2 == l0 || en2 == l1))) break;
+                }
+                const int rlastn = k == 2 ? r2n : r1n;
+                if (rlastn == INT_MAX || !qless(rlast, rlastn, thK, thN)) {                  // beyond the window's reach
+                    if (wcnt < 56 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
+                    break;
+                }
+                // lanes 0 .. 3 settle one node each: leaving, leaving, entering, entering
+                int hx = lane == 0 ? lv1 : lane == 1 ? lv2 : lane == 2 ? en1 : lane == 3 ? en2 : -1;
+                if (lane >= 4) hx = -1;
+                int c_new = 0, t_new = 0;
+                u64 nk = ~0ull;
+                if (hx >= 0) {
+                    const int ds = lane < 2 ? -w : w;
+                    c_new = cntL[hx] + ds;
+                    t_new = totL[hx] + ds;
+                }
+                int e_new = 0;
+                if (fold && hx >= 0) e_new = (int)ntL[hx] + (lane >= 2 ? 1 : 0);          // plan.go:238-245: the chosen nodes' entries of row ""
+                if (NP > 0 && __ballot(hx >= 0 && ((unsigned)t_new >= (unsigned)kFfTab || e_new >= kLpTab))) break;   // beyond the tables: the general code divides
+                if (hx >= 0) {
+                    double r = (double)c_new;                         // queue_score with no stickiness and a power-of-two weight
+                    if (NP > 0) { r = r + lpT[e_new]; r = r + ffT[t_new]; }
+                    if (fold) ntL[hx] = (unsigned short)e_new;
+                    r = ldexp(r, -(int)shL[hx]);
+                    r = r - 0.0;
+                    nk = sortable_bits(r);
+                    cntL[hx] = c_new; totL[hx] = t_new; gB[hx] = nk;
+                }
+                n_moved++;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int x = __builtin_amdgcn_readlane(hx, j);
+                    if (x < 0) continue;
+                    const u64 xk = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nk >> 32), j) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)nk, j);
+                    win_remove(x);
+                    win_insert(xk, x);
+                    stalemask |= __ballot(own_a == x || own_b == x);
+                }
+                if (lane == f) {
+                    int* o = outS + f * OWs;
+                    o[0] = k; o[1] = r1n;
+                    if (k == 2) o[2] = r2n;
+                }
+                cur = f + 1;
+                retried = false;
+            }
+            PH(4);
+            if (f >= B) break;
+            cur = f;
+            if (fold) { stop_pos = oi + f; stop_why = kQStopShape; break; }        // (the general code reads the matrix, not the folded row)
+            // lane-level views of the masks, and the front of the window, for the general code below
+            bool stale = (stalemask >> lane) & 1;
+            u64 frontK = thK;
+            int frontN = thN;
+            if (wcnt > 0) {
+                frontK = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), 0) << 32) |
+                         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, 0);
+                frontN = __builtin_amdgcn_readlane(wn, 0);
+            }
+
+            // ================= step f does not certainly stay =================
+            const bool simple_f = __builtin_amdgcn_readlane(simple ? 1 : 0, f) != 0;
+            if (!simple_f) { stop_pos = oi + f; stop_why = kQStopShape; cur = f; break; }
+            const bool dirty_f = __builtin_amdgcn_readlane(dirty ? 1 : 0, f) != 0;
+            const bool stale_f = __builtin_amdgcn_readlane(stale ? 1 : 0, f) != 0;
+            bool have_bits = NP > 0;
+            if (dirty_f) {                           // this step reads a row an earlier step of the batch bumps
+                flush_bumps(f);
+                BLANCE_QFENCE();
+                BLANCE_WAVE_SYNC();                  // (the emulated lanes are not in lockstep: bumps before the re-read)
+                have_bits = false;
+            }
+#ifdef BLANCE_QDEBUG2
+            if (lane == f) printf("[q2] step %d turn: dirty %d stale %d sfail %d simple %d row %d own %d last %llx/%d front %llx/%d\n", oi + f, (int)dirty, (int)stale, (int)sfail, (int)simple, row, ownv[0], lastK, lastN, frontK, frontN);
+#endif
+            if (dirty_f || stale_f) {               // lane f's keys are out of date: again, from what is true now
+                if (lane == f) {
+                    if (NP > 0) {
+#pragma unroll
+                        for (int j = 0; j < KM; j++)
+                            if (j < nown) ntn_own[j] = BLANCE_QLD(q.ntn + (size_t)row * N + ownv[j]);
+                    }
+                    own_keys();
+                    dirty = false; stale = false;
+                }
+                stalemask &= ~(1ull << f);
+                const bool ok = !sfail && qless(lastK, lastN, frontK, frontN);
+                if ((__ballot(ok) >> f) & 1) {       // a stay after all
+                    if (lane == f) emit_stay();
+                    n_bulk++;
+                    cur = f + 1;
+                    continue;
+                }
+            }
+            const int w = __builtin_amdgcn_readlane(wj, f);
+            const int rowf = __builtin_amdgcn_readlane(row, f);
+            const int nown_f = __builtin_amdgcn_readlane(nown, f);
+            int qown[KM], qh[KH];
+            u64 qK[KM];
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                qown[j] = __builtin_amdgcn_readlane(ownv[j], f);
+                qK[j] = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(oK[j] >> 32), f) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)oK[j], f);
+            }
+#pragma unroll
+            for (int j = 0; j < KH; j++) qh[j] = __builtin_amdgcn_readlane(hv[j], f);
+            const bool other_f = __builtin_amdgcn_readlane(has_other ? 1 : 0, f) != 0;
+
+            PH(5);
+            // the k best (key, node) of the step; wave uniform, ascending
+            u64 bB[KM];
+            int bN[KM];
+            auto insert = [&](u64 b, int n) {
+#pragma unroll
+                for (int j = KM - 1; j >= 0; j--) {
+                    if (j >= k) continue;
+                    const bool here = qless(b, n, bB[j], bN[j]);
+                    const bool above = j > 0 && qless(b, n, bB[j - 1], bN[j - 1]);
+                    if (here) {
+                        if (above) { bB[j] = bB[j - 1]; bN[j] = bN[j - 1]; }
+                        else { bB[j] = b; bN[j] = n; }
+                    }
+                }
+            };
+            int n_out = 0;
+            for (int attempt = 0; ; attempt++) {
+                attempt = uni(attempt);
+#pragma unroll
+                for (int j = 0; j < KM; j++) { bB[j] = ~0ull; bN[j] = INT_MAX; }
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < nown_f) insert(qK[j], qown[j]);
+                if (attempt == 2) {
+                    // ---- the window cannot decide (its entries' exact scores lie above THETA: rows with many entries,
+                    // many nodes of equal load): score every node exactly -- what the reference's sort sees
+                    n_dense++;
+                    u64 lb[KM];
+                    int ln[KM];
+#pragma unroll
+                    for (int j = 0; j < KM; j++) { lb[j] = ~0ull; ln[j] = INT_MAX; }
+                    for (int i = 0; i < G; i++) {
+                        const int n = i * 64 + lane;
+                        bool el = n < N && (flL[n] & 1);
+#pragma unroll
+                        for (int j = 0; j < KM; j++) if (qown[j] == n) el = false;      // own: scored above
+#pragma unroll
+                        for (int j = 0; j < KH; j++) if (qh[j] == n) el = false;        // plan.go:146-154
+                        if (el) {
+                            const int nt = NP > 0 ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
+                            const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                                         q.booster_kind, lpT, ffT)) : gB[n];
+#pragma unroll
+                            for (int j = KM - 1; j >= 0; j--) {      // the lane's own k best, ascending
+                                const bool here = qless(b, n, lb[j], ln[j]);
+                                const bool above = j > 0 && qless(b, n, lb[j - 1], ln[j - 1]);
+                                if (here) {
+                                    if (above) { lb[j] = lb[j - 1]; ln[j] = ln[j - 1]; }
+                                    else { lb[j] = b; ln[j] = n; }
+                                }
+                            }
+                        }
+                    }
+                    for (int j = 0; j < k; j++) {
+                        const QMin m = wave_min_key_node(lb[0], ln[0]);
+                        if (m.node == INT_MAX) break;
+                        insert(((u64)m.hi << 32) | m.lo, m.node);
+                        if (ln[0] == m.node) {
+#pragma unroll
+                            for (int e = 0; e + 1 < KM; e++) { lb[e] = lb[e + 1]; ln[e] = ln[e + 1]; }
+                            lb[KM - 1] = ~0ull; ln[KM - 1] = INT_MAX;
+                        }
+                    }
+                    n_out = 0;
+#pragma unroll
+                    for (int j = 0; j < KM; j++) if (j < k && bN[j] != INT_MAX) n_out++;
+                    break;
+                }
+                // window entries that are candidates for this partition (plan.go:142-156), and whose entry may be non-zero
+                bool elig = lane < wcnt;
+#pragma unroll
+                for (int j = 0; j < KM; j++) elig = elig && wn != qown[j];
+#pragma unroll
+                for (int j = 0; j < KH; j++) elig = elig && wn != qh[j];
+                bool bit = false;
+                if (NP > 0 && elig) bit = have_bits ? ((bitsL[f * BW + (wn >> 5)] >> (wn & 31)) & 1) != 0 : true;
+                const u64 em = __ballot(elig), dm = __ballot(elig && bit);
+                const u64 cm = em & ~dm;             // clean: exact score = window key
+                // the k-th clean candidate bounds what has to be looked at: everything behind it scores >= its g
+                u64 ck = cm;
+                for (int j = 1; j < k; j++) ck &= ck - 1;
+                const int cutoff = ck ? __ffsll((long long)ck) - 1 : 64;
+                const u64 upto = cutoff >= 63 ? ~0ull : ((2ull << cutoff) - 1);
+                const u64 dl = dm & upto;            // entries to read from the matrix
+                if (dl == 0) {
+                    // ---- fast: the first k eligible entries, as they stand
+                    u64 e2 = em & upto;
+                    for (int j = 0; j < k && e2; j++) {
+                        const int c = __ffsll((long long)e2) - 1;
+                        e2 &= e2 - 1;
+                        const u64 cb = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), c) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, c);
+                        insert(cb, __builtin_amdgcn_readlane(wn, c));
+                    }
+                } else {
+                    // ---- entries with their bit set in front of the k-th clean one: exact scores from the matrix
+                    n_exact++;
+                    u64 ek = ~0ull;
+                    int en = INT_MAX;
+                    if ((dl >> lane) & 1) {
+                        const int nt = BLANCE_QLD(q.ntn + (size_t)rowf * N + wn);
+                        ek = nt ? sortable_bits(queue_score(cntL[wn], nt, totL[wn], (flL[wn] >> 1) & 1, wL[wn], NP, 0.0,
+                                                            q.booster_kind, lpT, ffT)) : wk;
+                        en = wn;
+                    } else if (((cm & upto) >> lane) & 1) { ek = wk; en = wn; }
+                    for (int j = 0; j < k; j++) {
+                        const QMin m = wave_min_key_node(ek, en);
+                        if (m.node == INT_MAX) break;
+                        insert(((u64)m.hi << 32) | m.lo, m.node);
+                        if (en == m.node) { ek = ~0ull; en = INT_MAX; }
+                    }
+                }
+                // valid if every taken node lies below THETA (a node outside the window scores >= THETA)
+                n_out = 0;
+                bool below = true;
+#pragma unroll
+                for (int j = 0; j < KM; j++) {
+                    if (j < k && bN[j] != INT_MAX) {
+                        n_out++;
+                        if (!qless(bB[j], bN[j], thK, thN)) below = false;
+                    }
+                }
+                if ((n_out == k && below) || thN == INT_MAX) break;
+                // the window does not reach far enough.  Run dry (few entries): rebuild it around the current keys and
+                // look again; full, or rebuilt already: its entries are held back by their matrix entries -- every node then
+                if (attempt == 0 && wcnt < 56) rebuild();
+                else attempt = 1;
+            }
+            PH(6);
+            if (n_out < k) { stop_pos = oi + f; stop_why = kQStopShort; }      // fewer candidates than constraints: warnings
+            if (stop_why != kQStopNone) { cur = f; break; }
+            // a taken node the partition holds in a lower priority state would be promoted: k_pass_tree's business
+            if (other_f) {
+                const int* rf = recS + f * RW;
+                bool prom = false;
+                for (int t = 0; t < M; t++) {
+                    if (t == s || ((q.higher_mask >> t) & 1)) continue;
+                    const int h = rf[kRecHead + t * SW];
+                    if ((h >> 16) == kListAbsent) continue;
+                    for (int jj = 0; jj < (h & 0xffff); jj++) {
+                        const int x = rf[kRecHead + t * SW + 1 + jj];
+#pragma unroll
+                        for (int j = 0; j < KM; j++) if (j < k && bN[j] == x) prom = true;
+                    }
+                }
+                if (prom) { stop_pos = oi + f; stop_why = kQStopPromote; cur = f; break; }
+            }
+            // ---- commit (plan.go:290-301): own nodes not taken leave, taken nodes that are not own enter
+            n_moved++;
+#ifdef BLANCE_QDEBUG
+            if (lane == 0) {
+                printf("[q] step %d w %d row %d nown %d own %d %d keys %llx %llx high %d %d -> %d %d (%llx %llx) wcnt %d theta %llx/%d bits %d\n", oi + f, w, rowf, nown_f, qown[0], qown[1],
+                       qK[0], qK[1], qh[0], qh[1], bN[0], bN[1], bB[0], bB[1], wcnt, thK, thN, (int)have_bits);
+            }
+            for (int l_ = 0; l_ < wcnt; l_++) { const unsigned h_ = __builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), l_), lo_ = __builtin_amdgcn_readlane((int)(unsigned)wk, l_); const int n_ = __builtin_amdgcn_readlane(wn, l_);
+                if (lane == 0) printf("[q]   win %d: node %d key %08x%08x cnt %d tot %d\n", l_, n_, h_, lo_, cntL[n_], totL[n_]); }
+#endif
+            int chg[2 * KM];                         // nodes whose counters change, wave uniform (-1: none)
+            int nchg = 0;
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                bool kept = false;
+#pragma unroll
+                for (int e = 0; e < KM; e++) kept = kept || (e < k && bN[e] == qown[j]);
+                chg[j] = (j < nown_f && !kept) ? qown[j] : -1;
+            }
+#pragma unroll
+            for (int e = 0; e < KM; e++) {
+                bool mine = false;
+#pragma unroll
+                for (int j = 0; j < KM; j++) mine = mine || (j < nown_f && qown[j] == bN[e]);
+                chg[KM + e] = (e < k && !mine) ? bN[e] : -1;
+            }
+            // lanes 0 .. 2 KM - 1 settle one node each
+            int hx = -1;
+            u64 nk = ~0ull;
+#pragma unroll
+            for (int j = 0; j < 2 * KM; j++) if (lane == j) hx = chg[j];
+            if (hx >= 0) {
+                const int ds = lane < KM ? -w : w;
+                cntL[hx] += ds;
+                totL[hx] += ds;
+                nk = gkey(hx);
+                gB[hx] = nk;
+            }
+            PH(7);
+            BLANCE_WAVE_SYNC();
+#pragma unroll
+            for (int j = 0; j < 2 * KM; j++) {
+                const int x = chg[j];
+                if (x < 0) continue;
+                nchg++;
+                const u64 xk = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nk >> 32), j) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)nk, j);
+                win_remove(x);
+                win_insert(xk, x);
+                // later lanes of the batch that hold x were validated against its old counters
+#pragma unroll
+                for (int jj = 0; jj < KM; jj++) stalemask |= __ballot(lane > f && ownv[jj] == x);
+            }
+            (void)nchg;
+            if (lane == f) {
+                int* o = outS + f * OWs;             // (its row is bumped with the batch's, plan.go:238-245)
+                o[0] = k;
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < k) o[1 + j] = bN[j];
+            }
+            PH(8);
+            cur = f + 1;
+        }
+        // ---- the batch's outputs (up to the step that stopped the launch), and the bumps still pending
+        const int done = stop_why == kQStopNone ? B : cur;
+        BLANCE_WAVE_SYNC();
+        flush_bumps(done);
+        for (int idx = lane; idx < done * OWs; idx += 64) q.out[(size_t)oi * OWs + idx] = outS[idx];
+        PH(9);
+        BLANCE_WAVE_SYNC();
+    }
+#ifdef BLANCE_PHASE_PROF
+    if (lane == 0) {
+        printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild);
+        for (int i_ = 0; i_ < 12; i_++) printf("[queue phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
+    }
+#endif
+    if (lane == 0) {
+        q.stop[0] = stop_pos;
+        q.stop[1] = stop_why;
+        if (q.spec_count) *q.spec_count += n_bulk;
+        if (q.qstats) { q.qstats[0] += n_moved; q.qstats[1] += n_exact; q.qstats[2] += n_rebuild; q.qstats[3] += n_dense; }
+    }
+    BLANCE_WAVE_SYNC();
+    for (int i = 0; i < G; i++) {
+        const int n = i * 64 + lane;
+        if (n < NX) q.cnt[s * NX + n] = cntL[n];
+    }
+}
+
+// dynamic LDS of k_pass_queue for a pass
+static inline size_t queue_lds_bytes(int NX, int RW) {
+    const size_t NXp = (size_t)((NX + 63) / 64) * 64, BW = ((NXp >> 5) + 3) & ~(size_t)3;
+    return NXp * (8 + 4 + 4 + 4 + 1 + 1 + 1 + 2) + 64 + sizeof(double) * (kLpTab + kFfTab) + sizeof(int32_t) * (size_t)(64 * RW) +
+           sizeof(int32_t) * 64 * 3 + sizeof(int32_t) * 64 * BW + 64;
+}
+
+}  // namespace blance

@@ -442,6 +442,20 @@ __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32
         rec[(size_t)first * RW + j] = ((const int32_t*)lds)[(j / RW) * ST + j % RW];
 }
 
+// k_pass_queue's bit maps ("is nodeToNodeCounts[row][n] not zero", BW words per row) rebuilt from the matrix: kernels
+// other than k_pass_queue bump the matrix only, so the host runs this before k_pass_queue follows one of them in a pass.
+__global__ void k_ntn_bits(int N, int rows, int BW, const int32_t* ntn, uint32_t* bits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * BW) return;
+    const int row = (int)(i / BW), c = (int)(i % BW);
+    uint32_t w = 0;
+    for (int b = 0; b < 32; b++) {
+        const int n = c * 32 + b;
+        if (n < N && ntn[(size_t)row * N + n] != 0) w |= 1u << b;
+    }
+    bits[i] = w;
+}
+
 // Apply the pass's choices to the live lists (plan.go:290-299); list edits only
 // touch the step's own partition, so this runs in parallel after the pass.
 __global__ void k_scatter(DevProblem d, int m, int OW, const int32_t* order, const int32_t* out) {

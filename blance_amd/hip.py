@@ -80,7 +80,7 @@ class Planner:
     """One blance_ctx: a planner bound to one gfx950 device."""
 
     def __init__(self, device_id=0, engine=abi.ENGINE_AUTO, lib_path=None, force_threads=0,
-                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True, stay_top="auto", periodic=False):
+                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True, stay_top="auto", periodic=True, queue=True):
         self.lib = load_library(lib_path)
         opt = abi.Options()
         opt.engine = engine
@@ -93,9 +93,12 @@ class Planner:
         # 32 = the all-blank chain pass on k_pass_chain_blank (lane minima) instead of k_pass_chain_planes
         # 64 = never k_stay_by_top (a chain pass of stays verified per top priority node), 128 = try it in every
         # chain pass with NumPartitions > 0
-        # 256 = OPT-IN, not a test knob: an all-blank chain pass whose step records repeat walks two periods and copies
-        # the rest (k_period.h; also BLANCE_PERIODIC=1)
-        opt.reserved[2] = (256 if periodic else 0) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
+        # 256 = the all-blank chain pass WITHOUT its periodic form (k_period.h: a pass whose step records repeat walks two
+        # periods and copies the rest -- the default; also BLANCE_PERIODIC=0)
+        # 512 = flat passes with k <= 2 never on k_pass_queue (k_pass_tree / k_pass_seq take them, as before round 4);
+        # 1024 = k_pass_queue without its lean walk (every step that does not stay through its general code)
+        qbits = {True: 0, "on": 0, False: 512, "off": 512, "general": 1024}[queue]
+        opt.reserved[2] = qbits | (0 if periodic else 256) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))

@@ -284,3 +284,57 @@ def replan_problem(fp, res):
     fp2.set("node_added", np.zeros(len(fp.node_added), dtype=np.uint8))
     fp2.scalars.update(n_prev=P, nodes_to_add_nil=1)
     return fp2
+
+
+# ---- config 3's general regime ("time the general hierarchical regime") ------------------------------
+# The headline instance is the most regular one there is (fresh plan, numeric names, no weights).  Two more workloads
+# of the same size are timed beside it by bench.py: (a) the rebalance of config 3's plan after every tenth node left,
+# (b) config 3 with non-numeric, scrambled partition names and Zipf partition weights.
+
+def _scrambled_names_hash(P):
+    """name_i = "vb%08x" % h_i with h_i = (i * 2246822519 + 374761393) mod 2^32: distinct, fixed width, so the
+    reference's name key (plan.go:519-540: Atoi fails -> the raw name) orders the partitions by h_i."""
+    return (np.arange(P, dtype=np.uint64) * np.uint64(2246822519) + np.uint64(374761393)) & np.uint64(0xFFFFFFFF)
+
+
+def _zipf_weights(P):
+    """weight_i = clamp(1000 // rank_i, 1, 1000), rank a fixed pseudo-random permutation of 1..P (SURVEY.md 8d, config 5's law)."""
+    h = (np.arange(P, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    rank = np.empty(P, dtype=np.int64)
+    rank[np.argsort(h, kind="stable")] = np.arange(1, P + 1)
+    return np.clip(1000 // rank, 1, 1000).astype(np.int32)
+
+
+def config3_named_weighted_case(P, N):
+    """API-level arguments of workload (b) (for reduced sizes: tests/test_synth.py checks it against the flat builder)."""
+    c = config_case(3, P=P, N=N)
+    names = ["vb%08x" % int(h) for h in _scrambled_names_hash(P)]
+    w = _zipf_weights(P)
+    c["partitionsToAssign"] = {n: {"name": n, "nodesByState": {}} for n in names}
+    c["partitionWeights"] = {names[i]: int(w[i]) for i in range(P)}
+    return c
+
+
+def config3_named_weighted_flat(P=1048576, N=4096, max_iterations=10):
+    """Workload (b) as a flat problem without going through strings.  Partition ids are the generator's indices (the
+    interning layer numbers partitions in the order of the map it is given, problem.py); the static pass order is
+    (weight descending, name) -- plan.go:519-540."""
+    fp = config_flat(3, P=P, N=N, max_iterations=max_iterations)
+    h = _scrambled_names_hash(P)
+    w = _zipf_weights(P)
+    fp.set("part_weight", w)
+    fp.set("part_has_weight", np.ones(P, dtype=np.uint8))
+    fp.set("part_order", np.lexsort((h, -w.astype(np.int64))).astype(np.int32))
+    fp.scalars.update(partition_weights_nil=0)
+    return fp
+
+
+def config3_rebalance_flat(fp, res, every=10, which=3):
+    """Workload (a): PlanNextMap(prevMap = partitionsToAssign = the plan `res` of `fp`, nodesToRemove = every `every`-th
+    node (id % every == which), nodesToAdd = nil).  tests/golden/config3_full_size_properties.json holds the oracle's digest."""
+    fp2 = replan_problem(fp, res)
+    N = int(fp.n_nodes)
+    rm = np.zeros(N, dtype=np.uint8)
+    rm[np.arange(N) % every == which] = 1
+    fp2.set("node_removed", rm)
+    return fp2

@@ -194,8 +194,8 @@ typedef struct blance_options {
     int32_t reserved[6];      /* zero in production.  Test knobs: [0] workgroup size of k_pass_seq (64 / 256 / 512 /
                                * 1024), [1] smallest pass handed to the bulk engines, [2] & 1 = k_pass_seq without
                                * verified-stay speculation (further bits of [2]: blance_amd/hip.py).
-                               * One bit of [2] is an OPTION, not a test knob: & 256 = the all-blank chain pass in its
-                               * periodic form (csrc/k_period.h; exact, opt-in until it has been measured)       */
+                               * & 256 = the all-blank chain pass WITHOUT its periodic form (csrc/k_period.h, on by
+                               * default since round 4; the environment's BLANCE_PERIODIC=0 does the same)       */
 } blance_options;
 
 typedef struct blance_ctx blance_ctx;   /* opaque: device buffers, stream, events */

@@ -217,6 +217,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
     else if (ctrl == 0x142) { from = (l & ~15) - 1; if (from < 0) { from = l; write = false; } }   // row_bcast:15
     else if (ctrl == 0x143) { from = 31; if (l < 32) write = false; }                             // row_bcast:31
+    else if (ctrl == 0x138) { from = l - 1; if (from < 0) { from = l; write = false; } }            // wave_shr:1: lane i <- lane i - 1
+    else if (ctrl == 0x130) { from = l + 1; if (from > 63) { from = l; write = false; } }           // wave_shl:1: lane i <- lane i + 1
     else { fprintf(stderr, "emu: dpp ctrl %x not modelled\n", ctrl); abort(); }
     int got = (int)(uint32_t)emu::wave_exchange((uint32_t)src, from);
     return write ? got : old;

@@ -462,7 +462,7 @@ def test_all_blank_pass_plane_automaton(k_rep):
     import random
     shapes = [(16, 8, 3), (8, 16, 2), (4, 10, 3), (5, 9, 4), (7, 11, 2), (12, 10, 2), (16, 5, 3), (2, 30, 2), (32, 4, 2)]
     for planes in (True, False):
-        pl = hip.Planner(device_id=0, chain_min_parts=1, planes=planes)
+        pl = hip.Planner(device_id=0, chain_min_parts=1, planes=planes, periodic=False)     # every step walked
         for si, (rack, racks_per_zone, n_zones) in enumerate(shapes):
             if rack * racks_per_zone > 128 or racks_per_zone <= k_rep + 1:
                 continue

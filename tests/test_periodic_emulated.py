@@ -1,6 +1,6 @@
-"""The opt-in periodic form of the all-blank chain pass (blance_amd/csrc/k_period.h): two periods walked, the rest of
+"""The periodic form of the all-blank chain pass (blance_amd/csrc/k_period.h): two periods walked, the rest of
 the periodic stretch copied, whatever lies behind it walked -- bit for bit the oracle's plan, on the emulated kernels.
-(The GPU counterpart is tests/test_hip_parity.py::test_periodic_all_blank_pass.)"""
+(The GPU counterpart is tests/test_periodic_gpu.py::test_periodic_all_blank_pass.)"""
 import os
 import subprocess
 import sys

@@ -17,8 +17,8 @@ EMU_SRC = os.path.join(HERE, "simt", "emu_lib.cpp")
 EMU_SO = os.path.join(HERE, "simt", "_build", "libblance_emu.so")
 DEPS = [EMU_SRC, os.path.join(HERE, "simt", "hip_emu.h"), os.path.join(HERE, "..", "include", "blance_hip.h")] + [
     os.path.join(HERE, "..", "blance_amd", "csrc", f) for f in
-    ("blance_hip.hip", "tu_seq.hip", "tu_tree.hip", "tu_chain.hip", "dev_prelude.h", "blance_kernels.h", "dev_common.h",
-     "k_pass_seq.h", "k_pass_tree.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h", "k_period.h", "k_stay.h")]
+    ("blance_hip.hip", "tu_seq.hip", "tu_tree.hip", "tu_queue.hip", "tu_chain.hip", "dev_prelude.h", "blance_kernels.h", "dev_common.h",
+     "k_pass_seq.h", "k_pass_tree.h", "k_pass_queue.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h", "k_period.h", "k_stay.h")]
 
 
 def build_emu():

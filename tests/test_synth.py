@@ -47,3 +47,14 @@ def test_metric_bookkeeping():
     assert synth.algorithmic_bytes_per_sweep(fp) == 1024 * (65576 + 98344)
     fp2 = synth.config_flat(2)
     assert synth.algorithmic_bytes_per_sweep(fp2) == 65536 * 8272
+
+
+@pytest.mark.parametrize("P,N", [(700, 256), (2048, 512)])
+def test_named_weighted_flat_equals_interned(P, N):
+    """Workload (b) of bench.py's general-regime block: the numpy builder equals the string-level route (scrambled
+    non-numeric names, Zipf partition weights) field for field."""
+    a = synth.config3_named_weighted_flat(P, N)
+    b = synth.case_to_flat(synth.config3_named_weighted_case(P, N))
+    assert a.scalars == b.scalars
+    for k in abi.I32_FIELDS + abi.U8_FIELDS:
+        assert np.array_equal(a.arrays[k], b.arrays[k]), k
