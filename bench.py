@@ -17,7 +17,10 @@ when it is not already running under it):
     all-reduce of [flags | load-vector change] and one all-gather of the output slices (BASELINE.json
     config 4) -- timed the same way and reported beside it, whatever it is (DESIGN.md "Multi-GPU").
 N = 1 also reports "sharded_on_one_gpu": the same sharded plan with 8 ranks as 8 contexts of this one
-device (collectives staged through the host) -- it proves the path on real kernels, it is not a speed.
+device (collectives staged through the host) -- it proves the path on real kernels, it is not a speed --
+"general_regime": config 3's size in its general regime (a rebalance after every tenth node left; scrambled
+non-numeric partition names + Zipf partition weights), each checked against the oracle's digest -- and
+roofline.traffic measured in this run (two rocprofv3 --pmc passes of one more PlanNextMap call).
 """
 import argparse
 import json
@@ -48,7 +51,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(parts, nodes, cfg):
+def cpu_baseline(parts, nodes, cfg, full=False):
     """CPU legs, one core each (the Go planner is single threaded), on a bounded sample of the same
     workload: (i) "port": oracle/blance_oracle.c, the id-based restatement; (ii) "naive": the
     string-keyed proxy of the reference's Go code path (hash maps + comparison sort calling Score
@@ -68,20 +71,24 @@ def cpu_baseline(parts, nodes, cfg):
         what = "the rebalance PlanNextMap"
         frac = "1/32"
     else:
-        sample_parts = max(1024, parts // 4)
+        sample_parts = parts if full else max(1024, parts // 4)
         fp = synth.config_flat(cfg, P=sample_parts, N=nodes)
         what = "full PlanNextMap"
-        frac = "1/4"
+        frac = "all" if full else "1/4"
     t0 = time.perf_counter()
     res = loader.plan(fp)
     dt = time.perf_counter() - t0
     info["value"] = synth.assignments(fp) / dt
-    info["extrapolated"] = True
-    info["sample"] = ("oracle/blance_oracle.c, %s (%d sweeps) on %d partitions x %d nodes (%s of the partitions, same "
-                      "nodes/hierarchy/model; per-step cost is O(nodes), so assignments/s carries over: EXTRAPOLATED "
-                      "from the sample, the full-size run is %s), %.1f s"
-                      % (what, res.iterations, sample_parts, nodes, frac,
-                         "8 minutes" if cfg == 5 else "126 s on this repository's build container", dt))
+    info["extrapolated"] = sample_parts != parts
+    if sample_parts == parts:
+        info["sample"] = "oracle/blance_oracle.c, %s (%d sweeps) on all %d partitions x %d nodes: NOT extrapolated, %.1f s" % (
+            what, res.iterations, sample_parts, nodes, dt)
+    else:
+        info["sample"] = ("oracle/blance_oracle.c, %s (%d sweeps) on %d partitions x %d nodes (%s of the partitions, same "
+                          "nodes/hierarchy/model; per-step cost is O(nodes), so assignments/s carries over: EXTRAPOLATED "
+                          "from the sample -- bench.py --cpu-full runs all of them, %s), %.1f s"
+                          % (what, res.iterations, sample_parts, nodes, frac,
+                             {5: "8 minutes", 3: "about 2 minutes"}.get(cfg, "under a second"), dt))
     # config 2 in full (65,536 x 256, not sampled), same port, same core
     fp2 = synth.config_flat(2)
     t0 = time.perf_counter()
@@ -111,16 +118,6 @@ def profile_json(name):
     except Exception:
         now = None
     if now != data.get("source_hash"):
-        # one documented exception: sources that differ from the profiled ones by a change listed, with its reason and
-        # commit, in profiles/r3_equivalent_sources.json -- quoted WITH both hashes, never silently
-        try:
-            with open(os.path.join(ROOT, "profiles", "r3_equivalent_sources.json")) as f:
-                eq = json.load(f).get(now or "", {})
-        except Exception:
-            eq = {}
-        if eq.get("profiled_as") == data.get("source_hash"):
-            return data, "profiles/%s (git %s, kernel sources %s; the sources are now %s: %s -- profiles/r3_NOTE_sources.txt)" % (
-                name, data.get("git_head"), data.get("source_hash"), now, eq.get("difference"))
         return None, "%s was taken from other kernel sources (%s, now %s)" % (name, data.get("source_hash"), now)
     return data, "profiles/%s (git %s, kernel sources %s)" % (name, data.get("git_head"), data.get("source_hash"))
 
@@ -136,6 +133,101 @@ def kernel_counters(data, prefix):
             if k != "calls":
                 tot[k] = tot.get(k, 0) + v
     return tot, calls
+
+
+def live_pmc(args):
+    """roofline.traffic measured IN THIS RUN: one more PlanNextMap call of the same configuration under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes: the TCC has no
+    room for both; no other trace domain with --pmc), summed per kernel.  Returns ({"kernels": {short name:
+    {"calls", "FETCH_SIZE", "WRITE_SIZE"}}, "plan_calls": 1}, description) or (None, why not)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "no rocprofv3 on this machine"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_summary
+    per = {}
+    work = tempfile.mkdtemp(prefix="blance_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(work, counter), "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "1", "--warmup", "0",
+                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc"]
+            if args.parts:
+                cmd += ["--parts", str(args.parts)]
+            if args.nodes:
+                cmd += ["--nodes", str(args.nodes)]
+            if args.no_periodic:
+                cmd += ["--no-periodic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            dbs = glob.glob(os.path.join(work, counter, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s gave no result (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])
+            cur = sqlite3.connect(dbs[0]).cursor()
+            g = profile_summary.tables(cur)
+            rows = cur.execute(
+                "select s.kernel_name, i.name, count(distinct d.id), sum(e.value) from %s e join %s i on e.pmc_id=i.id join %s d on "
+                "e.event_id=d.event_id join %s s on d.kernel_id=s.id group by s.kernel_name, i.name"
+                % (g("pmc_event"), g("info_pmc"), g("kernel_dispatch"), g("kernel_symbol"))).fetchall()
+            for kname, cname, n, v in rows:
+                row = per.setdefault(profile_summary.short(kname), {"calls": n})
+                row[cname] = v
+                row["calls"] = max(row["calls"], n)
+    except Exception as e:
+        return None, "live counters failed: %s: %s" % (type(e).__name__, str(e)[:200])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return ({"kernels": per, "plan_calls": 1},
+            "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) around one more "
+            "PlanNextMap call of this configuration; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 counts half of a streaming "
+            "read, MI355X_MICROARCH.md HBM), per launch")
+
+
+def general_regime(pl, fp3, res3, steps):
+    """Config 3's size outside its most regular instance: (a) the rebalance of the headline plan after every
+    tenth node left, (b) scrambled non-numeric partition names + Zipf partition weights.  Each: uploaded, one warm-up,
+    `steps` timed calls, digest against the oracle's (tests/golden/config3_full_size_properties.json, config3_general_regime.json)."""
+    from blance_amd import synth
+    out = []
+    gold = {}
+    for name in ("config3_full_size_properties.json", "config3_general_regime.json"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                gold.update(json.load(f))
+    full = fp3.n_parts == 1 << 20 and fp3.n_nodes == 4096
+    work = [("config 3's plan rebalanced after every tenth node left (prevMap = partitionsToAssign = the headline plan, "
+             "nodesToRemove = node ids with id % 10 == 3)", lambda: synth.config3_rebalance_flat(fp3, res3), gold.get("rebalance")),
+            ("config 3 with scrambled non-numeric partition names and Zipf partition weights (fresh plan)",
+             lambda: synth.config3_named_weighted_flat(fp3.n_parts, fp3.n_nodes), gold.get("named_weighted"))]
+    for label, make, want in work:
+        try:
+            fp = make()
+            pl.upload(fp)
+            pl.plan_resident()
+            t0 = time.perf_counter()
+            acc = {"pass_ms": 0.0, "flat_ms": 0.0, "device_ms": 0.0}
+            r = None
+            for _ in range(steps):
+                r = pl.plan_resident()
+                acc["pass_ms"] += r.pass_kernel_ms
+                acc["flat_ms"] += r.flat_pass_ms
+                acc["device_ms"] += r.device_ms
+            dt = (time.perf_counter() - t0) / steps
+            digest = pl.download().digest()
+            a = synth.assignments(fp)
+            out.append({"workload": label, "headline": False, "partitions": fp.n_parts, "nodes": fp.n_nodes, "steps": steps,
+                        "ms_per_step": dt * 1e3, "value": a / dt, "unit": "assignments/s", "sweeps_per_call": r.iterations,
+                        "converged": bool(r.converged), "device_ms_per_step": acc["device_ms"] / steps,
+                        "pass_kernel_ms_per_step": acc["pass_ms"] / steps, "flat_pass_ms_per_step": acc["flat_ms"] / steps,
+                        "steps_bulk": int(r.steps_batched), "steps_one_by_one": int(r.steps_sequential), "result_sha256": digest,
+                        "matches_oracle_digest": (want["digest"] == digest) if (want and full) else None})
+        except Exception as e:
+            out.append({"workload": label, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    return out
 
 
 def self_launch(args):
@@ -157,8 +249,12 @@ def main():
     ap.add_argument("--nodes", type=int, default=0, help="override node count (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="skip the 8-contexts-on-one-GPU leg of N = 1")
-    ap.add_argument("--periodic", action="store_true", help="OPT-IN, not the headline: the all-blank chain pass in its periodic "
-                    "form (blance_amd/csrc/k_period.h); the line then carries config.opt_in and no committed counters apply")
+    ap.add_argument("--no-periodic", action="store_true", help="the all-blank chain pass without its periodic form (blance_amd/csrc/"
+                    "k_period.h, the default since round 4): every step walked; not the headline")
+    ap.add_argument("--no-extra", action="store_true", help="skip the general_regime block (two more workloads of config 3's size)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on ALL partitions of the configuration (config 3: about two minutes) "
+                    "instead of the quarter sample that is extrapolated")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -184,9 +280,9 @@ def main():
 
     from blance_amd import dist_util, hip, synth
     if rehearsal:
-        pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8, periodic=args.periodic)
+        pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8, periodic=not args.no_periodic)
     else:
-        pl = hip.Planner(device_id=local_rank, periodic=args.periodic)      # raises without the HIP library / a device
+        pl = hip.Planner(device_id=local_rank, periodic=not args.no_periodic)      # raises without the HIP library / a device
     if args.config == 5:                            # the rebalance starts from a plan over the old nodes (setup, untimed)
         fp1 = synth.config5_initial(args.parts or 1 << 20, args.nodes or 4096)
         fp = synth.config5_rebalance(fp1, pl.plan(fp1), args.parts or 1 << 20, args.nodes or 4096)
@@ -246,10 +342,20 @@ def main():
         # record and writes its choice; nothing else leaves registers / LDS) over its average launch duration, measured
         # in this run with HIP events on the planner's stream
         headline_shape = not args.parts and not args.nodes
-        hbm, hbm_src = profile_json("r3_pmc_hbm_config%d.json" % args.config)
-        sq, sq_src = profile_json("r3_pmc_sq_config%d.json" % args.config)
+        # HBM traffic per kernel: measured in this run when rocprofv3 is here (N = 1, not the rehearsal), else quoted from a
+        # committed profile of EXACTLY these kernel sources (hash checked, no exceptions), else null
+        hbm, hbm_src = None, "not measured (--no-live-pmc)"
+        if world == 1 and not rehearsal and not args.no_live_pmc:
+            hbm, hbm_src = live_pmc(args)
+        if hbm is None:
+            why = hbm_src
+            hbm, hbm_src = profile_json("r4_pmc_hbm_config%d.json" % args.config)
+            hbm_src = "%s -- a committed profile of the same kernel sources, NOT measured in this run (%s)" % (hbm_src, why) if hbm else \
+                      "none: %s; %s" % (why, hbm_src)
+        sq, sq_src = profile_json("r4_pmc_sq_config%d.json" % args.config)
+        survey_state = synth.algorithmic_bytes_per_state(fp)          # the reference's dense scan, per pass of a state
 
-        def kernel_line(label, prefix, words, ms, launches, chains):
+        def kernel_line(label, prefix, words, ms, launches, chains, dense_bytes):
             if not launches:
                 return None
             bytes_per_launch = 4.0 * words * P
@@ -258,14 +364,19 @@ def main():
             line = {"kernel": label, "launches": launches, "avg_launch_ms": avg_ms, "bound": "hbm", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "algorithmic_bytes_model": "%d partitions x %d words x 4 B: every step reads its record and writes its "
+                    "algorithmic_bytes_model": "SCHEDULE bytes: %d partitions x %d words x 4 B -- every step reads its record and writes its "
                                                "choice; load tables stay in registers / LDS (DESIGN.md 5)" % (P, words),
-                    "traffic": None, "traffic_from": hbm_src + " -- a committed profile of the same kernel sources, NOT measured in this run"}
+                    # the other model, side by side: what SURVEY.md 8(d) prices a pass at (the reference's dense per-step scan)
+                    "survey_8d_bytes_per_launch": float(dense_bytes),
+                    "survey_8d_GBps": dense_bytes / (avg_ms * 1e-3) / 1e9,
+                    "survey_8d_frac": dense_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": None, "traffic_from": hbm_src}
             if hbm and headline_shape:
                 tot, calls = kernel_counters(hbm, prefix)
                 if calls:
                     # gfx950: FETCH_SIZE (KB) counts half of a streaming read's bytes (MI355X_MICROARCH.md, HBM)
                     line["traffic"] = (2.0 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024 / calls
+                    line["traffic_launches_counted"] = calls
             if chains:
                 chain_steps = -(-P // chains)
                 ns = avg_ms * 1e6 / chain_steps
@@ -287,38 +398,43 @@ def main():
                             "issue_bound_frac": (per_step * 4.5 / SCLK_GHZ) / ns if ns else None,
                             "wave_active_frac": tot.get("SQ_ACTIVE_INST_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
                             "wave_waiting_frac": tot.get("SQ_WAIT_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,
-                            "counters_from": sq_src + " (committed profile, not this run)"})
+                            "counters_from": sq_src + " (committed profile of the same kernel sources, not this run)"})
                 line["critical_path"] = crit
             return line
 
         kernels = []
         kmax = max(k_by_state)
+        rule_states = [m for m in kernel_states if survey_state[m] > 0]
+        dense_pass = max([survey_state[m] for m in rule_states] or [0])          # the pass-kernel states' pass (config 3 / 5: replica)
+        dense_flat = max([survey_state[m] for m in range(M) if m not in kernel_states] or [0])
         if args.config == 5:
-            kernels.append(kernel_line("k_pass_tree (flat replica pass, one wave64, one launch per sub-range of a pass)", ("k_pass_tree",),
-                                       RW + 1 + kmax, acc["pass_ms"], acc["pass_launches"], 1))
+            kernels.append(kernel_line("k_pass_queue (flat replica pass, one wave64: the candidates as a sorted window over the lanes)",
+                                       ("k_pass_queue", "k_pass_tree"), RW + 1 + kmax, acc["pass_ms"], acc["pass_launches"], 1, dense_pass))
         else:
             zones = -(-N // 128)                     # zones of 8 racks x 16 nodes: one chain each
-            kernels.append(kernel_line("k_pass_chain_planes (all-blank replica pass of the first sweep: scalar bit-plane automaton, one "
-                                       "wave64 per hierarchy region)", ("k_pass_chain_planes", "k_pass_chain_blank"),
-                                       K_CW + 1 + kmax, acc["blank_ms"], acc["blank_launches"], zones))
+            kernels.append(kernel_line("all-blank replica pass of the first sweep (k_pass_chain_planes: scalar bit-plane automaton, one wave64 per "
+                                       "hierarchy region; with k_period.h two periods walked and the periodic stretch copied)",
+                                       ("k_pass_chain_planes", "k_pass_chain_blank", "k_period"), K_CW + 1 + kmax, acc["blank_ms"],
+                                       acc["blank_launches"], zones, dense_pass))
             kernels.append(kernel_line("k_pass_chain / k_stay_by_top (replica passes of the later sweeps: verified stays -- one wave64 per "
                                        "hierarchy region, or, in a converged sweep, one thread per top priority node incl. its grouping)",
                                        ("k_pass_chainI", "k_stay_by_top"), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"],
-                                       acc["pass_launches"] - acc["blank_launches"], zones))
+                                       acc["pass_launches"] - acc["blank_launches"], zones, dense_pass))
         kernels.append(kernel_line("flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)",
-                                   ("k_flat", "k_fresh", "k_sort"), RW + 2, acc["flat_ms"], acc["flat_passes"], None))
+                                   ("k_flat", "k_fresh", "k_sort"), RW + 2, acc["flat_ms"], acc["flat_passes"], None, dense_flat))
         kernels = [k for k in kernels if k]
         kernels.sort(key=lambda k: -k["avg_launch_ms"] * k["launches"])
         dom = dict(kernels[0]) if kernels else {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
-        # the whole call against the HBM peak: every kernel's measured traffic (committed profile) over this run's device time
+        # the whole call against the HBM peak: every kernel's measured traffic over this run's device time
         whole = None
         if hbm and headline_shape:
             tot, calls = kernel_counters(hbm, ("",))
             per_call = (2.0 * tot.get("FETCH_SIZE", 0) + tot.get("WRITE_SIZE", 0)) * 1024 / max(hbm.get("plan_calls", 1), 1)
             dev_s = acc["device_ms"] / args.steps * 1e-3
             whole = {"hbm_bytes_per_call": per_call, "GBps": per_call / dev_s / 1e9, "frac_of_hbm_peak": per_call / dev_s / 1e9 / HBM_PEAK_GBS,
-                     "from": hbm_src + " (committed profile of the same kernel sources) over this run's device time"}
-        dense = synth.algorithmic_bytes_per_sweep(fp) * iterations * args.steps / (acc["device_ms"] * 1e-3) / 1e9
+                     "from": hbm_src + "; over this run's device time"}
+        dense_call = synth.algorithmic_bytes_per_sweep(fp) * iterations
+        dense = dense_call * args.steps / (acc["device_ms"] * 1e-3) / 1e9
         out = {
             "metric": "partition-state assignments/sec at 1M partitions x 4,096 nodes",
             "value": value, "unit": "assignments/s", "n_gpus": world, "steps": args.steps,
@@ -333,17 +449,20 @@ def main():
                        "partitions": P, "nodes": N, "assignments_per_call": assignments,
                        "sweeps_per_call": iterations, "parallelism": "replicas x%d" % world,
                        "steps_bulk": int(batched), "steps_one_by_one": int(sequential),
-                       "headline": bool(args.config == 3 and headline_shape and not args.periodic),
-                       **({"opt_in": "periodic all-blank chain pass (k_period.h): two periods walked per region, the periodic "
-                                     "stretch copied; the roofline blocks below describe the default kernels, not this run's"}
-                          if args.periodic else {})},
+                       "headline": bool(args.config == 3 and headline_shape and not args.no_periodic),
+                       **({"not_default": "--no-periodic: the all-blank chain pass walks every step (the default copies the periodic stretch, k_period.h)"}
+                          if args.no_periodic else {})},
             "roofline": dict(dom, **{
                 "reference_dense_scan_equivalent_GBps": dense,
+                "survey_8d_whole_call": {"bytes": float(dense_call), "GBps": dense, "frac": dense / HBM_PEAK_GBS},
                 "whole_call": whole,
-                "note": "the dominant kernel is bound by the instruction issue of one dependent chain per wave (one wave64 per "
-                        "hierarchy region; critical_path), not by HBM: frac is the honest HBM fraction of the bytes its schedule "
-                        "moves; reference_dense_scan_equivalent_GBps prices this run's device time at the bytes the reference's "
-                        "dense per-step scan would read (SURVEY.md 8d) -- not executed work, may exceed the HBM peak"}),
+                "note": "two byte models, side by side.  frac = SCHEDULE bytes (what this implementation has to move per launch: one record in, "
+                        "one choice out per step) over the launch time over 8 TB/s -- small, because the dominant kernel is bound by the "
+                        "instruction issue of one dependent chain per wave (critical_path), not by HBM; traffic = the PMC counters' bytes for "
+                        "the same launch.  survey_8d_frac = the bytes SURVEY.md 8(d) prices the same pass at (the reference's dense scan of "
+                        "every node per step: N x (16 + 4k) + 40 bytes per step) over the same time: it EXCEEDS 1 because that scan is not "
+                        "executed -- the kernels keep the load tables in registers / LDS and read one record per step -- so 8(d)'s model "
+                        "does not describe this implementation's memory traffic (results are bit-identical by digest)"}),
             "roofline_per_kernel": kernels,
             "device_ms_per_step": acc["device_ms"] / args.steps,
             "pass_kernel_ms_per_step": acc["pass_ms"] / args.steps, "flat_pass_ms_per_step": acc["flat_ms"] / args.steps,
@@ -362,8 +481,10 @@ def main():
                               "not applicable: flat passes are one chain (DESIGN.md 7); only config 3's region chains shard")
             if args.config == 3 and not args.no_sharded:
                 out["sharded_on_one_gpu"] = sharded_on_one_gpu(fp, digest, local_rank, dt / args.steps)
+        if world == 1 and args.config == 3 and not args.no_extra:
+            out["general_regime"] = general_regime(pl, fp, res, max(1, min(args.steps, 5)))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config)
+            out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config, full=args.cpu_full)
             out["host_end_to_end"] = host_end_to_end(args.config)
     # ---- one plan over all ranks (config 4).  The line of the replicas is ready before this starts: RCCL is bound at
     # run time inside the library and has never met this node, so a watchdog prints that line if the leg does not return.

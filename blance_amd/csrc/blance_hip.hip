@@ -105,6 +105,8 @@ struct blance_ctx {
     bool no_planes = false;         // test knob (& 32): the all-blank chain pass on k_pass_chain_blank, not k_pass_chain_planes
     bool no_queue = false;          // test knob (& 512): flat passes with k <= 2 on k_pass_tree, never on k_pass_queue
     bool queue_general = false;     // test knob (& 1024): k_pass_queue without its lean walk
+    bool queue_no_asm = false;      // test knob (& 4096): k_pass_queue's lean walk as compiled C++ only
+    bool queue_force_dense = false; // test knob (& 2048): every general step of k_pass_queue scores every node
     DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
     bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
     int64_t queue_launches = 0, queue_stops = 0, queue_moved = 0, queue_exact = 0, queue_rebuilds = 0, queue_dense = 0;
@@ -315,6 +317,8 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->no_planes = opt && (opt->reserved[2] & 32);
     c->no_queue = opt && (opt->reserved[2] & 512);
     c->queue_general = opt && (opt->reserved[2] & 1024);
+    c->queue_force_dense = opt && (opt->reserved[2] & 2048);
+    c->queue_no_asm = opt && (opt->reserved[2] & 4096);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->periodic = !(opt && (opt->reserved[2] & 256));
@@ -643,7 +647,7 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
     q.ntn_bits = c->ntn_bits.as<uint32_t>();
     q.stop = scal + 16;
     q.qstats = (long long*)(scal + 18);
-    q.spec = c->queue_general ? 8 : 0;
+    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0);
     int pos = q0.beg, chunk = 64;
     while (pos < q0.end) {
         q.beg = pos; q.end = q0.end;

@@ -42,9 +42,25 @@ constexpr int kQStopNone = 0, kQStopShape = 1, kQStopShort = 3, kQStopPromote = 
 #ifndef BLANCE_SIMT_EMU
 #define BLANCE_QLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define BLANCE_QFENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent")
+// This kernel is one wave on one CU: its atomics and its loads meet in the same L2, so "my bumps are done before I read
+// again" needs no cache maintenance, only (a) the bumps acknowledged (vmcnt) and (b) reads that do not hit a stale L1 line
+// -- the scoped loads above and the 16-byte row loads below (sc0 sc1: past the L1).  The full fence (L2 write-back and
+// invalidate) stays where it is rare.
+#define BLANCE_QWAIT_BUMPS() __builtin_amdgcn_s_waitcnt(0x0F70)      /* vmcnt(0): gfx9 counts returnless atomics there too */
+typedef int qv4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ qv4 q_load_row16(const qv4* p) {
+    qv4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+#define BLANCE_QROWS_ARRIVED(v) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
 #else
 #define BLANCE_QLD(p) (*(p))
 #define BLANCE_QFENCE()
+#define BLANCE_QWAIT_BUMPS()
+typedef int4 qv4;
+static inline qv4 q_load_row16(const qv4* p) { return *p; }
+#define BLANCE_QROWS_ARRIVED(v)
 #endif
 
 // lane i takes lane i - 1's value (lane 0: fill) / lane i + 1's value (lane 63: fill): DPP wave shifts
@@ -104,6 +120,10 @@ __device__ __forceinline__ QMin wave_min_key_node(unsigned long long key, int no
     return r;
 }
 
+}  // namespace blance
+#include "k_queue_walk.h"
+namespace blance {
+
 template <int KM>
 __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     static_assert(KM == 2, "k <= 2");
@@ -159,6 +179,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
         shL[n] = (unsigned char)sh;
         if ((fl & 1) && sh == 255) odd_weight = true;
     }
+    u64 alivecol = 0;                                // bit i: node 64 i + lane is in nodesNext (and inside nodesAll)
+    for (int i = 0; i < G; i++) if (i * 64 + lane < N && (flL[i * 64 + lane] & 1)) alivecol |= 1ull << i;
     const bool lean_ok = __ballot(odd_weight) == 0 && !(q.spec & 8);      // (q.spec & 8: test knob, every step through the general code)
     BLANCE_WAVE_SYNC();
     for (int i = 0; i < G; i++) gB[i * 64 + lane] = gkey(i * 64 + lane);
@@ -171,38 +193,74 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     u64 thK = ~0ull;                                 // THETA: every node outside the window has (g, node) >= it
     int thN = INT_MAX;
     long long n_rebuild = 0;
+#ifdef BLANCE_PHASE_PROF
+    long long rb_cycles = 0, rb_scans = 0, rb_scan_cycles = 0;
+#endif
     auto rebuild = [&]() {
+#ifdef BLANCE_PHASE_PROF
+        const long long rb_t0 = clock64();
+#endif
         // 64 + 1 successive minima of the keys in LDS; lane l owns nodes l, 64 + l, ... (bit i of `taken`: node 64 i + l)
-        // and keeps its two smallest untaken keys, so that a column is scanned again only when both are gone
+        // and keeps its four smallest untaken keys, so that a column is scanned again only when all four are gone
+        // (64 minima over 64 columns: a column with five of them is rare)
+        constexpr int RC = 4;
         u64 taken = 0;
         wk = ~0ull; wn = INT_MAX; wcnt = 0; thK = ~0ull; thN = INT_MAX;
-        u64 a1 = ~0ull, a2 = ~0ull;
-        int m1 = INT_MAX, m2 = INT_MAX;
+        u64 ca[RC];
+        int cm[RC];
         bool exhausted = false;
-        auto scan2 = [&]() {
-            a1 = ~0ull; a2 = ~0ull; m1 = INT_MAX; m2 = INT_MAX;
-            for (int i = 0; i < G; i++) {
-                const u64 v = gB[i * 64 + lane];
-                if ((taken >> i) & 1) continue;
-                if (v < a1) { a2 = a1; m2 = m1; a1 = v; m1 = i * 64 + lane; }      // ascending i: ties keep the lower node
-                else if (v < a2) { a2 = v; m2 = i * 64 + lane; }
+        auto scan4 = [&]() {
+#pragma unroll
+            for (int j = 0; j < RC; j++) { ca[j] = ~0ull; cm[j] = INT_MAX; }
+            for (int i0 = 0; i0 < G; i0 += 8) {      // (8 independent LDS reads at a time)
+                u64 kv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    u64 v = kv[u];
+                    int n = (i0 + u) * 64 + lane;
+                    if (((taken >> (i0 + u)) & 1) || v == ~0ull) continue;
+                    bool placed = false;             // ascending i: ties keep the lower node in front; what follows moves down
+#pragma unroll
+                    for (int j = 0; j < RC; j++) {
+                        if (placed || v < ca[j]) { const u64 tv = ca[j]; const int tn = cm[j]; ca[j] = v; cm[j] = n; v = tv; n = tn; placed = true; }
+                    }
+                }
             }
-            if (m1 == INT_MAX) exhausted = true;
+            if (cm[0] == INT_MAX) exhausted = true;
+#ifdef BLANCE_PHASE_PROF
+            rb_scans++;
+#endif
         };
-        scan2();
+#ifdef BLANCE_PHASE_PROF
+        const long long rb_t1 = clock64();
+#endif
+        scan4();
+#ifdef BLANCE_PHASE_PROF
+        rb_scan_cycles += clock64() - rb_t1;
+#endif
         for (int e = 0; e <= 64; e++) {
-            const QMin m = wave_min_key_node(a1, m1);
+            const QMin m = wave_min_key_node(ca[0], cm[0]);
             if (m.node == INT_MAX) break;            // fewer than 65 candidates: THETA stays infinite
             const u64 mk = ((u64)m.hi << 32) | m.lo;
             if (e < 64) {
                 if (lane == e) { wk = mk; wn = m.node; }
                 wcnt = uni(e + 1);
             } else { thK = uni64(mk); thN = uni(m.node); }
-            if (m1 == m.node) { taken |= 1ull << (m.node >> 6); a1 = a2; m1 = m2; a2 = ~0ull; m2 = INT_MAX; }
-            const bool dry = m1 == INT_MAX && !exhausted;
-            if (__ballot(dry)) { if (dry) scan2(); }
+            if (cm[0] == m.node) {
+                taken |= 1ull << (m.node >> 6);
+#pragma unroll
+                for (int j = 0; j + 1 < RC; j++) { ca[j] = ca[j + 1]; cm[j] = cm[j + 1]; }
+                ca[RC - 1] = ~0ull; cm[RC - 1] = INT_MAX;
+            }
+            const bool dry = cm[0] == INT_MAX && !exhausted;
+            if (__ballot(dry)) { if (dry) scan4(); }
         }
         n_rebuild++;
+#ifdef BLANCE_PHASE_PROF
+        rb_cycles += clock64() - rb_t0;
+#endif
     };
     rebuild();
     // remove node x from the window if it is there; insert (key, x) if below THETA
@@ -239,17 +297,52 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 
     PH_DECL;
     long long n_bulk = 0, n_moved = 0, n_exact = 0, n_dense = 0, n_bound = 0;
+#ifndef BLANCE_SIMT_EMU
+    // the assembly walk (k_queue_walk.h): k = 2, NumPartitions > 0, power-of-two node weights; q.spec & 32: test knob, never
+    const bool walk_asm = lean_ok && k == 2 && NP > 0 && KM == 2 && !(q.spec & 32) && NXp <= 4096;
+    const int cfa = (int)((((unsigned)(size_t)cntL) >> 2) | ((((unsigned)(size_t)totL) >> 2) << 16));
+    const int cfb = (int)((((unsigned)(size_t)shL) >> 2) | ((((unsigned)(size_t)ffT) >> 2) << 16));
+    const int cfc = (int)((((unsigned)(size_t)bitsL) >> 2) | ((unsigned)(BW * 4) << 16));
+    int cfd = (int)(((unsigned)(size_t)gB) >> 2);   // | B << 16, per batch
+    int mo1 = 0, mo2 = 0;                            // output nodes of the lanes the assembly walk moved
+    const u64 lp_one = uni64((u64)__double_as_longlong(NP > 0 ? (double)1 / (double)NP : 0.0));      // = lpT[1], as bits
+#endif
     int stop_pos = q.end, stop_why = kQStopNone;
 
     PH(11);
+    constexpr int kRecPre = 16;                      // step records of up to 16 words are fetched a batch ahead
+    int pre[kRecPre];
+    {
+        const int B0 = q.end - q.beg < 64 ? q.end - q.beg : 64;
+#pragma unroll
+        for (int r = 0; r < kRecPre; r++) {
+            const int idx = r * 64 + lane;
+            pre[r] = (r < RW && RW <= kRecPre && idx < B0 * RW) ? q.rec[(size_t)q.beg * RW + idx] : 0;
+        }
+    }
     for (int oi = q.beg; ; oi += 64) {
         oi = uni(oi); wcnt = uni(wcnt); stop_why = uni(stop_why);
         if (oi >= q.end || stop_why != kQStopNone) break;
         const int B = q.end - oi < 64 ? q.end - oi : 64;
-        BLANCE_QFENCE();                             // earlier bumps of nodeToNodeCounts / its bit maps are visible below
-        for (int r = 0; r < RW; r++) {
-            const int idx = r * 64 + lane;
-            if (idx < B * RW) recS[idx] = q.rec[(size_t)oi * RW + idx];
+        BLANCE_QWAIT_BUMPS();                        // earlier bumps of nodeToNodeCounts / its bit maps are done before the reads below
+        if (RW <= kRecPre) {
+            // (the records of this batch were fetched while the last one was walked; now the next batch's are started)
+#pragma unroll
+            for (int r = 0; r < kRecPre; r++) {
+                const int idx = r * 64 + lane;
+                if (r < RW && idx < B * RW) recS[idx] = pre[r];
+            }
+            const int on = oi + 64, Bn = q.end - on < 64 ? q.end - on : 64;
+#pragma unroll
+            for (int r = 0; r < kRecPre; r++) {
+                const int idx = r * 64 + lane;
+                pre[r] = (r < RW && on < q.end && idx < Bn * RW) ? q.rec[(size_t)on * RW + idx] : 0;
+            }
+        } else {
+            for (int r = 0; r < RW; r++) {
+                const int idx = r * 64 + lane;
+                if (idx < B * RW) recS[idx] = q.rec[(size_t)oi * RW + idx];
+            }
         }
         BLANCE_WAVE_SYNC();
 
@@ -343,26 +436,30 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
             }
         }
         // ---- the row bit maps of the batch's steps: lanes 0..31 / 32..63 copy one 4 BW-byte row each per round
-        // (plain 16-byte loads: the fence above invalidated this CU's L1, and nothing bumps the maps before the batch ends)
+        // (16-byte loads past the L1; nothing bumps the maps before the batch ends)
         if (NP > 0 && !fold) {
             const int BQ = BW >> 2;
             if (BQ <= 32) {
-                // (8 rounds' loads in flight at once: one round trip to the L2 per 16 rows, not per 2)
-                for (int r8 = 0; r8 < B; r8 += 16) {
-                    int4 v[8];
+                // (all 32 rounds' loads in flight at once -- 128 registers, the wave has the file to itself -- one round trip to the L2)
+                qv4 v[4][8];
+#pragma unroll
+                for (int g8 = 0; g8 < 4; g8++) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        const int r2 = r8 + 2 * u;
-                        const int ra = r2 < 64 ? r2 : 63, rb = r2 + 1 < 64 ? r2 + 1 : 63;
-                        const int row_r = __builtin_amdgcn_readlane(row, ra), row_r1 = __builtin_amdgcn_readlane(row, rb);
+                        const int r2 = 16 * g8 + 2 * u;
+                        const int row_r = __builtin_amdgcn_readlane(row, r2), row_r1 = __builtin_amdgcn_readlane(row, r2 + 1);
                         const int myrow = (lane >> 5) ? row_r1 : row_r;
                         const int c = lane & 31;
-                        v[u] = (r2 + (lane >> 5) < B && c < BQ) ? ((const int4*)q.ntn_bits)[(size_t)myrow * BQ + c] : int4{0, 0, 0, 0};
+                        v[g8][u] = q_load_row16((const qv4*)q.ntn_bits + (size_t)((r2 + (lane >> 5) < B && c < BQ) ? myrow : 0) * BQ + (c < BQ ? c : 0));
                     }
+                }
+#pragma unroll
+                for (int g8 = 0; g8 < 4; g8++) {
+                    BLANCE_QROWS_ARRIVED(v[g8]);
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        const int rr = r8 + 2 * u + (lane >> 5), c = lane & 31;
-                        if (rr < B && c < BQ) ((int4*)bitsL)[rr * BQ + c] = v[u];
+                        const int rr = 16 * g8 + 2 * u + (lane >> 5), c = lane & 31;
+                        if (rr < B && c < BQ) ((qv4*)bitsL)[rr * BQ + c] = v[g8][u];
                     }
                 }
             } else {
@@ -370,8 +467,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                     const int rr = r2 + (lane >> 5);
                     const int row_r = __builtin_amdgcn_readlane(row, r2), row_r1 = __builtin_amdgcn_readlane(row, r2 + 1 < 64 ? r2 + 1 : r2);
                     const int myrow = (lane >> 5) ? row_r1 : row_r;
-                    for (int c = (lane & 31); c < BQ; c += 32)
-                        if (rr < B) ((int4*)bitsL)[rr * BQ + c] = ((const int4*)q.ntn_bits)[(size_t)myrow * BQ + c];
+                    for (int c = (lane & 31); c < BW; c += 32)
+                        if (rr < B) bitsL[rr * BW + c] = BLANCE_QLD(q.ntn_bits + (size_t)myrow * BW + c);
                 }
             }
         }
@@ -481,7 +578,30 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
             if (lane == 0) printf("[q3] outer cur %d B %d wcnt %d\n", cur, B, wcnt);
 #endif
             int f = B;
-            bool retried = false;
+            bool retried = false, back_to_asm = false;
+#ifndef BLANCE_SIMT_EMU
+            // ================= the lean walk in assembly (k_queue_walk.h) for the plain case; it leaves at a step it does not take
+            if (walk_asm && !fold) {
+                QueueWalkState st;
+                st.wk = wk; st.wn = wn; st.o1 = mo1; st.o2 = mo2; st.cur = cur; st.wcnt = wcnt; st.thK = thK; st.thN = thN;
+                st.stale = stalemask; st.moved = 0; st.code = 0;
+                queue_walk_k2(st, lastK, lastN, own_a, own_b, sKv[0], sKv[1], hv[0], wj, (ov0 & 0xffff) | (ov1 << 16), lane,
+                              sfailmask | dirtymask, slowmask, actmask, cfa, cfb, cfc, (cfd & 0xffff) | (B << 16), lp_one);
+                wk = st.wk; wn = st.wn; mo1 = st.o1; mo2 = st.o2;
+                const int c1_ = uni(st.cur);
+                wcnt = uni(st.wcnt); thK = uni64(st.thK); thN = uni(st.thN); stalemask = uni64(st.stale);
+                const u64 mv = uni64(st.moved);
+                if ((mv >> lane) & 1) {              // plan.go:299: the steps that moved (their rows are bumped with the batch's)
+                    int* o = outS + lane * OWs;
+                    o[0] = 2; o[1] = mo1; o[2] = mo2;
+                }
+                const int nm = __popcll(mv);
+                n_moved += nm;
+                n_bulk += (c1_ - cur) - nm;
+                cur = c1_;
+                if (uni(st.code) == 0 || cur >= B) break;
+            }
+#endif
             // ================= the lean walk: steps in order as long as they stay or move the plain way =================
             // (a step whose two best candidates are the first eligible entries of the window, none of them with a
             // nodeToNodeCounts entry, all nodes' weights powers of two: one pass of straight-line code per step)
@@ -628,8 +748,12 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 }
                 cur = f + 1;
                 retried = false;
+#ifndef BLANCE_SIMT_EMU
+                if (walk_asm && !fold) { back_to_asm = true; break; }
+#endif
             }
             PH(4);
+            if (back_to_asm) continue;
             if (f >= B) break;
             cur = f;
             if (fold) { stop_pos = oi + f; stop_why = kQStopShape; break; }        // (the general code reads the matrix, not the folded row)
@@ -709,7 +833,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 }
             };
             int n_out = 0;
-            for (int attempt = 0; ; attempt++) {
+            for (int attempt = (q.spec & 16) ? 2 : 0; ; attempt++) {      // (q.spec & 16: test knob, every general step scores every node)
                 attempt = uni(attempt);
 #pragma unroll
                 for (int j = 0; j < KM; j++) { bB[j] = ~0ull; bN[j] = INT_MAX; }
@@ -723,27 +847,90 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                     int ln[KM];
 #pragma unroll
                     for (int j = 0; j < KM; j++) { lb[j] = ~0ull; ln[j] = INT_MAX; }
-                    for (int i = 0; i < G; i++) {
-                        const int n = i * 64 + lane;
+                    auto keep_local = [&](u64 b, int n) {               // the lane's own k best, ascending
+#pragma unroll
+                        for (int j = KM - 1; j >= 0; j--) {
+                            const bool here = qless(b, n, lb[j], ln[j]);
+                            const bool above = j > 0 && qless(b, n, lb[j - 1], ln[j - 1]);
+                            if (here) {
+                                if (above) { lb[j] = lb[j - 1]; ln[j] = ln[j - 1]; }
+                                else { lb[j] = b; ln[j] = n; }
+                            }
+                        }
+                    };
+                    auto is_cand = [&](int n) -> bool {
                         bool el = n < N && (flL[n] & 1);
 #pragma unroll
                         for (int j = 0; j < KM; j++) if (qown[j] == n) el = false;      // own: scored above
 #pragma unroll
                         for (int j = 0; j < KH; j++) if (qh[j] == n) el = false;        // plan.go:146-154
-                        if (el) {
-                            const int nt = NP > 0 ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
-                            const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
-                                                                         q.booster_kind, lpT, ffT)) : gB[n];
+                        return el;
+                    };
+                    if (NP > 0 && have_bits) {
+                        // the row's bit map says which entries are zero: (A) the k best of those, by their keys in LDS; (B) a node
+                        // with an entry is read from the matrix only if its score with an entry of 1 -- a lower bound -- does
+                        // not lie above the k-th of (A).  Lane l looks at nodes l, 64 + l, ...: bit i of the masks = node 64 i + l.
+                        u64 cand = alivecol, dirtycol = 0;
 #pragma unroll
-                            for (int j = KM - 1; j >= 0; j--) {      // the lane's own k best, ascending
-                                const bool here = qless(b, n, lb[j], ln[j]);
-                                const bool above = j > 0 && qless(b, n, lb[j - 1], ln[j - 1]);
-                                if (here) {
-                                    if (above) { lb[j] = lb[j - 1]; ln[j] = ln[j - 1]; }
-                                    else { lb[j] = b; ln[j] = n; }
+                        for (int j = 0; j < KM; j++) if (qown[j] >= 0 && (qown[j] & 63) == lane) cand &= ~(1ull << (qown[j] >> 6));
+#pragma unroll
+                        for (int j = 0; j < KH; j++) if (qh[j] >= 0 && (qh[j] & 63) == lane) cand &= ~(1ull << (qh[j] >> 6));
+                        for (int i0 = 0; i0 < G; i0 += 8) {            // (8 independent LDS reads at a time)
+                            unsigned wv[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) wv[u] = i0 + u < G ? bitsL[f * BW + 2 * (i0 + u) + (lane >> 5)] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 8; u++) dirtycol |= (u64)((wv[u] >> (lane & 31)) & 1) << (i0 + u);
+                        }
+                        for (int i0 = 0; i0 < G; i0 += 8) {
+                            u64 kv[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+                            for (int u = 0; u < 8; u++)
+                                if (((cand & ~dirtycol) >> (i0 + u)) & 1) keep_local(kv[u], (i0 + u) * 64 + lane);
+                        }
+                        u64 cK = ~0ull;                              // the k-th best clean key over the wave (~0: fewer than k)
+                        {
+                            u64 tb[KM];
+                            int tn[KM];
+#pragma unroll
+                            for (int j = 0; j < KM; j++) { tb[j] = lb[j]; tn[j] = ln[j]; }
+                            for (int j = 0; j < k; j++) {
+                                const QMin m = wave_min_key_node(tb[0], tn[0]);
+                                cK = m.node == INT_MAX ? ~0ull : (((u64)m.hi << 32) | m.lo);
+                                if (tn[0] == m.node) {
+#pragma unroll
+                                    for (int e = 0; e + 1 < KM; e++) { tb[e] = tb[e + 1]; tn[e] = tn[e + 1]; }
+                                    tb[KM - 1] = ~0ull; tn[KM - 1] = INT_MAX;
                                 }
                             }
                         }
+                        for (u64 dd = cand & dirtycol; dd; dd &= dd - 1) {
+                            const int n = (__ffsll((long long)dd) - 1) * 64 + lane;
+                            if (gB[n] > cK) continue;
+                            const int tt = totL[n];
+                            double r = (double)cntL[n];
+                            r = r + lpT[1];
+                            r = r + ((unsigned)tt < (unsigned)kFfTab ? ffT[tt] : (0.001 * (double)tt) / (double)NP);
+                            bool maybe = true;
+                            if (shL[n] != 255) { r = ldexp(r, -(int)shL[n]); r = r - 0.0; maybe = !(sortable_bits(r) > cK); }
+                            if (!maybe) continue;
+                            const int nt = BLANCE_QLD(q.ntn + (size_t)rowf * N + n);
+                            const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                                         q.booster_kind, lpT, ffT)) : gB[n];
+                            keep_local(b, n);
+                        }
+                    } else {
+                    for (int i = 0; i < G; i++) {
+                        const int n = i * 64 + lane;
+                        if (is_cand(n)) {
+                            const int nt = NP > 0 ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
+                            const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                                         q.booster_kind, lpT, ffT)) : gB[n];
+                            keep_local(b, n);
+                        }
+                    }
                     }
                     for (int j = 0; j < k; j++) {
                         const QMin m = wave_min_key_node(lb[0], ln[0]);
@@ -823,21 +1010,30 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
             PH(6);
             if (n_out < k) { stop_pos = oi + f; stop_why = kQStopShort; }      // fewer candidates than constraints: warnings
             if (stop_why != kQStopNone) { cur = f; break; }
-            // a taken node the partition holds in a lower priority state would be promoted: k_pass_tree's business
+            // a taken node that the partition holds in lower priority states is promoted (plan.go:294-297): it leaves those
+            // lists -- their counters drop (only lane 0 touches them), and so does the node's total
+            int promo[KM];                           // lists of lower priority states that hold the e-th taken node
+#pragma unroll
+            for (int e = 0; e < KM; e++) promo[e] = 0;
             if (other_f) {
                 const int* rf = recS + f * RW;
-                bool prom = false;
                 for (int t = 0; t < M; t++) {
                     if (t == s || ((q.higher_mask >> t) & 1)) continue;
                     const int h = rf[kRecHead + t * SW];
                     if ((h >> 16) == kListAbsent) continue;
                     for (int jj = 0; jj < (h & 0xffff); jj++) {
                         const int x = rf[kRecHead + t * SW + 1 + jj];
+                        bool first = true;           // (a node twice in one list counts once: misc.go:45)
+                        for (int j2 = 0; j2 < jj; j2++) if (rf[kRecHead + t * SW + 1 + j2] == x) first = false;
 #pragma unroll
-                        for (int j = 0; j < KM; j++) if (j < k && bN[j] == x) prom = true;
+                        for (int e = 0; e < KM; e++) {
+                            if (e < k && bN[e] == x && first) {
+                                promo[e]++;
+                                if (lane == 0) q.cnt[t * NX + x] -= w;
+                            }
+                        }
                     }
                 }
-                if (prom) { stop_pos = oi + f; stop_why = kQStopPromote; cur = f; break; }
             }
             // ---- commit (plan.go:290-301): own nodes not taken leave, taken nodes that are not own enter
             n_moved++;
@@ -872,8 +1068,11 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
             for (int j = 0; j < 2 * KM; j++) if (lane == j) hx = chg[j];
             if (hx >= 0) {
                 const int ds = lane < KM ? -w : w;
+                int np = 0;
+#pragma unroll
+                for (int e = 0; e < KM; e++) if (lane == KM + e) np = promo[e];
                 cntL[hx] += ds;
-                totL[hx] += ds;
+                totL[hx] += ds - w * np;
                 nk = gkey(hx);
                 gB[hx] = nk;
             }
@@ -914,6 +1113,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     if (lane == 0) {
         printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild);
         for (int i_ = 0; i_ < 12; i_++) printf("[queue phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
+        printf("[queue rebuilds] %.0f kcycles, %lld column scans of lane 0 (first scans: %.0f kcycles)\n", (double)rb_cycles / 1e3, rb_scans, (double)rb_scan_cycles / 1e3);
     }
 #endif
     if (lane == 0) {

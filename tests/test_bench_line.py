@@ -96,20 +96,28 @@ def test_live_line_of_a_rehearsal_has_the_same_fields():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["sample"]
 
 
-def test_periodic_run_of_the_bench_is_not_a_headline():
-    """bench.py --periodic (the opt-in pass of DESIGN.md 4.1c) on the CPU rehearsal: same result as the default run of the
-    same shape, and the line says that it is an opt-in run, not the headline."""
+def test_bench_without_the_periodic_form_is_not_a_headline():
+    """bench.py --no-periodic (every step of the all-blank chain pass walked) on the CPU rehearsal: same result as the default
+    run of the same shape, the line says it is not the default; the default line carries both byte models of the roofline
+    block and the general_regime block (two more workloads of the same size)."""
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_simt_emulated import build_emu
     env = dict(os.environ, BLANCE_BENCH_REHEARSAL=build_emu())
     got = {}
-    for flag in ([], ["--periodic"]):
+    for flag in ([], ["--no-periodic", "--no-extra"]):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--parts", "4096", "--nodes", "256", "--steps", "1",
                               "--warmup", "0", "--no-sharded", "--no-cpu-baseline"] + flag, env=env, capture_output=True,
                              text=True, timeout=900)
         assert out.returncode == 0, out.stdout + out.stderr
         got[bool(flag)] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert got[True]["result_sha256"] == got[False]["result_sha256"]
-    assert "opt_in" in got[True]["config"] and got[True]["config"]["headline"] is False
-    assert "opt_in" not in got[False]["config"]
+    assert "not_default" in got[True]["config"] and got[True]["config"]["headline"] is False
+    assert "not_default" not in got[False]["config"]
+    roof = got[False]["roofline"]
+    for key in ("frac", "survey_8d_frac", "survey_8d_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic", "traffic_from", "note"):
+        assert key in roof, key
+    assert roof["survey_8d_bytes_per_launch"] > roof["algorithmic_bytes_per_launch"]
+    gr = got[False]["general_regime"]
+    assert len(gr) == 2 and all("error" not in w and w["headline"] is False and w["ms_per_step"] > 0 for w in gr), gr
+    assert "general_regime" not in got[True]

@@ -41,6 +41,21 @@ def test_golden_cases_queue(emu_lib, golden_cases, lean):
         pl.close()
 
 
+def test_random_instances_queue_dense(emu_lib):
+    pl = hip.Planner(lib_path=emu_lib, queue="dense")
+    n = 0
+    for seed in range(700, 860):
+        try:
+            fp = build_from_case(random_case(seed))
+        except problem.Unsupported:
+            continue
+        got, want = pl.plan(fp), _oracle(fp)
+        assert (got.digest(), got.iterations, got.n_warnings) == (want.digest(), want.iterations, want.n_warnings), seed
+        n += 1
+    assert n > 90
+    pl.close()
+
+
 @pytest.mark.parametrize("lean", [True, False])
 def test_random_instances_queue(emu_lib, lean):
     pl = hip.Planner(lib_path=emu_lib, queue="on" if lean else "general")
@@ -68,6 +83,10 @@ def test_rebalance_queue(emu_lib):
     pl.close()
     pl = hip.Planner(lib_path=emu_lib, queue="general")
     _rebalance(pl, 200, 90)
+    pl.close()
+    pl = hip.Planner(lib_path=emu_lib, queue="dense")       # every moving step scores every node (bit map, bound, matrix)
+    _rebalance(pl, 300, 150)
+    _rebalance(pl, 200, 24)
     pl.close()
 
 
@@ -121,7 +140,7 @@ def test_odd_node_weights_queue(emu_lib):
 
 def test_edge_shapes_queue(emu_lib):
     cases = edge_cases()
-    for mode in ("on", "general"):
+    for mode in ("on", "general", "dense"):
         pl = hip.Planner(lib_path=emu_lib, queue=mode)
         for i, (a, k) in enumerate(cases):
             fp = problem.build_problem(*a, **k)
