@@ -642,8 +642,11 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     std::vector<PartitionPtr>& parts = sc.parts;
     parts.clear();
     parts.resize((size_t)P);
+    // the result's Partition objects live in ONE block (a million make_shared calls are a million control blocks): every
+    // PartitionPtr aliases the block and keeps it alive
+    auto block = std::make_shared<std::vector<Partition>>((size_t)P);
     for (int p = 0; p < P; p++) {
-        auto part = std::make_shared<Partition>();
+        PartitionPtr part(block, &(*block)[(size_t)p]);
         part->Name = f.part_names[p];
         part->NodesByState.emplace();
         auto& nbs = *part->NodesByState;
@@ -671,6 +674,15 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     // plan.go:49-52: every non-converged sweep stores its partitions into both input maps;
     // the last such store has the final map's content
     if ((res.iterations > 1 || !res.converged) && prevMap) {
+        // What the reference leaves in the input maps are the objects of the LAST SWEEP THAT DID NOT CONVERGE: when the call
+        // converged in sweep n > 1 those are sweep n - 1's -- equal in content to the returned ones (that is what converged
+        // means, plan.go:36-45) but not the same objects (plan.go:334-343 makes fresh ones every sweep), so a caller that
+        // edits nextMap[p] afterwards does not edit prevMap[p].  At the iteration cap the returned objects ARE the stored
+        // ones (plan.go:49-52 ran on them).  One clone per partition, shared by both maps as in the reference.
+        if (res.converged) {
+            auto clones = std::make_shared<std::vector<Partition>>(*block);
+            for (int p = 0; p < P; p++) parts[(size_t)p] = PartitionPtr(clones, &(*clones)[(size_t)p]);
+        }
         // the slots recorded while the maps were read: independent stores (the tree is not walked a second time);
         // names the map does not hold yet are inserted in name order, each right after its predecessor
         auto store = [&](PartitionMap& dst, const std::vector<PartitionPtr*>& slot) {

@@ -262,7 +262,18 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < kv.second.size(); i++) std::cout << (i ? "," : "") << q(kv.second[i]);
             std::cout << "]";
         }
-        std::cout << "},\"prevMap\":" << dump_map(prev) << ",\"partitionsToAssign\":" << dump_map(assign) << "}\n";
+        // object identity, as the reference leaves it (plan.go:49-52, :334-343): how many returned partitions ARE the object
+        // stored in prevMap / partitionsToAssign, and how many names hold ONE object in both input maps
+        size_t same_prev = 0, same_assign = 0, shared = 0;
+        for (auto& kv : r.nextMap) {
+            auto ip = prev.find(kv.first);
+            auto ia = assign.find(kv.first);
+            if (ip != prev.end() && ip->second.get() == kv.second.get()) same_prev++;
+            if (ia != assign.end() && ia->second.get() == kv.second.get()) same_assign++;
+            if (ip != prev.end() && ia != assign.end() && ip->second.get() == ia->second.get()) shared++;
+        }
+        std::cout << "},\"prevMap\":" << dump_map(prev) << ",\"partitionsToAssign\":" << dump_map(assign)
+                  << ",\"identity\":[" << same_prev << "," << same_assign << "," << shared << "]}\n";
     }
     std::cout << "]\n";
     return 0;

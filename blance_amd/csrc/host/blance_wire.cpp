@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -636,16 +637,13 @@ const char* blance_wire_last_error(void) { return g_err.c_str(); }
 int blance_wire_decode(const char* json, size_t len, blance_wire_map** out) try {
     if (!out || (!json && len)) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
     *out = nullptr;
-    blance_wire_map* m = new blance_wire_map();
+    std::unique_ptr<blance_wire_map> m(new blance_wire_map());      // (an exception below must not leak a half-built map)
     Decoder d;
-    d.m = m;
+    d.m = m.get();
     d.ps.b = d.ps.p = json;
     d.ps.e = json + len;
-    if (!d.document()) {
-        delete m;
-        return fail(d.ps.code ? d.ps.code : BLANCE_WIRE_ERR_SYNTAX, d.ps.msg);
-    }
-    *out = m;
+    if (!d.document()) return fail(d.ps.code ? d.ps.code : BLANCE_WIRE_ERR_SYNTAX, d.ps.msg);
+    *out = m.release();
     return BLANCE_WIRE_OK;
 } catch (const std::bad_alloc&) {
     return fail(BLANCE_WIRE_ERR_ARG, "out of memory");           // no exception crosses the C boundary
@@ -830,9 +828,11 @@ int blance_wire_encode_into(const blance_wire_view* v, char* buf, size_t cap, si
 
 int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b, blance_wire_view* view) try {
     if (!b || !view) return fail(BLANCE_WIRE_ERR_ARG, "null argument");
-    blance_wire_map* m = nullptr;
-    int st = blance_wire_decode(json, len, &m);
+    blance_wire_map* m_raw = nullptr;
+    int st = blance_wire_decode(json, len, &m_raw);
     if (st) return st;
+    std::unique_ptr<blance_wire_map> m_owner(m_raw);                // freed on every way out, exceptions included
+    blance_wire_map* m = m_raw;
     blance_wire_view v;
     blance_wire_view_of(m, &v);
     const int64_t kb = v.n_parts ? v.key_off[v.n_parts] : 0, nb = v.n_parts ? v.name_off[v.n_parts] : 0;
@@ -847,8 +847,8 @@ int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b
     // what the document needs, whether or not it fits
     b->cap_parts = v.n_parts; b->cap_states = v.n_states; b->cap_nodes = v.n_nodes; b->cap_entries = v.n_entries;
     b->cap_node_refs = v.n_node_refs; b->cap_key_bytes = kb; b->cap_name_bytes = nb; b->cap_state_bytes = sb; b->cap_node_bytes = db;
-    if (!fits) { blance_wire_free(m); return fail(BLANCE_WIRE_ERR_SPACE, "the caller's arrays are too small (sizes written to cap_*)"); }
-    if (!have) { blance_wire_free(m); return fail(BLANCE_WIRE_ERR_ARG, "null array in the buffers"); }
+    if (!fits) return fail(BLANCE_WIRE_ERR_SPACE, "the caller's arrays are too small (sizes written to cap_*)");
+    if (!have) return fail(BLANCE_WIRE_ERR_ARG, "null array in the buffers");
     auto put = [](void* dst, const void* src, size_t n) { if (n) memcpy(dst, src, n); };
     put(b->key_bytes, v.key_bytes, (size_t)kb);     put(b->key_off, v.key_off, sizeof(int64_t) * (size_t)(v.n_parts + 1));
     put(b->name_bytes, v.name_bytes, (size_t)nb);   put(b->name_off, v.name_off, sizeof(int64_t) * (size_t)(v.n_parts + 1));
@@ -868,7 +868,6 @@ int blance_wire_decode_into(const char* json, size_t len, blance_wire_buffers* b
     view->node_bytes = b->node_bytes;   view->node_off = b->node_off;
     view->entry_state = b->entry_state; view->entry_kind = b->entry_kind;
     view->entry_off = b->entry_off;     view->entry_nodes = b->entry_nodes;
-    blance_wire_free(m);
     return BLANCE_WIRE_OK;
 } catch (const std::bad_alloc&) {
     return fail(BLANCE_WIRE_ERR_ARG, "out of memory");           // no exception crosses the C boundary

@@ -12,7 +12,7 @@
 //   * the nodes that have any pending move are a dense list -- a supply round touches those nodes only;
 //   * lowest_weight(node, count) is what filterNextPlausibleMovesForNode yields under the reference's default
 //     FindMoveFunc LowestWeightPartitionMoveForNode (orchestrate.go:174-184, MoveOpWeight :187-192): `count`
-//     moves in ascending op weight -- promote, demote, add, del.  Which partition comes first among equal
+//     moves in ascending op weight -- (unknown ops, weight 0), promote, demote, add, del.  Which partition comes first among equal
 //     weights is not specified by the reference (it ranges over a Go map, orchestrate.go:755); any member of the
 //     lowest non-empty op class is a valid answer, and that is what the equivalence test checks;
 //   * bucket(node) lists everything pending for a node, for an application FindMoveFunc (O(bucket), still no
@@ -25,7 +25,10 @@
 
 namespace blance {
 
-enum MoveOp : int8_t { kOpPromote = 0, kOpDemote = 1, kOpAdd = 2, kOpDel = 3 };   // ascending MoveOpWeight
+// op classes in ascending MoveOpWeight (orchestrate.go:187-192); an op the reference's table does not know weighs 0 there
+// (a missing map key) and ranks BEFORE promote: class 0
+enum MoveOp : int8_t { kOpUnknown = 0, kOpPromote = 1, kOpDemote = 2, kOpAdd = 3, kOpDel = 4 };
+constexpr int kMoveOpClasses = 5;
 
 struct NodeStateOpId { int32_t node; int32_t state; int8_t op; };
 
@@ -37,21 +40,24 @@ struct NextMovesId {                       // NextMoves, orchestrate.go:194-212,
 class MoveIndex {
 public:
     MoveIndex(int n_nodes, const std::vector<NextMovesId>* all)
-        : all_(all), buckets_((size_t)n_nodes * 4), pending_(n_nodes, 0), active_pos_(n_nodes, -1),
+        : all_(all), buckets_((size_t)n_nodes * kMoveOpClasses), pending_(n_nodes, 0), active_pos_(n_nodes, -1),
           where_(all->size(), -1) {
         for (size_t p = 0; p < all->size(); p++) insert((int32_t)p);
     }
 
-    // nodes with at least one pending move (the key set of findAvailableMovesUnlocked's map)
+    // nodes with at least one pending move (the key set of findAvailableMovesUnlocked's map).  The Go form hands out
+    // SNAPSHOTS taken under the orchestrator's lock (go/blance/orchestrate_index.go "LOCKING"): advanced() reorders this
+    // list and the buckets, so nothing here may be iterated while moves complete concurrently.
     const std::vector<int32_t>& active_nodes() const { return active_; }
+    std::vector<int32_t> active_snapshot() const { return active_; }
     int64_t pending_total() const { return total_; }
     int32_t pending(int node) const { return pending_[node]; }
 
     // up to `count` partitions whose next move goes to `node`, ascending op weight
     void lowest_weight(int node, int count, std::vector<int32_t>* out) const {
         out->clear();
-        for (int op = 0; op < 4 && count > 0; op++) {
-            const std::vector<int32_t>& b = buckets_[(size_t)node * 4 + op];
+        for (int op = 0; op < kMoveOpClasses && count > 0; op++) {
+            const std::vector<int32_t>& b = buckets_[(size_t)node * kMoveOpClasses + op];
             for (size_t i = 0; i < b.size() && count > 0; i++, count--) out->push_back(b[i]);
         }
     }
@@ -59,8 +65,8 @@ public:
     // every partition whose next move goes to `node` (for an application's own FindMoveFunc)
     void bucket(int node, std::vector<int32_t>* out) const {
         out->clear();
-        for (int op = 0; op < 4; op++) {
-            const std::vector<int32_t>& b = buckets_[(size_t)node * 4 + op];
+        for (int op = 0; op < kMoveOpClasses; op++) {
+            const std::vector<int32_t>& b = buckets_[(size_t)node * kMoveOpClasses + op];
             out->insert(out->end(), b.begin(), b.end());
         }
     }
@@ -78,15 +84,17 @@ private:
         const NextMovesId& nm = (*all_)[p];
         if (nm.next >= (int32_t)nm.moves.size()) { where_[p] = -1; return; }     // nothing left for this partition
         const NodeStateOpId& m = nm.moves[nm.next];
-        std::vector<int32_t>& b = buckets_[(size_t)m.node * 4 + m.op];
+        std::vector<int32_t>& b = buckets_[(size_t)m.node * kMoveOpClasses + m.op];
         where_[p] = (int32_t)b.size();
         b.push_back(p);
         if (pending_[m.node]++ == 0) { active_pos_[m.node] = (int32_t)active_.size(); active_.push_back(m.node); }
         total_++;
     }
     void remove(int32_t p, int node, int op) {
-        std::vector<int32_t>& b = buckets_[(size_t)node * 4 + op];
-        const int32_t at = where_[p], last = b.back();
+        std::vector<int32_t>& b = buckets_[(size_t)node * kMoveOpClasses + op];
+        const int32_t at = where_[p];
+        if (at < 0 || at >= (int32_t)b.size() || b[at] != p) return;     // not filed: nothing to take out
+        const int32_t last = b.back();
         b[at] = last;
         where_[last] = at;
         b.pop_back();

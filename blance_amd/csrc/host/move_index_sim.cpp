@@ -18,7 +18,7 @@
 #include "move_index.hpp"
 using namespace blance;
 
-static const int kOpWeight[4] = {1, 2, 3, 4};          // MoveOpWeight, orchestrate.go:187-192 (enum order)
+static const int kOpWeight[5] = {0, 1, 2, 3, 4};       // MoveOpWeight, orchestrate.go:187-192 (enum order; 0: an op the table does not know)
 
 // moves of one partition: a plausible CalcPartitionMoves output (1..4 steps over distinct nodes)
 static void make_moves(std::mt19937_64& rng, int n_nodes, std::vector<NextMovesId>& all) {
@@ -30,7 +30,7 @@ static void make_moves(std::mt19937_64& rng, int n_nodes, std::vector<NextMovesI
             NodeStateOpId m;
             m.node = (int32_t)(rng() % n_nodes);
             m.state = (int32_t)(rng() % 2);
-            m.op = (int8_t)(rng() % 4);
+            m.op = (int8_t)(rng() % 16 == 0 ? 0 : 1 + rng() % 4);
             nm.moves.push_back(m);
         }
     }
@@ -166,7 +166,64 @@ static int timing(int P, int N, int count) {
     return 0;
 }
 
+// `replay <count>`: the partitions' move lists on stdin ("P N" then per partition "n (node state op) x n"), the
+// orchestrator's supply rounds run through the index (orchestrate.go:506-590: every round each node with pending moves is
+// offered its `count` lowest-weight next moves; all of them complete), the rescan of orchestrate.go:749-763 beside it.
+// Prints, per round, the moves carried out as "partition:position" -- tests/test_move_index.py feeds it the move lists of
+// the reference's own orchestrator fixtures (orchestrate_test.go:1049-1811).
+static int replay(int count) {
+    int P = 0, N = 0;
+    if (scanf("%d %d", &P, &N) != 2) return 2;
+    std::vector<NextMovesId> all((size_t)P);
+    for (int p = 0; p < P; p++) {
+        int n = 0;
+        if (scanf("%d", &n) != 1) return 2;
+        for (int i = 0; i < n; i++) {
+            int node, state, op;
+            if (scanf("%d %d %d", &node, &state, &op) != 3) return 2;
+            all[(size_t)p].moves.push_back(NodeStateOpId{node, state, (int8_t)op});
+        }
+    }
+    MoveIndex ix(N, &all);
+    std::vector<std::vector<int32_t>> avail((size_t)N);
+    std::vector<int32_t> picks, lst;
+    printf("{\"rounds\":[");
+    for (long round = 0;; round++) {
+        rescan(all, avail);
+        int64_t total = 0;
+        for (int n = 0; n < N; n++) {
+            ix.bucket(n, &lst);
+            std::vector<int32_t> a = avail[n], b = lst;
+            std::sort(a.begin(), a.end());
+            std::sort(b.begin(), b.end());
+            if (a != b) { printf("],\"error\":\"bucket of node %d differs from the rescan in round %ld\"}\n", n, round); return 1; }
+            total += (int64_t)a.size();
+        }
+        if (total == 0) break;
+        printf("%s[", round ? "," : "");
+        bool first = true;
+        const std::vector<int32_t> nodes = ix.active_snapshot();
+        std::vector<std::pair<int32_t, int32_t>> done;
+        for (int32_t n : nodes) {
+            ix.lowest_weight(n, count <= 0 ? 1 : count, &picks);
+            if ((int)picks.size() > (count <= 0 ? 1 : count)) { printf("],\"error\":\"too many picks\"}\n"); return 1; }
+            for (int32_t p : picks) done.emplace_back(p, all[p].next);
+        }
+        // (a partition has one next move, so it is offered by one node only: no pick twice)
+        for (auto& d : done) {
+            printf("%s\"%d:%d\"", first ? "" : ",", d.first, d.second);
+            first = false;
+            all[d.first].next++;
+            ix.advanced(d.first);
+        }
+        printf("]");
+    }
+    printf("],\"pending\":%lld}\n", (long long)ix.pending_total());
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 3 && !strcmp(argv[1], "replay")) return replay(atoi(argv[2]));
     if (argc >= 6 && !strcmp(argv[1], "check")) return check(strtoull(argv[2], nullptr, 10), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
     if (argc >= 5 && !strcmp(argv[1], "time")) return timing(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     fprintf(stderr, "usage: move_index_sim check <seed> <P> <N> <count> | time <P> <N> <count>\n");

@@ -93,10 +93,17 @@ def PlanNextMapEx(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToA
     nextMap = {name: Partition(name, p["nodesByState"]) for name, p in flat.items()}
     # plan.go:49-52: every non-converged sweep stores its partitions into BOTH input maps.
     # The last such store holds the final map's content.
+    # When the call converged (in sweep n > 1) the stored objects are sweep n - 1's: equal in content to the returned
+    # ones but distinct objects (plan.go:334-343 makes fresh ones every sweep); at the iteration cap they are the returned
+    # objects themselves.
     if res.iterations > 1 or not res.converged:
         for name, part in nextMap.items():
-            prevMap[name] = part
-            partitionsToAssign[name] = part
+            stored = part
+            if res.converged:
+                stored = Partition(part.Name, None if part.NodesByState is None else
+                                   {s: (None if l is None else list(l)) for s, l in part.NodesByState.items()})
+            prevMap[name] = stored
+            partitionsToAssign[name] = stored
     return nextMap, warnings
 
 

@@ -16,22 +16,45 @@
 //     order among equal weights is unspecified in the reference (it ranges over a Go map, orchestrate.go:755);
 //   * bucket(node) lists a node's pending partitions for an application FindMoveFunc.
 //
-// Call sites (all under o.m, like the fields they replace):
-//   * OrchestrateMoves, after mapPartitionToNextMoves is filled (orchestrate.go:271-290):
+// LOCKING.  Every method of moveIndex reads or writes the live buckets and must run with o.m HELD -- like the
+// fields it replaces.  Nothing of the index may be touched after o.m.Unlock(): the reference's supply loop
+// iterates AFTER unlocking (orchestrate.go:521-560) while runSupplyMove goroutines advance Next under o.m
+// (orchestrate.go:684-691), and advanced() swap-removes -- it reorders `active` and the buckets.  So the loop
+// works on a SNAPSHOT taken under the lock, exactly as the reference iterates the fresh map that
+// findAvailableMovesUnlocked built under the lock: snapshot() returns fresh slices that the index never
+// touches again.
+//
+// Call sites:
+//   * OrchestrateMoves, after mapPartitionToNextMoves is filled (orchestrate.go:271-290), under o.m:
 //         o.moveIndex = newMoveIndex(mapPartitionToNextMoves)
-//   * runSupplyMoves, instead of o.findAvailableMovesUnlocked() (orchestrate.go:521) and of the per-node
-//     filterNextPlausibleMovesForNode call (orchestrate.go:549):
-//         for _, node := range o.moveIndex.activeNodes() { nxt := o.moveIndex.lowestWeight(node, count) ... }
-//     (with an application FindMoveFunc: filterNextPlausibleMovesForNode(node, o.moveIndex.bucket(node)))
-//   * where a move completes, next to nextMoves[i].Next++ (orchestrate.go:689):
+//   * runSupplyMoves, instead of o.findAvailableMovesUnlocked() (orchestrate.go:521), still under o.m:
+//         avail := o.moveIndex.snapshot(count)        // node -> its `count` lowest-weight pending moves
+//         o.m.Unlock()
+//         for node, nxt := range avail { ... }         // replaces the per-node filter call (orchestrate.go:549)
+//     (with an application FindMoveFunc: o.moveIndex.snapshotBuckets(), then filterNextPlausibleMovesForNode)
+//   * where a move completes, next to nextMoves[i].Next++ (orchestrate.go:689), under o.m:
 //         o.moveIndex.advanced(nextMoves[i])
 
 package blance
 
-var moveOpClass = map[string]int{"promote": 0, "demote": 1, "add": 2, "del": 3} // ascending MoveOpWeight
+// op classes in ascending MoveOpWeight (orchestrate.go:187-192).  An op the table does not know has weight 0 in
+// the reference (a missing map key) and therefore ranks BEFORE promote: class 0; the four known ops follow.
+const (
+	moveOpUnknown = 0
+	moveOpClasses = 5
+)
+
+var moveOpClass = map[string]int{"promote": 1, "demote": 2, "add": 3, "del": 4}
+
+func opClass(op string) int {
+	if c, ok := moveOpClass[op]; ok {
+		return c
+	}
+	return moveOpUnknown
+}
 
 type moveIndexNode struct {
-	byOp      [4][]*NextMoves // partitions whose next move is (this node, op)
+	byOp      [moveOpClasses][]*NextMoves // partitions whose next move is (this node, op class)
 	pending   int
 	activePos int // position in moveIndex.active, -1 if pending == 0
 }
@@ -61,7 +84,7 @@ func (ix *moveIndex) insert(nm *NextMoves) {
 		n = &moveIndexNode{activePos: -1}
 		ix.nodes[m.Node] = n
 	}
-	op := moveOpClass[m.Op]
+	op := opClass(m.Op)
 	ix.where[nm] = len(n.byOp[op])
 	n.byOp[op] = append(n.byOp[op], nm)
 	if n.pending == 0 {
@@ -74,9 +97,13 @@ func (ix *moveIndex) insert(nm *NextMoves) {
 
 func (ix *moveIndex) remove(nm *NextMoves, node string, opName string) {
 	n := ix.nodes[node]
-	op := moveOpClass[opName]
+	op := opClass(opName)
+	at, ok := ix.where[nm]
+	if n == nil || !ok || at >= len(n.byOp[op]) || n.byOp[op][at] != nm {
+		return // not filed (it had no move left when the index was built): nothing to take out
+	}
 	b := n.byOp[op]
-	at, last := ix.where[nm], b[len(b)-1]
+	last := b[len(b)-1]
 	b[at] = last
 	ix.where[last] = at
 	b[len(b)-1] = nil
@@ -100,10 +127,26 @@ func (ix *moveIndex) advanced(nm *NextMoves) {
 	ix.insert(nm)
 }
 
-// activeNodes: the key set of findAvailableMovesUnlocked's map.
-func (ix *moveIndex) activeNodes() []string { return ix.active }
+// snapshot: for every node with pending moves, up to count of them in ascending MoveOpWeight -- what the supply
+// loop needs, as FRESH slices (call with o.m held; the result may be used after Unlock).
+func (ix *moveIndex) snapshot(count int) map[string][]*NextMoves {
+	out := make(map[string][]*NextMoves, len(ix.active))
+	for _, node := range ix.active {
+		out[node] = ix.lowestWeight(node, count)
+	}
+	return out
+}
 
-// lowestWeight: up to count partitions whose next move goes to node, ascending MoveOpWeight.
+// snapshotBuckets: findAvailableMovesUnlocked()'s map itself, built from the index (fresh slices; o.m held).
+func (ix *moveIndex) snapshotBuckets() map[string][]*NextMoves {
+	out := make(map[string][]*NextMoves, len(ix.active))
+	for _, node := range ix.active {
+		out[node] = ix.bucket(node)
+	}
+	return out
+}
+
+// lowestWeight: up to count partitions whose next move goes to node, ascending MoveOpWeight (a fresh slice; o.m held).
 func (ix *moveIndex) lowestWeight(node string, count int) []*NextMoves {
 	n := ix.nodes[node]
 	if n == nil {
@@ -113,7 +156,7 @@ func (ix *moveIndex) lowestWeight(node string, count int) []*NextMoves {
 		count = 1 // orchestrate.go:485-487
 	}
 	var out []*NextMoves
-	for op := 0; op < 4 && count > 0; op++ {
+	for op := 0; op < moveOpClasses && count > 0; op++ {
 		for i := 0; i < len(n.byOp[op]) && count > 0; i++ {
 			out = append(out, n.byOp[op][i])
 			count--
@@ -129,7 +172,7 @@ func (ix *moveIndex) bucket(node string) []*NextMoves {
 		return nil
 	}
 	out := make([]*NextMoves, 0, n.pending)
-	for op := 0; op < 4; op++ {
+	for op := 0; op < moveOpClasses; op++ {
 		out = append(out, n.byOp[op]...)
 	}
 	return out

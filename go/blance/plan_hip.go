@@ -246,12 +246,36 @@ func planNextMapHip(
 				f.stateConstraints[warnState[i]], state, name))
 	}
 	// plan.go:49-52: every sweep that did not converge stores its partitions into BOTH caller maps;
-	// the last such store carries the final content (a converging last sweep changes nothing)
+	// the last such store carries the final content (a converging last sweep changes nothing).
+	// When the call converged (in sweep n > 1) the stored objects are sweep n-1's: equal in content to the
+	// returned ones, but not the same objects (plan.go:334-343 makes fresh ones every sweep) -- a caller that
+	// edits nextMap[p] afterwards must not edit prevMap[p].  At the iteration cap the returned objects ARE
+	// the stored ones.  One clone per partition, shared by both maps as in the reference.
 	if int(res.iterations) > 1 || res.converged == 0 {
 		for name, part := range nextMap {
-			prevMap[name] = part
-			partitionsToAssign[name] = part
+			stored := part
+			if res.converged != 0 {
+				stored = clonePartition(part)
+			}
+			prevMap[name] = stored
+			partitionsToAssign[name] = stored
 		}
 	}
 	return nextMap, warnings, true
+}
+
+// clonePartition: a deep copy (nil maps and nil slices stay nil: reflect.DeepEqual tells them from empty ones, plan.go:38).
+func clonePartition(p *Partition) *Partition {
+	c := &Partition{Name: p.Name}
+	if p.NodesByState != nil {
+		c.NodesByState = make(map[string][]string, len(p.NodesByState))
+		for s, l := range p.NodesByState {
+			if l == nil {
+				c.NodesByState[s] = nil
+			} else {
+				c.NodesByState[s] = append(make([]string, 0, len(l)), l...)
+			}
+		}
+	}
+	return c
 }

@@ -118,6 +118,12 @@ def _check(cases, results):
         assert got["iterations"] == info["iterations"] and got["converged"] == info["converged"], c["source"]
         assert got["prevMap"] == R.partition_map_to_json(prev_o), c["source"]          # plan.go:49-52
         assert got["partitionsToAssign"] == R.partition_map_to_json(assign_o), c["source"]
+        # object identity (plan.go:49-52 stores the objects of the last sweep that did NOT converge; :334-343 makes fresh
+        # ones every sweep): a caller that edits nextMap[p] edits prevMap[p] only where the reference would
+        if want is not None:
+            ident = [sum(1 for n, p in want.items() if prev_o.get(n) is p), sum(1 for n, p in want.items() if assign_o.get(n) is p),
+                     sum(1 for n in want if n in prev_o and n in assign_o and prev_o[n] is assign_o[n])]
+            assert got["identity"] == ident, (c["source"], got["identity"], ident)
 
 
 def test_cpp_mirror_on_golden_cases_emulated(golden_cases):

@@ -42,6 +42,21 @@ def _check_case(c, pl):
     # caller-visible mutations (plan.go:49-52)
     assert _json(prev) == R.partition_map_to_json(prev_o), c["source"]
     assert _json(assign) == R.partition_map_to_json(assign_o), c["source"]
+    # object identity: what is stored in the input maps are the objects of the last sweep that did NOT converge
+    # (plan.go:49-52), the returned ones are fresh (plan.go:334-343) -- editing nextMap[p] edits prevMap[p] only where
+    # the reference would
+    if want is not None:
+        for name in want:
+            assert (got[name] is prev.get(name)) == (want[name] is prev_o.get(name)), (c["source"], name)
+            assert (got[name] is assign.get(name)) == (want[name] is assign_o.get(name)), (c["source"], name)
+            if name in prev_o and name in assign_o:
+                assert (prev[name] is assign[name]) == (prev_o[name] is assign_o[name]), (c["source"], name)
+        if any(want[n] is not prev_o.get(n) for n in want):
+            n0 = next(n for n in want if want[n] is not prev_o.get(n))
+            if got[n0].NodesByState and n0 in prev:
+                before = copy.deepcopy(prev[n0].NodesByState)
+                got[n0].NodesByState["edited-by-the-caller"] = ["x"]
+                assert prev[n0].NodesByState == before, c["source"]
 
 
 @pytest.mark.gpu

@@ -232,3 +232,48 @@ def test_caller_owned_forms_agree_with_the_handles(golden_cases):
     with pytest.raises(wire.WireError) as e:
         wire.decode_into_numpy(b'{"a":')
     assert e.value.status == -1
+
+
+def _wire_vectors():
+    with open(os.path.join(ROOT, "tests", "golden", "wire_cases.json")) as f:
+        return json.load(f)
+
+
+def test_rule_derived_vectors_marshal():
+    """tests/golden/wire_cases.json: bytes written out BY HAND from the rules encoding/json documents (each vector cites its
+    rule) -- they pin both the restatement oracle/wire_ref.py and the C++ codec."""
+    v = _wire_vectors()
+    for c in v["marshal"]:
+        want = bytes.fromhex(c["hex"])
+        assert wire_ref.marshal(c["value"]) == want, (c["id"], c["rule"])
+        assert wire.encode(c["value"]) == want, (c["id"], c["rule"])
+    for c in v["marshal_raw"]:
+        want = bytes.fromhex(c["hex"])
+        pmap = {bytes.fromhex(c["key_hex"]): {"name": bytes.fromhex(c["name_hex"]), "nodesByState": None}}
+        assert wire_ref.marshal(pmap) == want, (c["id"], c["rule"])
+        assert wire.encode(pmap) == want, (c["id"], c["rule"])
+    assert len(v["marshal"]) + len(v["marshal_raw"]) >= 9
+
+
+def test_rule_derived_vectors_unmarshal():
+    v = _wire_vectors()
+    for c in v["unmarshal"]:
+        doc = bytes.fromhex(c["hex"])
+        assert wire_ref.unmarshal(doc) == c["value"], (c["id"], c["rule"])
+        m = wire.decode(doc)
+        assert m.to_dict() == c["value"], (c["id"], c["rule"])
+        m.close()
+    for c in v["unmarshal_raw"]:
+        doc = bytes.fromhex(c["hex"])
+        want = {bytes.fromhex(c["key_hex"]).decode("utf-8"): {"name": bytes.fromhex(c["name_hex"]).decode("utf-8"), "nodesByState": None}}
+        assert wire_ref.unmarshal(doc) == want, (c["id"], c["rule"])
+        m = wire.decode(doc)
+        assert m.to_dict() == want, (c["id"], c["rule"])
+        m.close()
+    for c in v["errors"]:
+        doc = bytes.fromhex(c["hex"])
+        with pytest.raises((wire_ref.WireSyntaxError, wire_ref.WireTypeError)):
+            wire_ref.unmarshal(doc)
+        with pytest.raises(wire.WireError):
+            wire.decode(doc)
+    assert len(v["unmarshal"]) + len(v["unmarshal_raw"]) + len(v["errors"]) >= 18
