@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -229,4 +229,5 @@ class PlanStats(C.Structure):
     _fields_ = [("n_states", C.c_int32), ("n_nodes_next", C.c_int32),
                 ("load_min", C.POINTER(C.c_int64)), ("load_max", C.POINTER(C.c_int64)),
                 ("load_sum", C.POINTER(C.c_int64)), ("load_sumsq", C.POINTER(C.c_int64)),
-                ("nodes_used", C.POINTER(C.c_int32)), ("unmet_slots", C.POINTER(C.c_int64))]
+                ("nodes_used", C.POINTER(C.c_int32)), ("unmet_slots", C.POINTER(C.c_int64)),
+                ("rule_violations", C.POINTER(C.c_int64))]

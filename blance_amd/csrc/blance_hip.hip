@@ -1833,24 +1833,30 @@ extern "C" int blance_plan_stats_get(blance_ctx* c, blance_plan_stats* st) {
         return fail(BLANCE_ERR_BAD_ARG, "stats arrays missing or shorter than n_states");
     HIPTRY(hipSetDevice(c->device));
     hipStream_t sm = c->stream;
-    DevBuf load, out, cons, unmet;
-    struct Free { DevBuf* b[4]; ~Free() { for (DevBuf* x : b) x->release(); } } fr{{&load, &out, &cons, &unmet}};
+    DevBuf load, out, cons, unmet, roff;
+    struct Free { DevBuf* b[5]; ~Free() { for (DevBuf* x : b) x->release(); } } fr{{&load, &out, &cons, &unmet, &roff}};
     if (load.reserve(sizeof(int32_t) * ((size_t)M * (NX > 0 ? NX : 1) + 1)) || out.reserve(sizeof(long long) * ((size_t)M * 5 + 1)) ||
-        cons.reserve(sizeof(int32_t) * ((size_t)M + 1)) || unmet.reserve(sizeof(long long) * ((size_t)M + 1)))
+        cons.reserve(sizeof(int32_t) * ((size_t)M + 1)) || unmet.reserve(sizeof(long long) * (2 * (size_t)M + 1)) ||
+        roff.reserve(sizeof(int32_t) * ((size_t)M + 2)))
         return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
-    std::vector<long long> host((size_t)M * 5 + 1), hun((size_t)M + 1, 0);
+    std::vector<long long> host((size_t)M * 5 + 1), hun(2 * (size_t)M + 1, 0);
     int n_next = 0;
     if (c->iterations > 0 && M > 0) {
         HIPTRY(hipMemsetAsync(load.p, 0, sizeof(int32_t) * (size_t)M * (NX > 0 ? NX : 1), sm));
-        HIPTRY(hipMemsetAsync(unmet.p, 0, sizeof(long long) * (size_t)M, sm));
+        HIPTRY(hipMemsetAsync(unmet.p, 0, sizeof(long long) * 2 * (size_t)M, sm));
         HIPTRY(hipMemcpyAsync(cons.p, c->state_constraints.data(), sizeof(int32_t) * (size_t)M, hipMemcpyHostToDevice, sm));
         DevProblem d = dev_problem(c);
         if ((int64_t)P * M > 0)
             BLANCE_LAUNCH_NOSYNC(k_stats_load, cdiv((int64_t)P * M, 256), 256, 0, sm, d, load.as<int32_t>(), cons.as<int32_t>(),
                                  unmet.as<unsigned long long>());
+        if (!h.hierarchy_rules_nil && h.n_rules > 0 && (int64_t)P * M > 0) {      // rule violations (words M .. 2M - 1 of `unmet`)
+            HIPTRY(hipMemcpyAsync(roff.p, c->rule_off.data(), sizeof(int32_t) * ((size_t)M + 1), hipMemcpyHostToDevice, sm));
+            BLANCE_LAUNCH_NOSYNC(k_stats_rules, cdiv((int64_t)P * M, 256), 256, 0, sm, d, h.top_state, roff.as<int32_t>(),
+                                 c->anchors.as<AnchorSet>(), c->node_leaf_pos.as<int32_t>(), unmet.as<unsigned long long>() + M);
+        }
         BLANCE_LAUNCH(k_stats_reduce, M, 256, sizeof(long long) * 5 * 256 + 64, sm, N, NX, c->alive.as<uint8_t>(), load.as<int32_t>(), out.as<long long>());
         HIPTRY(hipMemcpyAsync(host.data(), out.p, sizeof(long long) * (size_t)M * 5, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipMemcpyAsync(hun.data(), unmet.p, sizeof(long long) * (size_t)M, hipMemcpyDeviceToHost, sm));
+        HIPTRY(hipMemcpyAsync(hun.data(), unmet.p, sizeof(long long) * 2 * (size_t)M, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipStreamSynchronize(sm));
     }
     if (c->iterations > 0) n_next = c->n_alive;
@@ -1863,6 +1869,7 @@ extern "C" int blance_plan_stats_get(blance_ctx* c, blance_plan_stats* st) {
         st->load_sumsq[m] = any ? host[(size_t)m * 5 + 3] : 0;
         st->nodes_used[m] = any ? (int32_t)host[(size_t)m * 5 + 4] : 0;
         st->unmet_slots[m] = c->iterations > 0 ? hun[(size_t)m] : 0;
+        if (st->rule_violations) st->rule_violations[m] = c->iterations > 0 ? hun[(size_t)M + m] : 0;
     }
     return BLANCE_OK;
     });

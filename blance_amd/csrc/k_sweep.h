@@ -616,6 +616,34 @@ __global__ void k_stats_load(DevProblem d, int32_t* load /* [M][NX] */, const in
     if (len < k) atomicAdd(&unmet[m], (unsigned long long)(k - len));
 }
 
+// (partition, slot) pairs whose node breaks a hierarchy rule of its state against the partition's top priority node or an
+// earlier node of the same list: outside the include interval or inside the exclude interval of such an anchor
+// (includeExcludeNodes, plan.go:723-734; the anchors of plan.go:185-212).  One thread per (partition, state).
+__global__ void k_stats_rules(DevProblem d, int top_state, const int32_t* rule_off /* [M + 1] */, const AnchorSet* anchors /* [R][NX + 1] */,
+                              const int32_t* node_leaf_pos, unsigned long long* viol /* [M] */) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.P * d.M) return;
+    const int p = idx / d.M, m = idx - p * d.M;
+    const int r0 = rule_off[m], r1 = rule_off[m + 1];
+    if (r1 <= r0) return;
+    const int len = d.live_kind[idx] == kListAbsent ? 0 : d.live_len[idx];
+    const int ti = p * d.M + top_state;
+    const int top = (d.live_kind[ti] != kListAbsent && d.live_len[ti] > 0) ? d.live[(size_t)ti * d.L] : d.NX;     // NX: the anchor ""
+    int bad = 0;
+    for (int i = 0; i < len; i++) {
+        const int c = d.live[(size_t)idx * d.L + i];
+        const int lp = node_leaf_pos[c];
+        bool v = false;
+        for (int r = r0; r < r1 && !v; r++)
+            for (int j = -1; j < i && !v; j++) {
+                const AnchorSet a = anchors[(size_t)r * (d.NX + 1) + (j < 0 ? top : d.live[(size_t)idx * d.L + j])];
+                v = lp < a.alo || lp >= a.ahi || (lp >= a.blo && lp < a.bhi);
+            }
+        bad += v;
+    }
+    if (bad) atomicAdd(&viol[m], (unsigned long long)bad);
+}
+
 // one workgroup per state: min / max / sum / sum of squares / nodes in use over nodesNext
 __global__ __launch_bounds__(256) void k_stats_reduce(int N, int NX, const uint8_t* alive, const int32_t* load,
                                                       long long* out /* [M][5] */) {

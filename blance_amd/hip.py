@@ -177,10 +177,10 @@ class Planner:
 
     def plan_stats(self, n_states):
         """Per-state load statistics of the map the last plan produced (blance_plan_stats_get):
-        dict of numpy arrays load_min / load_max / load_sum / load_sumsq / nodes_used / unmet_slots
+        dict of numpy arrays load_min / load_max / load_sum / load_sumsq / nodes_used / unmet_slots / rule_violations
         plus n_nodes_next."""
         import numpy as np
-        a = {k: np.zeros(max(n_states, 1), dtype=np.int64) for k in ("load_min", "load_max", "load_sum", "load_sumsq", "unmet_slots")}
+        a = {k: np.zeros(max(n_states, 1), dtype=np.int64) for k in ("load_min", "load_max", "load_sum", "load_sumsq", "unmet_slots", "rule_violations")}
         used = np.zeros(max(n_states, 1), dtype=np.int32)
         st = abi.PlanStats()
         st.n_states = n_states

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define BLANCE_ABI_VERSION 3
+#define BLANCE_ABI_VERSION 4
 
 /* status codes */
 #define BLANCE_OK                0
@@ -263,6 +263,11 @@ typedef struct blance_plan_stats {
     int64_t* load_sumsq;     /* out: sum of squares (variance = sumsq / n - (sum / n)^2) */
     int32_t* nodes_used;     /* out: nodes with load > 0 */
     int64_t* unmet_slots;    /* out: sum over partitions of max(0, constraints - len(list)); warnings of plan.go:231-234 */
+    int64_t* rule_violations; /* out (ABI 4; may be NULL): (partition, slot) pairs of this state whose node breaks one of the
+                              * state's hierarchy rules against the partition's top priority node or an EARLIER node of the
+                              * same list -- outside leaves(findAncestor(a, IncludeLevel)) or inside
+                              * leaves(findAncestor(a, ExcludeLevel)) of such an anchor a (plan.go:723-753); what the
+                              * fallback of plan.go:216-218 produces when racks disappear.  0 for states without rules */
 } blance_plan_stats;
 
 int blance_plan_stats_get(blance_ctx* ctx, blance_plan_stats* stats);

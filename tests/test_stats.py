@@ -8,7 +8,7 @@ from helpers import build_from_case, edge_cases
 from oracle import stats_ref
 from randgen import random_case
 
-KEYS = ("load_min", "load_max", "load_sum", "load_sumsq", "nodes_used", "unmet_slots")
+KEYS = ("load_min", "load_max", "load_sum", "load_sumsq", "nodes_used", "unmet_slots", "rule_violations")
 
 
 def _check(pl, fp, tag):
@@ -22,11 +22,18 @@ def _check(pl, fp, tag):
 
 
 def _run(pl, golden_cases):
+    broken = 0
     for c in golden_cases:
         fp = build_from_case(c)
         res, got = _check(pl, fp, c["source"])
+        broken += int(got["rule_violations"].sum() > 0)
+        if "MultiRackFailure" not in c["source"] and c.get("hierarchyRules") is None:
+            assert got["rule_violations"].sum() == 0, c["source"]
         # the warnings of plan.go:231-234 are exactly the (partition, state) pairs with unmet slots
         assert (got["unmet_slots"].sum() > 0) == (res.n_warnings > 0), c["source"]
+    # the reference's tables in which racks disappear (plan_test.go:2619-2863) are where the fallback of plan.go:216-218
+    # picks outside the rule: some of the 69 cases must report violations, and the rule-abiding ones none
+    assert broken >= 3, broken
     for seed in range(300, 380):
         try:
             fp = build_from_case(random_case(seed))
@@ -60,4 +67,5 @@ def test_stats_gpu(golden_cases):
     fp = synth.config_flat(3, P=65536, N=4096)
     _, got = _check(pl, fp, "cfg3 reduced")
     assert got["load_max"][0] - got["load_min"][0] <= 1 and got["unmet_slots"].sum() == 0
+    assert got["rule_violations"].sum() == 0            # replicas in the primary's zone, every copy in a rack of its own
     pl.close()
