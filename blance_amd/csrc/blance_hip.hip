@@ -109,6 +109,10 @@ struct blance_ctx {
     bool queue_force_dense = false; // test knob (& 2048): every general step of k_pass_queue scores every node
     DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
     bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
+    // nodeToNodeCounts (67 MB at config 3) is zeroed lazily: only a pass that reads or bumps the matrix in HBM pays for it
+    // (region chains keep their rows in LDS, a pass that is one run of stays needs none of it)
+    bool ntn_clean = false;         // the matrix (and its bit maps) are known to be all zero
+    bool pass_ntn_ready = false;    // this pass has been given its zeroed matrix already (plan.go:266)
     int64_t queue_launches = 0, queue_stops = 0, queue_moved = 0, queue_exact = 0, queue_rebuilds = 0, queue_dense = 0;
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
         bool ok = false;
@@ -374,6 +378,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     HIPTRY(hipSetDevice(c->device));
     c->uploaded = false;
     c->planned = false;
+    c->ntn_clean = false;
     c->h = *pb;
     const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
     const int64_t PM = (int64_t)P * M;
@@ -620,10 +625,28 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     return BLANCE_OK;
 }
 
+// plan.go:266: a state pass starts from an empty nodeToNodeCounts.  Called by whatever is about to read or bump the matrix
+// in HBM (NumPartitions > 0); the first such call of a pass zeroes it unless it is known to be zero already.
+static int ntn_prepare(blance_ctx* c) {
+    if (!c->pass_ntn_ready) {
+        if (!c->ntn_clean) {
+            const blance_problem& h = c->h;
+            HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(h.n_nodes_ext + 1) * (h.n_nodes > 0 ? h.n_nodes : 1), c->stream));
+            HIPTRY(hipMemsetAsync(c->ntn_bits.p, 0, sizeof(uint32_t) * queue_bits_words(h.n_nodes_ext), c->stream));
+        }
+        c->pass_ntn_ready = true;
+        c->bits_stale = false;
+    }
+    c->ntn_clean = false;                            // (the caller writes it)
+    return 0;
+}
+#define NTNTRY() do { int e__ = ntn_prepare(c); if (e__) return e__; } while (0)
+
 // A state pass (or a sub-range of one) in order.  Flat passes (no hierarchy rule for the state) of up
 // to kTreeMaxNodes node names: one wave64 with bound-ordered candidates (k_pass_tree.h) -- the cost
 // of a step does not grow with the cluster; everything else: the workgroup pass k_pass_seq.
 static int dispatch_pass_tree_or_seq(blance_ctx* c, const PassParams& q) {
+    if (q.NP > 0) NTNTRY();
     c->bits_stale = true;
     const bool tree = !c->no_tree && c->engine != BLANCE_ENGINE_SEQUENTIAL && (c->force_threads == 0 || c->tree_always);
     if (tree && launch_pass_tree(c->stream, q, (c->tree_dense ? 1 : 0) | (c->tree_long ? 2 : 0))) {
@@ -643,6 +666,7 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
                        !c->tree_dense && !c->tree_long && q0.k <= 2 && q0.rule_begin >= q0.rule_end && q0.NX >= 1 && q0.NX <= 4096;
     if (!queue) return dispatch_pass_tree_or_seq(c, q0);
     PassParams q = q0;
+    if (q.NP > 0) NTNTRY();
     int32_t* scal = c->scalars.as<int32_t>();
     q.ntn_bits = c->ntn_bits.as<uint32_t>();
     q.stop = scal + 16;
@@ -692,6 +716,8 @@ static int launch_scan_excl(blance_ctx* c, int n, int32_t* data) {
 }
 #define SCANTRY(n, data) do { int e__ = launch_scan_excl(c, (n), (data)); if (e__) return e__; } while (0)
 
+
+
 // stable LSD radix sort of the n (key, value) pairs in the f_*_a buffers; *sorted_vals = the buffer the sorted
 // values ended in (a or b: no copy back), *other_vals = the other one (free for the caller)
 static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches, int32_t** sorted_vals, int32_t** other_vals) {
@@ -735,6 +761,7 @@ static bool dispatch_chain(blance_ctx* c, ChainParams& q, int max_size);
 static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool lds_rows, int32_t* scal,
                           int64_t* launches) {
     hipStream_t sm = c->stream;
+    if (q.NP > 0) NTNTRY();
     c->bits_stale = true;
     ChainParams cq;
     memset(&cq, 0, sizeof cq);
@@ -819,7 +846,9 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
         *launches += 1;
         int first_nonstay = got[0] > P ? P : got[0], first_nonfresh = got[1] > P ? P : got[1];
         if (first_nonstay - pos >= kMinStayRun || (first_nonstay == P && first_nonstay > pos)) {
-            BLANCE_LAUNCH_NOSYNC(k_flat_commit_stay, cdiv(first_nonstay - pos, 256), 256, 0, sm, fq, pos, first_nonstay);
+            const bool whole = pos == 0 && first_nonstay == P;      // the pass is one run of stays: no one reads the matrix
+            if (q.NP > 0 && !whole) NTNTRY();
+            BLANCE_LAUNCH_NOSYNC(k_flat_commit_stay, cdiv(first_nonstay - pos, 256), 256, 0, sm, fq, pos, first_nonstay, whole ? 0 : 1);
             *launches += 1;
             *batched += first_nonstay - pos;
             pos = first_nonstay;
@@ -833,6 +862,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             // sequence then needs k elements per step and one more
             const bool excl = q.NP == 0 && (q.higher_mask != 0 || q.k == 2);
             const int RS = excl ? q.k * R + q.k : R;
+            if (q.NP > 0) NTNTRY();                 // (the fresh run reads and bumps row "" of the matrix)
             BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, RS, c->f_m.as<int32_t>(),
                           c->f_moff.as<int32_t>());
             BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
@@ -1349,7 +1379,10 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
             HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
         }
     }
-    if (!lean && !dispatch_chain(c, cq, rr.max_size)) return fail(BLANCE_ERR_UNSUPPORTED, "region chain shape");
+    if (!lean) {
+        if (NP > 0 && !chain_rows_in_lds(cq, rr.max_size)) NTNTRY();      // (rows in LDS: the matrix in HBM is not touched)
+        if (!dispatch_chain(c, cq, rr.max_size)) return fail(BLANCE_ERR_UNSUPPORTED, "region chain shape");
+    }
     HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
     launches += 8;
     c->pass_kind.resize(n_pass + 1);
@@ -1416,8 +1449,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         *batched_io += P;
         *done = true;
     } else {                                        // not region-local after all: redo in order
-        if (NP > 0)                                 // chains of big regions keep their rows in global memory
-            HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
+        c->pass_ntn_ready = false;                  // (chains of big regions keep their rows in global memory: zeroed again on demand)
         HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
     }
     *launches_io += launches;
@@ -1494,11 +1526,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 // static order itself
                 HIPTRY(hipMemcpyAsync(c->order.p, c->part_order.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToDevice, sm));
             }
-            if (NP > 0) {                                           // nodeToNodeCounts := fresh, plan.go:266
-                HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(NX + 1) * (N > 0 ? N : 1), sm));
-                HIPTRY(hipMemsetAsync(c->ntn_bits.p, 0, sizeof(uint32_t) * queue_bits_words(NX), sm));
-                c->bits_stale = false;
-            }
+            c->pass_ntn_ready = false;                              // nodeToNodeCounts := fresh (plan.go:266), zeroed when first needed
             const int OW = 1 + k;
             int higher_mask = 0;
             for (int t = 0; t < M; t++)

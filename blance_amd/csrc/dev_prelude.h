@@ -38,6 +38,8 @@ bool launch_pass_queue(hipStream_t stream, PassParams q);
 size_t queue_bits_words(int NX);   // words of PassParams::ntn_bits for a cluster of NX node names
 // k_pass_chain (tu_chain.hip): one wave64 per region; false when the shape has no variant
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast);
+// ... whether launch_chain would keep the regions' nodeToNodeCounts rows in LDS (then the matrix in HBM is not touched)
+bool chain_rows_in_lds(const ChainParams& q, int max_size);
 // k_pass_chain_blank (tu_chain.hip): the lean first-sweep kernel
 void launch_chain_blank(hipStream_t stream, const ChainParams& q, int max_size);
 // k_pass_chain_planes (tu_chain.hip): the all-blank pass as a scalar bit-plane automaton; false: shape outside it

@@ -573,6 +573,19 @@ bool Library::open(const std::string& path, std::string* err) {
     return true;
 }
 
+void Library::trim() {
+    auto it = g_abi.find(handle);
+    if (it == g_abi.end() || !it->second.scratch) return;
+    std::unique_lock<std::mutex> held(it->second.scratch->mu, std::try_to_lock);
+    if (!held.owns_lock()) return;                           // a call is using them: nothing to let go of now
+    Scratch& sc = *it->second.scratch;
+    sc.flat = Flat();
+    std::vector<int32_t>().swap(sc.out_off); std::vector<int32_t>().swap(sc.out_nodes);
+    std::vector<int32_t>().swap(sc.warn_part); std::vector<int32_t>().swap(sc.warn_state);
+    std::vector<uint8_t>().swap(sc.out_kind);
+    std::vector<PartitionPtr>().swap(sc.parts);
+}
+
 void Library::close() {
     if (handle) {
         auto it = g_abi.find(handle);

@@ -73,6 +73,10 @@ struct Library {
     void* ctx = nullptr;
     bool open(const std::string& path, std::string* err);
     void close();
+    // The flat arrays of the last call (~200 MB at a million partitions) stay with the Library so that the next call does
+    // not fault them in again; trim() lets them go (e.g. after one huge plan in a long-lived process).  Safe while no call
+    // is running on this Library; a call that finds the arrays taken or trimmed allocates its own.
+    void trim();
     ~Library() { close(); }
 };
 

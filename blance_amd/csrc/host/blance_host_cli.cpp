@@ -251,6 +251,7 @@ int main(int argc, char** argv) {
             NodeScoreBooster = b == "cbgt" ? Booster::Cbgt : (b == "other" ? Booster::Other : Booster::None);
             CustomNodeSorterIsDefault = b != "sorter";
         }
+        if (ci % 7 == 3) lib.trim();           // (the Library's scratch may be let go between calls)
         PlanOutcome r = PlanNextMapEx(lib, &prev, assign, nodesAll, rm, add, model, o);
         std::cout << (ci ? "," : "") << "{\"handled\":" << (r.handled ? "true" : "false") << ",\"why\":" << q(r.why)
                   << ",\"iterations\":" << r.iterations << ",\"converged\":" << (r.converged ? "true" : "false")

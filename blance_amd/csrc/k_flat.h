@@ -182,7 +182,8 @@ __global__ void k_flat_scan(FlatParams q, int beg, int end) {
 }
 
 // commit a run of certain stays: the lists do not change; nodeToNodeCounts does (plan.go:238-245)
-__global__ void k_flat_commit_stay(FlatParams q, int beg, int end) {
+// (bump = 0: the whole pass is this one run of stays -- nothing reads nodeToNodeCounts afterwards, plan.go:266 drops it)
+__global__ void k_flat_commit_stay(FlatParams q, int beg, int end, int bump) {
     int oi = beg + blockIdx.x * blockDim.x + threadIdx.x;
     if (oi >= end) return;
     const int SW = 1 + q.L;
@@ -191,7 +192,7 @@ __global__ void k_flat_commit_stay(FlatParams q, int beg, int end) {
     int* out = q.out + (size_t)oi * q.OW;
     out[0] = 1;
     out[1] = o;
-    if (q.NP > 0) {
+    if (q.NP > 0 && bump) {
         int hT = r[kRecHead + q.top_state * SW];
         int top = ((hT >> 16) != kListAbsent && (hT & 0xffff) > 0) ? r[kRecHead + q.top_state * SW + 1] : -1;
         atomicAdd(&q.ntn[(size_t)(top < 0 ? q.NX : top) * q.N + o], 1);

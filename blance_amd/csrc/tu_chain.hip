@@ -17,15 +17,25 @@ static void launch_chain_mode(hipStream_t stream, const ChainParams& q, size_t l
     else launch_chain_v<NPTC, KM, false>(stream, q, lds);
 }
 
+static size_t chain_lds_base(const ChainParams& q, int max_size) {
+    return sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
+           sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * ((size_t)max_size + 1) + 64;
+}
+
+// the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU); flat mode may insist on
+// global rows
+bool chain_rows_in_lds(const ChainParams& q, int max_size) {
+    const size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
+    if (!q.flat || q.ntn_in_lds) return ntn_bytes <= 100 * 1024 && chain_lds_base(q, max_size) + ntn_bytes <= 156 * 1024;
+    return false;
+}
+
 // one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast) {
     int nptc = (max_size + 63) / 64;
     size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
-    size_t lds = sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
-                 sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * ((size_t)max_size + 1) + 64;
-    // the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU);
-    // flat mode may insist on global rows
-    if (!q.flat || q.ntn_in_lds) q.ntn_in_lds = ntn_bytes <= 100 * 1024 && lds + ntn_bytes <= 156 * 1024;
+    size_t lds = chain_lds_base(q, max_size);
+    q.ntn_in_lds = chain_rows_in_lds(q, max_size);
     if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
     if (q.k <= 2) {
         if (nptc <= 2) launch_chain_mode<2, 2>(stream, q, lds, fast);

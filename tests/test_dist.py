@@ -155,3 +155,54 @@ def test_bench_multi_rank_flow_rehearsal():
     assert s["rccl_world_size"] == 2 and s["same_digest_on_every_rank"] and s["same_digest_as_single_rank_plan"]
     assert s["scaling"] == "strong" and s["comm_calls_per_plan"] >= 2 and s["comm_bytes_per_plan"] > 0
     assert "cpu_baseline" not in d                                       # rank 0 at N = 1 only
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_rccl_two_ranks_when_two_devices(tmp_path):
+    """RCCL between two GPUs (ncclAllReduce / ncclAllGather inside the library, bound at run time): one PlanNextMap of
+    config 3's generator sharded over two ranks, one process per device -- same digest on both ranks as the single-rank
+    plan and as the CPU oracle, two collectives per chain pass.  Skips unless this machine shows at least two devices
+    (the development boxes show one): the first multi-GPU box runs it inside pytest, not only inside bench.py's watchdog."""
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (found %d)" % (torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    script = tmp_path / "rccl2.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        from blance_amd import dist_util, hip, synth
+        from oracle import loader
+        local = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        rank, world = dist.get_rank(), dist.get_world_size()
+        fp = synth.config_flat(3, P=65536, N=4096)
+        want = loader.plan(fp).digest()
+        single = hip.Planner(device_id=local)
+        assert single.plan(fp).digest() == want
+        single.close()
+        pl = hip.Planner(device_id=local)
+        dist_util.shard_plan_rccl(pl, dist)
+        calls0, words0 = pl.comm_stats()
+        got = pl.plan(fp)
+        calls1, words1 = pl.comm_stats()
+        assert got.digest() == want, "sharded plan over RCCL differs from the single-rank plan"
+        assert 0 < calls1 - calls0 <= 2 * got.iterations and words1 > words0
+        box = [None] * world
+        dist.all_gather_object(box, got.digest())
+        assert len(set(box)) == 1
+        pl.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2
