@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     long long n_bulk = 0, n_moved = 0, n_exact = 0, n_dense = 0, n_bound = 0;
 #ifndef BLANCE_SIMT_EMU
     // the assembly walk (k_queue_walk.h): k = 2, NumPartitions > 0, power-of-two node weights; q.spec & 32: test knob, never
-    const bool walk_asm = lean_ok && k == 2 && NP > 0 && KM == 2 && !(q.spec & 32) && NXp <= 4096;
+    const bool walk_asm = lean_ok && (k == 1 || k == 2) && NP > 0 && KM == 2 && !(q.spec & 32) && NXp <= 4096;
     const int cfa = (int)((((unsigned)(size_t)cntL) >> 2) | ((((unsigned)(size_t)totL) >> 2) << 16));
     const int cfb = (int)((((unsigned)(size_t)shL) >> 2) | ((((unsigned)(size_t)ffT) >> 2) << 16));
     const int cfc = (int)((((unsigned)(size_t)bitsL) >> 2) | ((unsigned)(BW * 4) << 16));
@@ -586,14 +586,15 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 st.wk = wk; st.wn = wn; st.o1 = mo1; st.o2 = mo2; st.cur = cur; st.wcnt = wcnt; st.thK = thK; st.thN = thN;
                 st.stale = stalemask; st.moved = 0; st.code = 0;
                 queue_walk_k2(st, lastK, lastN, own_a, own_b, sKv[0], sKv[1], hv[0], wj, (ov0 & 0xffff) | (ov1 << 16), lane,
-                              sfailmask | dirtymask, slowmask, actmask, cfa, cfb, cfc, (cfd & 0xffff) | (B << 16), lp_one);
+                              sfailmask | dirtymask, slowmask, actmask, cfa, cfb, cfc, (cfd & 0xffff) | (B << 16) | ((k == 2 ? 1 : 0) << 24), lp_one);
                 wk = st.wk; wn = st.wn; mo1 = st.o1; mo2 = st.o2;
                 const int c1_ = uni(st.cur);
                 wcnt = uni(st.wcnt); thK = uni64(st.thK); thN = uni(st.thN); stalemask = uni64(st.stale);
                 const u64 mv = uni64(st.moved);
                 if ((mv >> lane) & 1) {              // plan.go:299: the steps that moved (their rows are bumped with the batch's)
                     int* o = outS + lane * OWs;
-                    o[0] = 2; o[1] = mo1; o[2] = mo2;
+                    o[0] = k; o[1] = mo1;
+                    if (k == 2) o[2] = mo2;
                 }
                 const int nm = __popcll(mv);
                 n_moved += nm;
@@ -848,6 +849,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 #pragma unroll
                     for (int j = 0; j < KM; j++) { lb[j] = ~0ull; ln[j] = INT_MAX; }
                     auto keep_local = [&](u64 b, int n) {               // the lane's own k best, ascending
+                        if (!qless(b, n, lb[KM - 1], ln[KM - 1])) return;       // (most nodes: not among them)
 #pragma unroll
                         for (int j = KM - 1; j >= 0; j--) {
                             const bool here = qless(b, n, lb[j], ln[j]);

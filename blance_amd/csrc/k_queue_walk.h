@@ -1,5 +1,5 @@
-// queue_walk_k2: the lean walk of k_pass_queue (k_pass_queue.h) for k = 2, NumPartitions > 0, the row of nodeToNodeCounts not
-// folded -- the replica passes of BASELINE config 5 -- as hand-written gfx950 assembly.  Part of tu_queue.hip.
+// queue_walk_k2: the lean walk of k_pass_queue (k_pass_queue.h) for k = 1 or 2, NumPartitions > 0, the row of nodeToNodeCounts
+// not folded -- the passes of BASELINE config 5 -- as hand-written gfx950 assembly.  Part of tu_queue.hip.
 //
 // Why: a lone wave issues one instruction per ~4.5 cycles whatever its kind (tools/dev_lat_micro.hip), so a moving step is
 // an instruction-count problem, and the compiler's rendering of the C++ walk (the twin of this text, `lean walk` in
@@ -119,7 +119,8 @@ namespace blance {
     "s_lshr_b32 s66, s58, 16\n\t"                                                \
     "s_and_b32 s67, s59, 0xffff\n\t"                                             \
     "s_lshl_b32 s67, s67, 2\n\t"                                                 \
-    "s_lshr_b32 s68, s59, 16\n"                                                  \
+    "s_bfe_u32 s68, s59, 0x80010\n\t"           /* B: bits 16..23 */             \
+    "s_bfe_u32 s69, s59, 0x10018\n"             /* bit 24: k = 2 (else 1) */      \
     /* ---- one step per iteration */                                            \
     "10:\n\t"                                                                    \
     "s_cmp_ge_u32 s40, s68\n\t"                                                  \
@@ -181,7 +182,10 @@ namespace blance {
     "s_add_u32 s90, s78, -1\n\t"                                                 \
     "s_addc_u32 s91, s79, -1\n\t"                                                \
     "s_and_b64 s[90:91], s[90:91], s[78:79]\n\t"                                 \
-    "s_cbranch_scc0 81f\n\t"                                                     \
+    "s_cmp_eq_u32 s69, 0\n\t"                   /* k = 1: the first clean entry bounds the search */ \
+    "s_cselect_b64 s[90:91], s[78:79], s[90:91]\n\t"                             \
+    "s_cmp_eq_u64 s[90:91], 0\n\t"                                               \
+    "s_cbranch_scc1 81f\n\t"                                                     \
     "s_ff1_i32_b64 s92, s[78:79]\n\t"                                            \
     "s_ff1_i32_b64 s93, s[90:91]\n\t"                                            \
     "s_lshl_b64 s[90:91], 2, s93\n\t"                                            \
@@ -239,6 +243,8 @@ namespace blance {
     "s_cselect_b32 s95, 0x7fffffff, s82\n\t"                                     \
     "s_mov_b32 s91, -2\n\t"                                                      \
     "s_mov_b32 s93, -2\n\t"                                                      \
+    "s_cmp_eq_u32 s69, 0\n\t"                                                    \
+    "s_cbranch_scc1 25f\n\t"                                                     \
     BLANCE_QW_LT96("s94", "s84", "s85", "s76", "s74", "s75")                     \
     "s_cbranch_scc0 20f\n\t"                                                     \
     BLANCE_QW_LT96("s95", "s86", "s87", "s76", "s74", "s75")                     \
@@ -271,7 +277,18 @@ namespace blance {
     "s_mov_b32 s93, s82\n\t"                                                     \
     "s_mov_b32 s98, s79\n\t"                                                     \
     "s_mov_b32 s99, s77\n\t"                                                     \
-    "s_mov_b32 s100, s78\n"                                                      \
+    "s_mov_b32 s100, s78\n\t"                                                    \
+    "s_branch 22f\n"                                                             \
+    "25:\n\t"                                   /* k = 1: the better of a and t1 */ \
+    BLANCE_QW_LT96("s94", "s84", "s85", "s76", "s74", "s75")                     \
+    "s_cbranch_scc1 70f\n\t"                                                     \
+    "s_mov_b32 s96, s76\n\t"                    /* t1 enters, a leaves */         \
+    "s_mov_b32 s97, -1\n\t"                                                      \
+    "s_mov_b32 s90, s76\n\t"                                                     \
+    "s_mov_b32 s92, s81\n\t"                                                     \
+    "s_mov_b32 s98, s76\n\t"                                                     \
+    "s_mov_b32 s99, s74\n\t"                                                     \
+    "s_mov_b32 s100, s75\n"                                                      \
     "22:\n\t"                                                                    \
     BLANCE_QW_LT96("s98", "s99", "s100", "s44", "s42", "s43")                    \
     "s_cbranch_scc0 81f\n\t"                     /* not below THETA: the caller rebuilds the window or scores every node */ \
@@ -376,7 +393,7 @@ __device__ __forceinline__ void queue_walk_k2(QueueWalkState& st, unsigned long 
                    "{s56}"(cfa), "{s57}"(cfb), "{s58}"(cfc), "{s59}"(cfd), "{s[38:39]}"(lp1_bits)
                  : "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",
                    "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
-                   "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
+                   "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
                    "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
                    "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "vcc", "m0", "scc", "memory");
 }
