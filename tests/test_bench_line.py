@@ -1,4 +1,4 @@
-"""The bench line contract, checked on the line committed from the last device run (profiles/r3_bench_default.json):
+"""The bench line contract, checked on the line committed from the last device run (profiles/r4_bench_default.json):
 the keys the driver parses, BASELINE.json's metric and headline workload, a roofline object that follows from its own
 inputs, a CPU baseline with its sample stated -- and the bookkeeping that ties the quoted counters to kernel sources."""
 import json
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r3_bench_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r4_bench_default.json")) as f:
         return json.load(f)
 
 
@@ -51,26 +51,34 @@ def test_cpu_baseline_states_its_sample():
 
 
 def test_quoted_counters_are_tied_to_kernel_sources():
-    """bench.py quotes a committed PMC profile only for the kernel sources it was taken from, or for sources listed --
-    with the reason -- in profiles/r3_equivalent_sources.json; anything else gives traffic null."""
+    """bench.py quotes a committed PMC profile only for the kernel sources it was taken from -- no list of "equivalent"
+    sources: any other hash gives traffic null (the default run measures its traffic live anyway, bench.live_pmc)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench
     import profile_summary
     now = profile_summary.source_hash()
-    data, src = bench.profile_json("r3_pmc_hbm_config3.json")
-    with open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_config3.json")) as f:
-        profiled = json.load(f)["source_hash"]
-    if now == profiled:
-        assert data is not None and profiled in src
-    else:
-        with open(os.path.join(ROOT, "profiles", "r3_equivalent_sources.json")) as f:
-            eq = json.load(f)
-        if eq.get(now, {}).get("profiled_as") == profiled:
-            assert data is not None and now in src and profiled in src and "r3_NOTE_sources.txt" in src
-            assert os.path.exists(os.path.join(ROOT, "profiles", "r3_NOTE_sources.txt"))
+    for name in ("r4_pmc_hbm_config3.json", "r4_pmc_sq_config3.json", "r4_pmc_hbm_config5.json"):
+        data, src = bench.profile_json(name)
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            profiled = json.load(f)["source_hash"]
+        if now == profiled:
+            assert data is not None and profiled in src
         else:
             assert data is None and "other kernel sources" in src
+    data, src = bench.profile_json("r4_no_such_profile.json")
+    assert data is None
+
+
+def test_committed_line_measured_its_traffic_in_the_same_run():
+    """The committed default line: roofline.traffic comes from PMC passes of the run itself, per launch of the dominant
+    kernel, and both byte models stand side by side."""
+    r = _line()["roofline"]
+    assert r["traffic"] and "measured in this run" in r["traffic_from"]
+    assert r["survey_8d_bytes_per_launch"] > r["algorithmic_bytes_per_launch"]
+    assert abs(r["survey_8d_frac"] - r["survey_8d_GBps"] / r["peak"]) < 1e-9
+    gr = _line()["general_regime"]
+    assert len(gr) == 2 and all(w["matches_oracle_digest"] is True and w["headline"] is False for w in gr)
 
 
 def test_live_line_of_a_rehearsal_has_the_same_fields():
@@ -92,7 +100,7 @@ def test_live_line_of_a_rehearsal_has_the_same_fields():
         assert key in d, key
     assert d["rehearsal"] is True and d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
     assert d["metric"] == committed["metric"] and d["unit"] == committed["unit"] and d["dtype"] == committed["dtype"]
-    assert set(committed["roofline"]) <= set(d["roofline"]) | {"traffic_from", "critical_path", "occupancy"}
+    assert set(committed["roofline"]) <= set(d["roofline"]) | {"traffic_from", "traffic_launches_counted", "critical_path", "occupancy"}
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["sample"]
 
 
