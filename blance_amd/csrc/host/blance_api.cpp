@@ -12,11 +12,17 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <set>
 #include <unordered_map>
 
 #include "../../../include/blance_hip.h"
+#ifdef BLANCE_CALL_ARENA
+#include "call_arena.hpp"
+#endif
 
 namespace blance {
 
@@ -25,6 +31,12 @@ Booster NodeScoreBooster = Booster::None;      // plan.go:693
 bool CustomNodeSorterIsDefault = true;         // plan.go:580
 
 namespace {
+
+#ifdef BLANCE_CALL_ARENA
+using ArenaScope = arena::Scope;        // allocations of the enclosing block, this thread: from the call's region
+#else
+struct ArenaScope { ArenaScope() {} };  // (call_arena.cpp not linked in: plain malloc)
+#endif
 
 struct Abi {
     int (*validate)(const blance_problem*) = nullptr;
@@ -165,7 +177,7 @@ struct Scratch {
     Flat flat;
     std::vector<int32_t> out_off, out_nodes, warn_part, warn_state;
     std::vector<uint8_t> out_kind;
-    std::vector<PartitionPtr> parts;
+    std::vector<PartitionPtr> parts, stored;
 };
 
 template <class T>
@@ -174,10 +186,89 @@ const T* ptr(const std::vector<T>& v) {
     return v.empty() ? dummy : v.data();
 }
 
+// The entries of a std::map in key order, as pointers.  A million-entry tree is a million dependent cache misses when it
+// is walked with an iterator; its subtrees are independent, so a few threads walk one each.  That needs the tree's root, which
+// the interface does not give: libstdc++'s iterator exposes its node (`_M_node`), the header's parent is the root (stl_tree.h).
+// With any other library this is the plain walk.
+template <class Map>
+void collect_in_order(const Map& m, std::vector<const typename Map::value_type*>& out, int n_threads, size_t min_size = 4096) {
+    using V = typename Map::value_type;
+    out.clear();
+    out.reserve(m.size());
+#if defined(__GLIBCXX__)
+    using Base = std::_Rb_tree_node_base;
+    using Node = std::_Rb_tree_node<V>;
+    if (n_threads > 1 && m.size() >= min_size) {
+        const Base* root = m.end()._M_node->_M_parent;
+        struct Task { const Base* n; bool subtree; std::vector<const V*> got; };
+        std::vector<Task> tasks;                            // in key order: subtrees of depth-5 nodes and the nodes above them
+        struct Frame { const Base* n; int d; bool left_done; };
+        std::vector<Frame> st{{root, 0, false}};
+        while (!st.empty()) {
+            Frame fr = st.back();
+            st.pop_back();
+            if (!fr.n) continue;
+            if (fr.d == 5) { tasks.push_back(Task{fr.n, true, {}}); continue; }
+            if (!fr.left_done) {
+                st.push_back(Frame{fr.n, fr.d, true});
+                st.push_back(Frame{fr.n->_M_left, fr.d + 1, false});
+            } else {
+                tasks.push_back(Task{fr.n, false, {}});
+                st.push_back(Frame{fr.n->_M_right, fr.d + 1, false});
+            }
+        }
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            std::vector<const Base*> stack;
+            for (;;) {
+                const size_t ti = next.fetch_add(1);
+                if (ti >= tasks.size()) break;
+                Task& t = tasks[ti];
+                if (!t.subtree) continue;
+                const Base* n = t.n;
+                stack.clear();
+                while (n || !stack.empty()) {               // in-order, children fetched ahead
+                    while (n) {
+                        if (n->_M_left) __builtin_prefetch(n->_M_left);
+                        if (n->_M_right) __builtin_prefetch(n->_M_right);
+                        stack.push_back(n);
+                        n = n->_M_left;
+                    }
+                    n = stack.back();
+                    stack.pop_back();
+                    t.got.push_back(static_cast<const Node*>(n)->_M_valptr());
+                    n = n->_M_right;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_threads; i++) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+        for (auto& t : tasks) {
+            if (t.subtree) out.insert(out.end(), t.got.begin(), t.got.end());
+            else out.push_back(static_cast<const Node*>(t.n)->_M_valptr());
+        }
+        if (out.size() == m.size()) return;
+        out.clear();                                        // (not the layout this was written for: the plain walk)
+    }
+#endif
+    (void)n_threads;
+    for (auto& kv : m) out.push_back(&kv);
+}
+
 void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, const std::vector<std::string>& nodesAll,
            const StringList& nodesToRemove, const StringList& nodesToAdd, const PartitionModel& model,
            const PlanNextMapOptions& o) {
     static const PartitionMap empty_map;
+    const bool tr_ = getenv("BLANCE_HOST_TRACE") != nullptr;
+    auto t0_ = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!tr_) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0_).count());
+        t0_ = t1;
+    };
     if (!prevMapIn && !assign.empty())
         throw Unsupported{"nil prevMap with partitions to assign (reference panics, plan.go:50)"};
     const PartitionMap& prevMap = prevMapIn ? *prevMapIn : empty_map;
@@ -226,149 +317,253 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     const int N = (int)nodes.names.size();
 
     // ---- partitions.  The maps are ordered by name (std::map, like the sorted walk the shim makes of Go's maps):
-    // prevMap and PartitionWeights are joined by walking them alongside partitionsToAssign, not looked up per name.
+    // prevMap and PartitionWeights are joined with partitionsToAssign by merging the three name-ordered sequences, not by
+    // a lookup per name.  At a million partitions this is the call's largest host cost, and all of it is waiting for
+    // memory (tree nodes and Partition objects lie wherever the caller allocated them), so it is done by a few threads:
+    // (1) the maps' entries are collected in name order, subtree by subtree (collect_in_order); (2) the partitions are cut
+    // into contiguous ranges; every range is flattened by one thread into its own buffers, which (3) are appended in order.
+    // One range (small inputs) is the same code without threads.
     const bool weights_nil = !o.PartitionWeights.has_value();
-    // one walk of the tree: the names are copied out (contiguous from here on) and parsed while they are in cache
+    int n_threads = 1;
+    const bool threads_forced = getenv("BLANCE_HOST_THREADS") != nullptr;          // (tests: the threaded paths on small maps)
+    if (const char* e = getenv("BLANCE_HOST_THREADS")) n_threads = std::max(1, atoi(e));
+    else if (assign.size() >= 65536) n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    using PmItem = const PartitionMap::value_type*;
+    using WItem = const std::map<std::string, int>::value_type*;
+    std::vector<PmItem> items, pitems;
+    std::vector<WItem> witems;
+    const size_t min_tree = threads_forced ? 8 : 4096;
+    collect_in_order(assign, items, n_threads, min_tree);
+    collect_in_order(prevMap, pitems, n_threads, min_tree);
+    if (!weights_nil) collect_in_order(*o.PartitionWeights, witems, n_threads, min_tree);
+    const int P = (int)items.size();
+    mark("maps in name order");
     std::vector<const Partition*>& pparts = f.pparts;
     std::vector<long long>& name_num = f.name_num;          // the name as a non-negative number (plan.go:525), or -1
     std::vector<std::string>& pnames = f.part_names;
-    pnames.reserve(assign.size());
-    pparts.reserve(assign.size());
-    name_num.reserve(assign.size());
-    f.assign_slot.reserve(assign.size());
-    for (auto& kv : assign) {
-        if (!kv.second) throw Unsupported{"nil *Partition in partitionsToAssign"};
-        pnames.push_back(kv.first);
-        long long v = 0;
-        name_num.push_back(atoi_go(kv.first, &v) && v >= 0 ? v : -1);
-        pparts.push_back(kv.second.get());
-        f.assign_slot.push_back(const_cast<PartitionPtr*>(&kv.second));
-    }
-    const int P = (int)pnames.size();
+    pnames.resize((size_t)P);
+    pparts.resize((size_t)P);
+    name_num.resize((size_t)P);
+    f.assign_slot.resize((size_t)P);
     f.prev_slot.assign((size_t)P, nullptr);
     f.part_weight.assign(P, 1);
     f.part_has_weight.assign(P, 0);
     f.part_in_prev.assign(P, 0);
     f.never_equal.assign(P, 0);
-    if (!weights_nil) {
-        auto iw = o.PartitionWeights->begin();
-        const auto we = o.PartitionWeights->end();
-        for (int i = 0; i < P && iw != we; i++) {
-            while (iw != we && iw->first < pnames[i]) ++iw;
-            if (iw != we && iw->first == pnames[i]) { f.part_weight[i] = iw->second; f.part_has_weight[i] = 1; }
-        }
-    }
+    f.a_kind.resize((size_t)P * M);
+    f.p_kind.resize((size_t)P * M);
+    f.a_off.resize((size_t)P * M + 1);
+    f.p_off.resize((size_t)P * M + 1);
+    f.a_off[0] = 0;
+    f.p_off[0] = 0;
     const bool any_removed = nodesToRemove && !nodesToRemove->empty();
-    f.a_off.reserve((size_t)P * M + 1);
-    f.p_off.reserve((size_t)P * M + 1);
-    f.a_kind.reserve((size_t)P * M);
-    f.p_kind.reserve((size_t)P * M);
-    f.a_off.push_back(0);
-    f.p_off.push_back(0);
-    long long abs_load = 0;
     auto labs64 = [](long long v) { return v < 0 ? -v : v; };
     static const std::map<std::string, StringList> no_states;
     // the model's states inside a NodesByState map: both are ordered by name -> one pass, no lookups
     std::vector<int> by_name(M);                            // state ids in name order
     for (int m = 0; m < M; m++) by_name[m] = m;
     std::sort(by_name.begin(), by_name.end(), [&](int a, int b) { return states[a] < states[b]; });
-    std::vector<const StringList*> lists(M);
-    std::vector<char> present(M);
-    auto split = [&](const std::map<std::string, StringList>& nbs, bool* foreign) {
-        for (int m = 0; m < M; m++) { lists[m] = nullptr; present[m] = 0; }
-        int bi = 0;
-        for (auto& kv : nbs) {
-            while (bi < M && states[by_name[bi]] < kv.first) bi++;
-            if (bi < M && states[by_name[bi]] == kv.first) { lists[by_name[bi]] = &kv.second; present[by_name[bi]] = 1; }
-            else *foreign = true;
-        }
+
+    struct Range {
+        int lo = 0, hi = 0;
+        std::vector<int32_t> a_nodes, p_nodes;              // the range's part of the CSR arrays (offsets relative to it)
+        std::vector<int32_t> load_state, load_node, load_weight;
+        std::vector<uint8_t> load_first;
+        long long abs_load = 0;
+        bool unknown_node = false;                          // a node name outside nodesAll: ids are given out in ONE order
+        bool failed = false;
+        Unsupported err;
     };
-    auto ip = prevMap.begin();
-    const auto pe = prevMap.end();
-    auto prev_only = [&](const std::string& name, const PartitionPtr& pp) {     // partitions only in prevMap
-        if (!pp) throw Unsupported{"nil *Partition in prevMap"};
-        long long w = 1;
-        if (!weights_nil) {
-            auto it = o.PartitionWeights->find(name);
-            if (it != o.PartitionWeights->end()) w = it->second;
-        }
-        if (pp->NodesByState)
-            for (auto& sl : *pp->NodesByState) {
-                if (!sl.second) continue;
-                auto is = sid.find(sl.first);
-                for (auto& x : *sl.second) {
-                    f.load_state.push_back(is == sid.end() ? M : is->second); f.load_node.push_back(nodes.add(x));
-                    f.load_weight.push_back((int32_t)w); f.load_first.push_back(0);
-                    abs_load += labs64(w);
-                }
-            }
-    };
-    for (int i = 0; i < P; i++) {
-        const std::string& name = pnames[i];
-        const Partition& pa = *pparts[i];
-        if (i + 16 < P) __builtin_prefetch(pparts[i + 16]);           // the objects lie wherever the caller allocated them
-        if (pa.Name != name) throw Unsupported{"partition key != Partition.Name"};
-        const auto& nbs = pa.NodesByState ? *pa.NodesByState : no_states;
-        bool foreign = false;
-        split(nbs, &foreign);
-        if (foreign) throw Unsupported{"partition carries a state that is not in the model"};
-        for (int m = 0; m < M; m++) {
-            if (present[m]) {
-                const StringList& l = *lists[m];
-                if (l) {
-                    const size_t first = f.a_nodes.size();
-                    for (auto& x : *l) f.a_nodes.push_back(nodes.add(x));
-                    for (size_t a = first; a < f.a_nodes.size(); a++)
-                        for (size_t b = first; b < a; b++)
-                            if (f.a_nodes[a] == f.a_nodes[b]) throw Unsupported{"duplicate node inside a state list"};
-                }
-                f.a_kind.push_back(l ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
-            } else {
-                f.a_kind.push_back(BLANCE_LIST_ABSENT);
-            }
-            f.a_off.push_back((int32_t)f.a_nodes.size());
-        }
-        while (ip != pe && ip->first < name) { prev_only(ip->first, ip->second); ++ip; }
-        const long long w = f.part_weight[i];
-        if (ip == pe || ip->first != name) {
-            if (any_removed && any_pass)
-                throw Unsupported{"nodesToRemove non-empty but a partition is missing from prevMap (plan.go:545)"};
-            for (int m = 0; m < M; m++) { f.p_kind.push_back(BLANCE_LIST_ABSENT); f.p_off.push_back((int32_t)f.p_nodes.size()); }
-            continue;
-        }
-        if (!ip->second) throw Unsupported{"nil *Partition in prevMap"};
-        f.part_in_prev[i] = 1;
-        f.prev_slot[(size_t)i] = const_cast<PartitionPtr*>(&ip->second);
-        const Partition& pp = *ip->second;
-        ++ip;
-        if (!pp.NodesByState || pp.Name != name) f.never_equal[i] = 1;
-        const auto& pn = pp.NodesByState ? *pp.NodesByState : no_states;
-        foreign = false;
-        split(pn, &foreign);
-        for (int m = 0; m < M; m++) {
-            if (present[m]) {
-                const StringList& l = *lists[m];
-                f.p_kind.push_back(l ? BLANCE_LIST_SET : BLANCE_LIST_NIL);
-                if (l)
-                    for (auto& x : *l) { f.p_nodes.push_back(nodes.add(x)); abs_load += labs64(w); }
-            } else {
-                f.p_kind.push_back(BLANCE_LIST_ABSENT);
-            }
-            f.p_off.push_back((int32_t)f.p_nodes.size());
-        }
-        if (foreign)
-            for (auto& kv : pn) {
-                if (sid.count(kv.first)) continue;
-                f.never_equal[i] = 1;
-                if (kv.second)
-                    for (auto& x : *kv.second) {
-                        f.load_state.push_back(M); f.load_node.push_back(nodes.add(x));
-                        f.load_weight.push_back((int32_t)w); f.load_first.push_back(1);
-                        abs_load += labs64(w);
-                    }
-            }
+    const int n_ranges = std::max(1, std::min(n_threads, P > 0 ? P : 1));
+    std::vector<Range> ranges((size_t)n_ranges);
+    for (int r = 0; r < n_ranges; r++) {
+        ranges[(size_t)r].lo = (int)((long long)P * r / n_ranges);
+        ranges[(size_t)r].hi = (int)((long long)P * (r + 1) / n_ranges);
     }
-    for (; ip != pe; ++ip) prev_only(ip->first, ip->second);
+    // single: the one thread may give new ids to names it meets (the reference's order of first appearance)
+    auto flatten = [&](Range& R, bool single, bool first_range, bool last_range) {
+        auto node_id = [&](const std::string& x) -> int32_t {
+            if (single) return nodes.add(x);
+            const int id = nodes.find(x);
+            if (id < 0) { R.unknown_node = true; return 0; }
+            return id;
+        };
+        std::vector<const StringList*> lists(M);
+        std::vector<char> present(M);
+        auto split = [&](const std::map<std::string, StringList>& nbs, bool* foreign) {
+            for (int m = 0; m < M; m++) { lists[m] = nullptr; present[m] = 0; }
+            int bi = 0;
+            for (auto& kv : nbs) {
+                while (bi < M && states[by_name[bi]] < kv.first) bi++;
+                if (bi < M && states[by_name[bi]] == kv.first) { lists[by_name[bi]] = &kv.second; present[by_name[bi]] = 1; }
+                else *foreign = true;
+            }
+        };
+        auto prev_only = [&](const std::string& name, const PartitionPtr& pp) {     // partitions only in prevMap
+            if (!pp) throw Unsupported{"nil *Partition in prevMap"};
+            long long w = 1;
+            if (!weights_nil) {
+                auto it = o.PartitionWeights->find(name);
+                if (it != o.PartitionWeights->end()) w = it->second;
+            }
+            if (pp->NodesByState)
+                for (auto& sl : *pp->NodesByState) {
+                    if (!sl.second) continue;
+                    auto is = sid.find(sl.first);
+                    for (auto& x : *sl.second) {
+                        R.load_state.push_back(is == sid.end() ? M : is->second); R.load_node.push_back(node_id(x));
+                        R.load_weight.push_back((int32_t)w); R.load_first.push_back(0);
+                        R.abs_load += labs64(w);
+                    }
+                }
+        };
+        if (R.lo >= R.hi && !(first_range && last_range)) return;
+        // where the range starts in the other two sequences; the first range also takes what lies in front of it
+        size_t ip = 0, pe = pitems.size(), iw = 0, we = witems.size();
+        if (!first_range && R.lo < P) {
+            const std::string& k = items[(size_t)R.lo]->first;
+            ip = (size_t)(std::lower_bound(pitems.begin(), pitems.end(), k, [](PmItem a, const std::string& b) { return a->first < b; }) - pitems.begin());
+            iw = (size_t)(std::lower_bound(witems.begin(), witems.end(), k, [](WItem a, const std::string& b) { return a->first < b; }) - witems.begin());
+        }
+        if (!last_range && R.hi < P) {
+            const std::string& k = items[(size_t)R.hi]->first;
+            pe = (size_t)(std::lower_bound(pitems.begin(), pitems.end(), k, [](PmItem a, const std::string& b) { return a->first < b; }) - pitems.begin());
+        }
+        R.a_nodes.reserve((size_t)(R.hi - R.lo) * 4);
+        R.p_nodes.reserve((size_t)(R.hi - R.lo) * 4);
+        for (int i = R.lo; i < R.hi; i++) {
+            if (i + 16 < R.hi) {
+                __builtin_prefetch(items[(size_t)i + 16]);
+                if (items[(size_t)i + 8]->second) __builtin_prefetch(items[(size_t)i + 8]->second.get());   // the objects lie wherever the caller allocated them
+            }
+            const auto& kv = *items[(size_t)i];
+            if (!kv.second) throw Unsupported{"nil *Partition in partitionsToAssign"};
+            const std::string& name = pnames[(size_t)i] = kv.first;
+            long long v = 0;
+            name_num[(size_t)i] = atoi_go(name, &v) && v >= 0 ? v : -1;
+            const Partition& pa = *kv.second;
+            pparts[(size_t)i] = &pa;
+            f.assign_slot[(size_t)i] = const_cast<PartitionPtr*>(&kv.second);
+            while (iw < we && witems[iw]->first < name) ++iw;
+            if (iw < we && witems[iw]->first == name) { f.part_weight[i] = witems[iw]->second; f.part_has_weight[i] = 1; }
+            if (pa.Name != name) throw Unsupported{"partition key != Partition.Name"};
+            const auto& nbs = pa.NodesByState ? *pa.NodesByState : no_states;
+            bool foreign = false;
+            split(nbs, &foreign);
+            if (foreign) throw Unsupported{"partition carries a state that is not in the model"};
+            for (int m = 0; m < M; m++) {
+                uint8_t kind = BLANCE_LIST_ABSENT;
+                if (present[m]) {
+                    const StringList& l = *lists[m];
+                    if (l) {
+                        const size_t first = R.a_nodes.size();
+                        for (auto& x : *l) R.a_nodes.push_back(node_id(x));
+                        for (size_t a = first; a < R.a_nodes.size(); a++)
+                            for (size_t b = first; b < a; b++)
+                                if (R.a_nodes[a] == R.a_nodes[b] && !R.unknown_node) throw Unsupported{"duplicate node inside a state list"};
+                    }
+                    kind = l ? BLANCE_LIST_SET : BLANCE_LIST_NIL;
+                }
+                f.a_kind[(size_t)i * M + m] = kind;
+                f.a_off[(size_t)i * M + m + 1] = (int32_t)R.a_nodes.size();
+            }
+            while (ip < pe && pitems[ip]->first < name) { prev_only(pitems[ip]->first, pitems[ip]->second); ++ip; }
+            const long long w = f.part_weight[i];
+            if (ip >= pe || pitems[ip]->first != name) {
+                if (any_removed && any_pass)
+                    throw Unsupported{"nodesToRemove non-empty but a partition is missing from prevMap (plan.go:545)"};
+                for (int m = 0; m < M; m++) { f.p_kind[(size_t)i * M + m] = BLANCE_LIST_ABSENT; f.p_off[(size_t)i * M + m + 1] = (int32_t)R.p_nodes.size(); }
+                continue;
+            }
+            const PartitionPtr& pptr = pitems[ip]->second;
+            if (!pptr) throw Unsupported{"nil *Partition in prevMap"};
+            f.part_in_prev[i] = 1;
+            f.prev_slot[(size_t)i] = const_cast<PartitionPtr*>(&pptr);
+            const Partition& pp = *pptr;
+            ++ip;
+            if (!pp.NodesByState || pp.Name != name) f.never_equal[i] = 1;
+            const auto& pn = pp.NodesByState ? *pp.NodesByState : no_states;
+            foreign = false;
+            split(pn, &foreign);
+            for (int m = 0; m < M; m++) {
+                uint8_t kind = BLANCE_LIST_ABSENT;
+                if (present[m]) {
+                    const StringList& l = *lists[m];
+                    kind = l ? BLANCE_LIST_SET : BLANCE_LIST_NIL;
+                    if (l)
+                        for (auto& x : *l) { R.p_nodes.push_back(node_id(x)); R.abs_load += labs64(w); }
+                }
+                f.p_kind[(size_t)i * M + m] = kind;
+                f.p_off[(size_t)i * M + m + 1] = (int32_t)R.p_nodes.size();
+            }
+            if (foreign)
+                for (auto& kv2 : pn) {
+                    if (sid.count(kv2.first)) continue;
+                    f.never_equal[i] = 1;
+                    if (kv2.second)
+                        for (auto& x : *kv2.second) {
+                            R.load_state.push_back(M); R.load_node.push_back(node_id(x));
+                            R.load_weight.push_back((int32_t)w); R.load_first.push_back(1);
+                            R.abs_load += labs64(w);
+                        }
+                }
+        }
+        for (; ip < pe; ++ip) prev_only(pitems[ip]->first, pitems[ip]->second);
+    };
+    auto run_range = [&](int r, bool single) {
+        Range& R = ranges[(size_t)r];
+        try {
+            flatten(R, single, r == 0, r == n_ranges - 1);
+        } catch (const Unsupported& u) {
+            R.failed = true;
+            R.err = u;
+        }
+    };
+    bool again = false;
+    if (n_ranges > 1) {
+        std::vector<std::thread> th;
+        for (int r = 1; r < n_ranges; r++) th.emplace_back(run_range, r, false);
+        run_range(0, false);
+        for (auto& x : th) x.join();
+        for (auto& R : ranges) if (R.unknown_node) again = true;
+    }
+    if (n_ranges == 1 || again) {
+        // names outside nodesAll get their ids in the order one walk meets them: all of it again as one range
+        ranges.assign(1, Range());
+        ranges[0].lo = 0;
+        ranges[0].hi = P;
+        const int keep = n_ranges;
+        (void)keep;
+        Range& R = ranges[0];
+        try {
+            flatten(R, true, true, true);
+        } catch (const Unsupported& u) {
+            R.failed = true;
+            R.err = u;
+        }
+    }
+    for (auto& R : ranges) if (R.failed) throw R.err;        // (the first range in name order that met one)
+    long long abs_load = 0;
+    {
+        size_t na = 0, np = 0, nl = 0;
+        for (auto& R : ranges) { na += R.a_nodes.size(); np += R.p_nodes.size(); nl += R.load_state.size(); }
+        f.a_nodes.resize(na); f.p_nodes.resize(np);
+        f.load_state.reserve(nl); f.load_node.reserve(nl); f.load_weight.reserve(nl); f.load_first.reserve(nl);
+        size_t ba = 0, bp = 0;
+        for (auto& R : ranges) {
+            if (!R.a_nodes.empty()) memcpy(f.a_nodes.data() + ba, R.a_nodes.data(), R.a_nodes.size() * sizeof(int32_t));
+            if (!R.p_nodes.empty()) memcpy(f.p_nodes.data() + bp, R.p_nodes.data(), R.p_nodes.size() * sizeof(int32_t));
+            if (ba || bp)
+                for (size_t j = (size_t)R.lo * M + 1; j <= (size_t)R.hi * M; j++) { f.a_off[j] += (int32_t)ba; f.p_off[j] += (int32_t)bp; }
+            ba += R.a_nodes.size(); bp += R.p_nodes.size();
+            f.load_state.insert(f.load_state.end(), R.load_state.begin(), R.load_state.end());
+            f.load_node.insert(f.load_node.end(), R.load_node.begin(), R.load_node.end());
+            f.load_weight.insert(f.load_weight.end(), R.load_weight.begin(), R.load_weight.end());
+            f.load_first.insert(f.load_first.end(), R.load_first.begin(), R.load_first.end());
+            abs_load += R.abs_load;
+        }
+    }
+    mark("partitions -> ids");
     {
         long long sumw = 0, maxw = 0, ksum = 0;
         for (int i = 0; i < P; i++) { sumw += labs64(f.part_weight[i]); maxw = std::max<long long>(maxw, labs64(f.part_weight[i])); }
@@ -457,6 +652,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
         f.leaf_pos.assign(NX, -1);
     }
 
+    mark("nodes, hierarchy");
     // ---- static part of partitionSorter's key (plan.go:519-540): ("%10d" of 999999999 - weight, "%10d" of the name if
     // it is a non-negative number else the name, Name), compared as strings.  "%10d" renderings of values in
     // [0, 9999999999] compare like the values (digits right-aligned behind spaces), so such keys are sorted as
@@ -479,15 +675,35 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
             std::vector<int32_t>&idx = f.sort_idx, &idx2 = f.sort_idx2;
             key.resize((size_t)P); key2.resize((size_t)P); idx.resize((size_t)P); idx2.resize((size_t)P);
             for (int i = 0; i < P; i++) idx[(size_t)i] = i;
-            auto radix = [&](long long mx) {                // sorts idx by key[] (key[j] belongs to idx[j])
+            // sorts idx by key[] (key[j] belongs to idx[j]); each thread counts and scatters its own slice of the input,
+            // slices in order, so the sort stays stable
+            const int T = (P >= 65536 || threads_forced) ? std::max(1, std::min(n_threads, P)) : 1;
+            std::vector<std::vector<size_t>> cnt((size_t)T, std::vector<size_t>(2048));
+            auto parallel = [&](const std::function<void(int)>& fn) {
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; t++) th.emplace_back(fn, t);
+                fn(0);
+                for (auto& x : th) x.join();
+            };
+            auto radix = [&](long long mx) {
                 for (int shift = 0; shift < 63 && (mx >> shift) != 0; shift += 11) {
-                    size_t cnt[2049] = {0};
-                    for (int i = 0; i < P; i++) cnt[((key[(size_t)i] >> shift) & 2047) + 1]++;
-                    for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
-                    for (int i = 0; i < P; i++) {
-                        const size_t at = cnt[(key[(size_t)i] >> shift) & 2047]++;
-                        key2[at] = key[(size_t)i]; idx2[at] = idx[(size_t)i];
-                    }
+                    parallel([&](int t) {
+                        auto& c = cnt[(size_t)t];
+                        std::fill(c.begin(), c.end(), 0);
+                        const size_t lo = (size_t)P * t / T, hi = (size_t)P * (t + 1) / T;
+                        for (size_t i = lo; i < hi; i++) c[(key[i] >> shift) & 2047]++;
+                    });
+                    size_t at = 0;
+                    for (int d = 0; d < 2048; d++)
+                        for (int t = 0; t < T; t++) { const size_t n = cnt[(size_t)t][(size_t)d]; cnt[(size_t)t][(size_t)d] = at; at += n; }
+                    parallel([&](int t) {
+                        auto& c = cnt[(size_t)t];
+                        const size_t lo = (size_t)P * t / T, hi = (size_t)P * (t + 1) / T;
+                        for (size_t i = lo; i < hi; i++) {
+                            const size_t to = c[(key[i] >> shift) & 2047]++;
+                            key2[to] = key[i]; idx2[to] = idx[i];
+                        }
+                    });
                     key.swap(key2); idx.swap(idx2);
                 }
             };
@@ -518,6 +734,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
         }
     }
 
+    mark("static order");
     blance_problem& pb = f.pb;
     pb.n_nodes = N; pb.n_nodes_ext = NX; pb.n_states = M; pb.n_parts = P; pb.n_prev = (int32_t)prevMap.size();
     pb.n_loads = (int32_t)f.load_state.size(); pb.n_rules = (int32_t)f.rule_inc.size(); pb.n_vertices = VX;
@@ -584,6 +801,10 @@ void Library::trim() {
     std::vector<int32_t>().swap(sc.warn_part); std::vector<int32_t>().swap(sc.warn_state);
     std::vector<uint8_t>().swap(sc.out_kind);
     std::vector<PartitionPtr>().swap(sc.parts);
+    std::vector<PartitionPtr>().swap(sc.stored);
+#ifdef BLANCE_CALL_ARENA
+    arena::trim();
+#endif
 }
 
 void Library::close() {
@@ -648,21 +869,36 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     out.converged = res.converged != 0;
     if (res.iterations == 0) { out.nil_result = true; return out; }
     // ids -> strings.  What this costs is allocations -- per partition its Partition, two map nodes, two list buffers,
-    // a node of the result map (node names fit the small-string buffer): ~7 M mallocs at config 3.  Building the objects
-    // on several threads does not help (measured on the MI355X box: 1 thread 205 ms, 4 threads 215 ms, 32 threads 440 ms
-    // -- the allocator and the page faults behind it serialise), so this is one loop; the map is filled in name order
-    // -- the order the partitions were taken from partitionsToAssign -- so every insertion lands at the end.
+    // a node of the result map (node names fit the small-string buffer): ~7 M at config 3, twice that when the call
+    // converged (below).  With glibc's malloc that was 230-450 ms and did not scale over threads (the allocator and the
+    // page faults behind it serialise).  Now (call_arena.hpp, when it is linked in) they are pointer bumps in per-thread
+    // chunks that are reused, warm, from call to call: the objects are built in blocks of kBlock partitions by a few
+    // threads, then the result map, the stores into prevMap and the stores into partitionsToAssign run side by side.
+    const bool need_store = (res.iterations > 1 || !res.converged) && prevMap;
+    // What the reference leaves in the input maps are the objects of the LAST SWEEP THAT DID NOT CONVERGE: when the call
+    // converged in sweep n > 1 those are sweep n - 1's -- equal in content to the returned ones (that is what converged
+    // means, plan.go:36-45) but not the same objects (plan.go:334-343 makes fresh ones every sweep), so a caller that
+    // edits nextMap[p] afterwards does not edit prevMap[p].  At the iteration cap the returned objects ARE the stored
+    // ones (plan.go:49-52 ran on them).  One second object per partition, shared by both input maps as in the reference.
+    const bool need_clones = need_store && res.converged;
     std::vector<PartitionPtr>& parts = sc.parts;
+    std::vector<PartitionPtr>& stored = sc.stored;
     parts.clear();
     parts.resize((size_t)P);
-    // the result's Partition objects live in ONE block (a million make_shared calls are a million control blocks): every
-    // PartitionPtr aliases the block and keeps it alive
-    auto block = std::make_shared<std::vector<Partition>>((size_t)P);
-    for (int p = 0; p < P; p++) {
-        PartitionPtr part(block, &(*block)[(size_t)p]);
-        part->Name = f.part_names[p];
-        part->NodesByState.emplace();
-        auto& nbs = *part->NodesByState;
+    stored.clear();
+    if (need_clones) stored.resize((size_t)P);
+    int kBlock = 8192, n_threads = 1;
+    if (const char* e = getenv("BLANCE_HOST_BLOCK")) kBlock = std::max(1, atoi(e));        // (tests: many blocks on small maps)
+    if (const char* e = getenv("BLANCE_HOST_THREADS")) n_threads = std::max(1, atoi(e));
+    else if (P >= 65536) n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    const int n_blocks = (P + kBlock - 1) / kBlock;
+    n_threads = std::max(1, std::min(n_threads, n_blocks));
+    std::atomic<int> next_block{0};
+    std::atomic<bool> failed{false};
+    auto fill = [&](Partition& part, int p) {
+        part.Name = f.part_names[(size_t)p];
+        part.NodesByState.emplace();
+        auto& nbs = *part.NodesByState;
         for (int m = 0; m < M; m++) {
             size_t i = (size_t)p * M + m;
             if (out_kind[i] == BLANCE_LIST_ABSENT) continue;
@@ -672,11 +908,38 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
             for (int32_t j = out_off[i]; j < out_off[i + 1]; j++) lst.push_back(f.node_names[out_nodes[j]]);
             nbs[f.state_names[m]] = std::move(lst);
         }
-        parts[(size_t)p] = std::move(part);
+    };
+    auto build_blocks = [&]() {
+        try {
+            ArenaScope scope;
+            for (;;) {
+                const int b = next_block.fetch_add(1);
+                if (b >= n_blocks || failed.load()) break;
+                const int lo = b * kBlock, hi = std::min(P, lo + kBlock);
+                // the Partition objects of a block live in ONE array (a make_shared each would be a control block each):
+                // every PartitionPtr aliases its block and keeps it alive
+                for (int copy = 0; copy < (need_clones ? 2 : 1); copy++) {
+                    auto block = std::make_shared<std::vector<Partition>>((size_t)(hi - lo));
+                    std::vector<PartitionPtr>& dst = copy ? stored : parts;
+                    for (int p = lo; p < hi; p++) {
+                        fill((*block)[(size_t)(p - lo)], p);
+                        dst[(size_t)p] = PartitionPtr(block, &(*block)[(size_t)(p - lo)]);
+                    }
+                }
+            }
+        } catch (...) {
+            failed.store(true);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_threads; i++) th.emplace_back(build_blocks);
+        build_blocks();
+        for (auto& x : th) x.join();
     }
+    if (failed.load()) { out.handled = false; out.why = "out of memory while building the result"; parts.clear(); stored.clear(); return out; }
     out.unintern_parts_ms = ms_since(t_un);
-    for (int p = 0; p < P; p++) out.nextMap.emplace_hint(out.nextMap.end(), f.part_names[p], parts[(size_t)p]);
-    out.unintern_map_ms = ms_since(t_un) - out.unintern_parts_ms;
+    out.threads = n_threads;
     for (int64_t i = 0; i < res.n_warnings; i++) {           // plan.go:231-234
         const std::string& name = f.part_names[warn_part[i]];
         char buf[64];
@@ -686,45 +949,59 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
     }
     // plan.go:49-52: every non-converged sweep stores its partitions into both input maps;
     // the last such store has the final map's content
-    if ((res.iterations > 1 || !res.converged) && prevMap) {
-        // What the reference leaves in the input maps are the objects of the LAST SWEEP THAT DID NOT CONVERGE: when the call
-        // converged in sweep n > 1 those are sweep n - 1's -- equal in content to the returned ones (that is what converged
-        // means, plan.go:36-45) but not the same objects (plan.go:334-343 makes fresh ones every sweep), so a caller that
-        // edits nextMap[p] afterwards does not edit prevMap[p].  At the iteration cap the returned objects ARE the stored
-        // ones (plan.go:49-52 ran on them).  One clone per partition, shared by both maps as in the reference.
-        if (res.converged) {
-            auto clones = std::make_shared<std::vector<Partition>>(*block);
-            for (int p = 0; p < P; p++) parts[(size_t)p] = PartitionPtr(clones, &(*clones)[(size_t)p]);
+    const std::vector<PartitionPtr>& to_store = need_clones ? stored : parts;
+    // the slots recorded while the maps were read: independent stores (the tree is not walked a second time);
+    // names the map does not hold yet are inserted in name order, each right after its predecessor
+    // (the slot stores are not spread over threads: what they let go of is the caller's malloc'ed objects, and glibc's free
+    // does not scale -- measured: 60 ms with 1, 2, 3 or 4 threads)
+    auto store = [&](PartitionMap& dst, const std::vector<PartitionPtr*>& slot) {
+        ArenaScope scope;                                  // (nodes this adds to the caller's map: deleted like any other)
+        size_t missing = 0;
+        for (int p = 0; p < P; p++) {                      // the map nodes and the objects they let go of lie wherever the
+            if (p + 32 < P && slot[(size_t)p + 32]) __builtin_prefetch(slot[(size_t)p + 32]);             // caller put them
+            if (p + 8 < P && slot[(size_t)p + 8]) __builtin_prefetch(slot[(size_t)p + 8]->get());
+            if (slot[(size_t)p]) *slot[(size_t)p] = to_store[(size_t)p];
+            else missing++;
         }
-        // the slots recorded while the maps were read: independent stores (the tree is not walked a second time);
-        // names the map does not hold yet are inserted in name order, each right after its predecessor
-        auto store = [&](PartitionMap& dst, const std::vector<PartitionPtr*>& slot) {
-            size_t missing = 0;
-            for (int p = 0; p < P; p++) {                  // the map nodes and the objects they let go of lie wherever the
-                if (p + 32 < P && slot[(size_t)p + 32]) __builtin_prefetch(slot[(size_t)p + 32]);             // caller put them
-                if (p + 8 < P && slot[(size_t)p + 8]) __builtin_prefetch(slot[(size_t)p + 8]->get());
-                if (slot[(size_t)p]) *slot[(size_t)p] = parts[(size_t)p];
-                else missing++;
-            }
-            if (!missing) return;
-            if (missing < (size_t)P / 16) {                // few: a lookup each costs less than the walk
-                for (int p = 0; p < P; p++)
-                    if (!slot[(size_t)p]) dst.emplace(f.part_names[(size_t)p], parts[(size_t)p]);
-                return;
-            }
-            auto id = dst.begin();
-            for (int p = 0; p < P; p++) {
-                if (slot[(size_t)p]) continue;
-                const std::string& name = f.part_names[(size_t)p];
-                while (id != dst.end() && id->first < name) ++id;
-                dst.emplace_hint(id, name, parts[(size_t)p]);      // lands right before id, which stays the successor
-            }
-        };
+        if (!missing) return;
+        if (missing < (size_t)P / 16) {                    // few: a lookup each costs less than the walk
+            for (int p = 0; p < P; p++)
+                if (!slot[(size_t)p]) dst.emplace(f.part_names[(size_t)p], to_store[(size_t)p]);
+            return;
+        }
+        auto id = dst.begin();
+        for (int p = 0; p < P; p++) {
+            if (slot[(size_t)p]) continue;
+            const std::string& name = f.part_names[(size_t)p];
+            while (id != dst.end() && id->first < name) ++id;
+            dst.emplace_hint(id, name, to_store[(size_t)p]);       // lands right before id, which stays the successor
+        }
+    };
+    {
         const auto t_st = std::chrono::steady_clock::now();
-        store(*prevMap, f.prev_slot);
-        if (&partitionsToAssign != prevMap) store(partitionsToAssign, f.assign_slot);
-        out.store_ms = ms_since(t_st);
+        double prev_ms = 0.0, assign_ms = 0.0;
+        auto store_prev = [&]() { store(*prevMap, f.prev_slot); prev_ms = ms_since(t_st); };
+        auto store_assign = [&]() { store(partitionsToAssign, f.assign_slot); assign_ms = ms_since(t_st); };
+        const bool two = need_store && &partitionsToAssign != prevMap;
+        std::vector<std::thread> th;
+        if (need_store && n_threads > 1) {
+            th.emplace_back(store_prev);
+            if (two) th.emplace_back(store_assign);
+        }
+        {   // the result map, filled in name order -- the order the partitions were taken from partitionsToAssign --
+            ArenaScope scope;                              // so every insertion lands at the end
+            for (int p = 0; p < P; p++) out.nextMap.emplace_hint(out.nextMap.end(), f.part_names[(size_t)p], parts[(size_t)p]);
+        }
+        out.unintern_map_ms = ms_since(t_st);
+        if (need_store && n_threads <= 1) {
+            store_prev();
+            if (two) store_assign();
+        }
+        for (auto& x : th) x.join();
+        if (getenv("BLANCE_HOST_TRACE")) fprintf(stderr, "[host] store prev %.1f ms, assign %.1f ms, result map %.1f ms (side by side)\n", prev_ms, assign_ms, out.unintern_map_ms);
+        out.store_ms = std::max(prev_ms, assign_ms);        // (side by side with the result map when threads are used)
     }
+    stored.clear();
     parts.clear();                                          // (the scratch keeps the capacity, not the partitions)
     out.unintern_ms = ms_since(t_un);
     return out;

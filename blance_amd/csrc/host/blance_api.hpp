@@ -64,6 +64,7 @@ struct PlanOutcome {
     double intern_ms = 0.0, plan_ms = 0.0, unintern_ms = 0.0, device_ms = 0.0;
     // inside unintern_ms: the Partition objects (threads), the result map, the stores of plan.go:49-52 into the input maps
     double unintern_parts_ms = 0.0, unintern_map_ms = 0.0, store_ms = 0.0;
+    int threads = 1;             // threads that built the result's objects (the result map and the two stores then run side by side)
 };
 
 // The C ABI entry points, resolved at run time so that one binary can drive

@@ -8,6 +8,9 @@
 #include <sstream>
 
 #include "blance_api.hpp"
+#ifdef BLANCE_CALL_ARENA
+#include "call_arena.hpp"
+#endif
 
 using namespace blance;
 
@@ -178,15 +181,21 @@ static int run_bench(Library& lib, int cfg, int P, int N) {
         r = PlanNextMapEx(lib, &prev, assign, nodes, std::vector<std::string>{}, nodes, model, o);
         total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
         if (!r.handled) { fprintf(stderr, "bench: not handled: %s\n", r.why.c_str()); return 4; }
+#ifdef BLANCE_CALL_ARENA
+        if (getenv("BLANCE_HOST_TRACE")) {
+            auto st = blance::arena::stats();
+            fprintf(stderr, "[host] round %d: parts %.1f ms; arena chunks in use %zu pooled %zu ever %zu\n", round, r.unintern_parts_ms, st.chunks_in_use, st.chunks_pooled, st.chunks_ever);
+        }
+#endif
     }
     const double assignments = 3.0 * P;
     printf("{\"what\": \"blance::PlanNextMapEx (C++ mirror of api.go:147), string maps in -> string maps out, second call\", "
            "\"partitions\": %d, \"nodes\": %d, \"sweeps\": %d, \"total_ms\": %.3f, \"intern_ms\": %.3f, "
            "\"blance_plan_ms\": %.3f, \"device_ms\": %.3f, \"unintern_ms\": %.3f, \"unintern_parts_ms\": %.3f, \"unintern_map_ms\": %.3f, "
            "\"store_into_input_maps_ms\": %.3f, \"caller_builds_input_maps_ms\": %.3f, "
-           "\"assignments_per_s\": %.1f, \"result_partitions\": %zu}\n",
+           "\"threads\": %d, \"assignments_per_s\": %.1f, \"result_partitions\": %zu}\n",
            P, N, r.iterations, total_ms, r.intern_ms, r.plan_ms, r.device_ms, r.unintern_ms, r.unintern_parts_ms, r.unintern_map_ms,
-           r.store_ms, build_ms,
+           r.store_ms, build_ms, r.threads,
            assignments / (total_ms * 1e-3), r.nextMap.size());
     return 0;
 }

@@ -17,11 +17,11 @@ CLI = os.path.join(ROOT, "blance_amd", "lib", "blance_host_cli")
 
 
 def build_cli():
-    srcs = [os.path.join(HOST, "blance_host_cli.cpp"), os.path.join(HOST, "blance_api.cpp")]
-    deps = srcs + [os.path.join(HOST, "blance_api.hpp"), os.path.join(ROOT, "include", "blance_hip.h")]
+    srcs = [os.path.join(HOST, "blance_host_cli.cpp"), os.path.join(HOST, "blance_api.cpp"), os.path.join(HOST, "call_arena.cpp")]
+    deps = srcs + [os.path.join(HOST, "blance_api.hpp"), os.path.join(HOST, "call_arena.hpp"), os.path.join(ROOT, "include", "blance_hip.h")]
     if not os.path.exists(CLI) or any(os.path.getmtime(d) > os.path.getmtime(CLI) for d in deps):
         os.makedirs(os.path.dirname(CLI), exist_ok=True)
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", CLI] + srcs + ["-ldl"])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-DBLANCE_CALL_ARENA", "-o", CLI] + srcs + ["-ldl"])
     return CLI
 
 
@@ -94,10 +94,13 @@ def serialize(cases):
     return "\n".join(out) + "\n"
 
 
-def run_cli(lib, cases, eager=False):
+def run_cli(lib, cases, eager=False, threads=0):
     env = dict(os.environ)
     if eager:
         env["BLANCE_HOST_EAGER_BULK"] = "1"
+    if threads:                                  # the threaded paths of the mirror (blance_api.cpp) on maps of any size
+        env["BLANCE_HOST_THREADS"] = str(threads)
+        env["BLANCE_HOST_BLOCK"] = "3"
     p = subprocess.run([build_cli(), lib], input=serialize(cases), capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr
     return json.loads(p.stdout)
@@ -194,6 +197,30 @@ def test_cpp_mirror_on_random_cases_emulated():
     from test_simt_emulated import build_emu
     cases = _random_cases(3000, 3160)
     assert _check_random(cases, run_cli(build_emu(), cases)) > 100
+
+
+def test_cpp_mirror_threaded_paths_emulated(golden_cases):
+    """What the mirror does with several threads at a million partitions -- the maps collected subtree by subtree, the
+    partitions flattened in ranges, the static order by a threaded radix sort, the result built in blocks, the stores side by
+    side, everything the result holds in the call's region (call_arena.cpp) -- forced onto the reference's tables, random
+    cases and maps with names missing from prevMap: same results, same caller-visible mutations, same object identities."""
+    from test_simt_emulated import build_emu
+    for t in (2, 5):
+        _check(golden_cases, run_cli(build_emu(), golden_cases, threads=t))
+    cases = _random_cases(3200, 3320)
+    assert _check_random(cases, run_cli(build_emu(), cases, threads=3)) > 70
+    cases = _sparse_miss_cases(5200, 5280)
+    assert _check_random(cases, run_cli(build_emu(), cases, threads=4)) > 10
+
+
+def test_call_arena_on_its_own(tmp_path):
+    """The region allocator behind the mirror's result objects (call_arena.cpp): built on four threads, deleted piecemeal on
+    four others, chunks recycled and reused, large / over-aligned requests and everything outside a Scope left to malloc."""
+    exe = str(tmp_path / "arena_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "tools", "arena_test.cpp"),
+                           os.path.join(HOST, "call_arena.cpp")])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().startswith("ok"), p.stdout + p.stderr
 
 
 def _sparse_miss_cases(lo, hi):
