@@ -218,10 +218,23 @@ func planNextMapHip(
 		return nil, nil, true
 	}
 
-	// ---- ids back to strings: fresh *Partition objects, every state key of the input carried through
-	nextMap = make(PartitionMap, P)
-	for p := 0; p < P; p++ {
-		part := &Partition{Name: f.partNames[p], NodesByState: make(map[string][]string, M)}
+	// ---- ids back to strings: fresh *Partition objects, every state key of the input carried through.
+	// Three allocations carry them instead of five per partition: one []Partition, one []string holding the node names
+	// of every list back to back (a list is a full slice expression of it -- cap == len --, so an append by the caller
+	// reallocates instead of running into the next list), and the result map sized up front.  The NodesByState map of a
+	// partition stays one make each (Go cannot carve maps out of a block).  When the call converged in sweep n > 1 the
+	// input maps get a SECOND set of objects (below); it comes out of the same two blocks.
+	stores := int(res.iterations) > 1 || res.converged == 0
+	copies := 1
+	if stores && res.converged != 0 {
+		copies = 2
+	}
+	total := int(outOff[PM])
+	parts := make([]Partition, copies*P)
+	names := make([]string, copies*total)
+	fill := func(part *Partition, p int, base int) {
+		part.Name = f.partNames[p]
+		part.NodesByState = make(map[string][]string, M)
 		for m := 0; m < M; m++ {
 			i := p*M + m
 			switch outKind[i] {
@@ -229,14 +242,18 @@ func planNextMapHip(
 			case listNil:
 				part.NodesByState[f.stateNames[m]] = nil
 			default:
-				lst := make([]string, 0, outOff[i+1]-outOff[i])
-				for j := outOff[i]; j < outOff[i+1]; j++ {
-					lst = append(lst, f.nodeNames[outNodes[j]])
+				lo, hi := base+int(outOff[i]), base+int(outOff[i+1])
+				for j := lo; j < hi; j++ {
+					names[j] = f.nodeNames[outNodes[j-base]]
 				}
-				part.NodesByState[f.stateNames[m]] = lst
+				part.NodesByState[f.stateNames[m]] = names[lo:hi:hi] // non-nil also when empty
 			}
 		}
-		nextMap[part.Name] = part
+	}
+	nextMap = make(PartitionMap, P)
+	for p := 0; p < P; p++ {
+		fill(&parts[p], p, 0)
+		nextMap[parts[p].Name] = &parts[p]
 	}
 	warnings = map[string][]string{}
 	for i := 0; i < int(res.n_warnings); i++ { // plan.go:231-234, the reference's own text
@@ -251,31 +268,16 @@ func planNextMapHip(
 	// returned ones, but not the same objects (plan.go:334-343 makes fresh ones every sweep) -- a caller that
 	// edits nextMap[p] afterwards must not edit prevMap[p].  At the iteration cap the returned objects ARE
 	// the stored ones.  One clone per partition, shared by both maps as in the reference.
-	if int(res.iterations) > 1 || res.converged == 0 {
-		for name, part := range nextMap {
-			stored := part
-			if res.converged != 0 {
-				stored = clonePartition(part)
+	if stores {
+		for p := 0; p < P; p++ {
+			stored := &parts[p]
+			if copies == 2 {
+				stored = &parts[P+p]
+				fill(stored, p, total)
 			}
-			prevMap[name] = stored
-			partitionsToAssign[name] = stored
+			prevMap[stored.Name] = stored
+			partitionsToAssign[stored.Name] = stored
 		}
 	}
 	return nextMap, warnings, true
-}
-
-// clonePartition: a deep copy (nil maps and nil slices stay nil: reflect.DeepEqual tells them from empty ones, plan.go:38).
-func clonePartition(p *Partition) *Partition {
-	c := &Partition{Name: p.Name}
-	if p.NodesByState != nil {
-		c.NodesByState = make(map[string][]string, len(p.NodesByState))
-		for s, l := range p.NodesByState {
-			if l == nil {
-				c.NodesByState[s] = nil
-			} else {
-				c.NodesByState[s] = append(make([]string, 0, len(l)), l...)
-			}
-		}
-	}
-	return c
 }
