@@ -485,6 +485,7 @@ def main():
             out["general_regime"] = general_regime(pl, fp, res, max(1, min(args.steps, 5)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config, full=args.cpu_full)
+        if world == 1 and not args.no_extra and not rehearsal:
             out["host_end_to_end"] = host_end_to_end(args.config)
     # ---- one plan over all ranks (config 4).  The line of the replicas is ready before this starts: RCCL is bound at
     # run time inside the library and has never met this node, so a watchdog prints that line if the leg does not return.

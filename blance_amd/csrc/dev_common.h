@@ -43,7 +43,7 @@ __device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0
 struct RedSlot { unsigned hi, lo; int n; int pad; };
 
 #ifdef BLANCE_PHASE_PROF     // developer build only: per-phase shader-clock totals of chain 0
-#define PH_DECL unsigned long long ph_acc[12] = {0}, ph_t0 = clock64(), ph_t1
+#define PH_DECL unsigned long long ph_acc[20] = {0}, ph_t0 = clock64(), ph_t1
 #define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
 #define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
     printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
@@ -51,10 +51,14 @@ struct RedSlot { unsigned hi, lo; int n; int pad; };
 #define PH_DECL
 #define PH(i) asm volatile("; PHASE_MARK " #i)
 #define PH_DUMP(steps)
+#define PHM(name) asm volatile("; MARK " #name)
 #else
 #define PH_DECL
 #define PH(i)
 #define PH_DUMP(steps)
+#endif
+#ifndef PHM
+#define PHM(name)            /* BLANCE_ASM_MARKS: a comment in the ISA */
 #endif
 
 constexpr unsigned kKeyNoneV = 0xffffffffu;

@@ -247,6 +247,57 @@ __global__ __launch_bounds__(1024) void k_fresh_threshold(FlatParams q, int beg,
         n_nw[i] = n_on[i] ? q.node_weight[n] : 0;
     }
     int probe = 0;
+    {
+        // A bracket before the bisection.  With A nodes in the race, the first ceil(R / A) elements of every node's sequence
+        // are >= R elements, so the R-th smallest is <= the largest of the nodes' elements number ceil(R / A) - 1; and a tau
+        // below every node's element number floor((R - 1) / A) has at most A floor((R - 1) / A) < R elements at or under
+        // it.  Nodes of equal load (a fresh plan) make the two bounds ONE key and the search below has nothing to do;
+        // otherwise it starts from a few thousand ulps instead of the whole 64-bit key space.
+        int mine = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; i++) mine += n_on[i] ? 1 : 0;
+        long long cntA = mine;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cntA += __shfl_xor((int)cntA, off, 64);
+        long long* row = part + 32;
+        if ((tid & 63) == 0) row[tid >> 6] = cntA;
+        __syncthreads();
+        long long A = 0;
+#pragma unroll
+        for (int wv = 0; wv < 16; wv++) A += row[wv];
+        __syncthreads();
+        if (A > 0 && R > 0) {
+            const int q_hi = (int)(((long long)R + A - 1) / A) - 1, q_lo = (int)(((long long)R - 1) / A);
+            unsigned long long kmin = ~0ull, kmax = 0;
+#pragma unroll
+            for (int i = 0; i < kPer; i++) {
+                if (!n_on[i]) continue;
+                const unsigned long long a = fresh_key_w(q, n_hw[i], n_nw[i], n_c0[i], n_t0[i], n_nt[i], w, q_lo);
+                const unsigned long long b = fresh_key_w(q, n_hw[i], n_nw[i], n_c0[i], n_t0[i], n_nt[i], w, q_hi < R ? q_hi : R - 1);
+                kmin = a < kmin ? a : kmin;
+                kmax = b > kmax ? b : kmax;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const unsigned long long a = ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(kmin >> 32), off, 64) << 32) |
+                                             (unsigned)__shfl_xor((int)(unsigned)kmin, off, 64);
+                const unsigned long long b = ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(kmax >> 32), off, 64) << 32) |
+                                             (unsigned)__shfl_xor((int)(unsigned)kmax, off, 64);
+                kmin = a < kmin ? a : kmin;
+                kmax = b > kmax ? b : kmax;
+            }
+            unsigned long long* urow = (unsigned long long*)(part + 64);
+            if ((tid & 63) == 0) { urow[tid >> 6] = kmin; urow[16 + (tid >> 6)] = kmax; }
+            __syncthreads();
+#pragma unroll
+            for (int wv = 0; wv < 16; wv++) {
+                kmin = urow[wv] < kmin ? urow[wv] : kmin;
+                kmax = urow[16 + wv] > kmax ? urow[16 + wv] : kmax;
+            }
+            __syncthreads();
+            if (kmin <= kmax) { lo = kmin; hi = kmax; }
+        }
+    }
     while (lo < hi) {
         unsigned long long mid = lo + (hi - lo) / 2;
         long long sum = 0;

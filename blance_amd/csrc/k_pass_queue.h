@@ -304,6 +304,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     const int cfb = (int)((((unsigned)(size_t)shL) >> 2) | ((((unsigned)(size_t)ffT) >> 2) << 16));
     const int cfc = (int)((((unsigned)(size_t)bitsL) >> 2) | ((unsigned)(BW * 4) << 16));
     int cfd = (int)(((unsigned)(size_t)gB) >> 2);   // | B << 16, per batch
+    const int cfe = (int)((((unsigned)(size_t)ntL) >> 2) | ((((unsigned)(size_t)lpT) >> 2) << 16));
     int mo1 = 0, mo2 = 0;                            // output nodes of the lanes the assembly walk moved
     const u64 lp_one = uni64((u64)__double_as_longlong(NP > 0 ? (double)1 / (double)NP : 0.0));      // = lpT[1], as bits
 #endif
@@ -579,14 +580,21 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 #endif
             int f = B;
             bool retried = false, back_to_asm = false;
+#ifdef BLANCE_QDEBUG4
+            int lean_why = 0;
+#define BLANCE_QWHY(x) lean_why = (x)
+#else
+#define BLANCE_QWHY(x)
+#endif
 #ifndef BLANCE_SIMT_EMU
             // ================= the lean walk in assembly (k_queue_walk.h) for the plain case; it leaves at a step it does not take
-            if (walk_asm && !fold) {
+            if (walk_asm) {
                 QueueWalkState st;
                 st.wk = wk; st.wn = wn; st.o1 = mo1; st.o2 = mo2; st.cur = cur; st.wcnt = wcnt; st.thK = thK; st.thN = thN;
                 st.stale = stalemask; st.moved = 0; st.code = 0;
                 queue_walk_k2(st, lastK, lastN, own_a, own_b, sKv[0], sKv[1], hv[0], wj, (ov0 & 0xffff) | (ov1 << 16), lane,
-                              sfailmask | dirtymask, slowmask, actmask, cfa, cfb, cfc, (cfd & 0xffff) | (B << 16) | ((k == 2 ? 1 : 0) << 24), lp_one);
+                              sfailmask | dirtymask, slowmask, actmask, cfa, cfb, cfc,
+                              (cfd & 0xffff) | (B << 16) | ((k == 2 ? 1 : 0) << 24) | ((fold ? 1 : 0) << 25), cfe, lp_one);
                 wk = st.wk; wn = st.wn; mo1 = st.o1; mo2 = st.o2;
                 const int c1_ = uni(st.cur);
                 wcnt = uni(st.wcnt); thK = uni64(st.thK); thN = uni(st.thN); stalemask = uni64(st.stale);
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 #endif
                 n_bulk += f - cur;
                 if (f >= B) break;
-                if (((slowmask | stalemask) >> f) & 1) break;
+                if (((slowmask | stalemask) >> f) & 1) { BLANCE_QWHY(((slowmask >> f) & 1) ? 1 : 2); break; }
                 const int w = __builtin_amdgcn_readlane(wj, f);
                 const int oa = __builtin_amdgcn_readlane(own_a, f), ob = __builtin_amdgcn_readlane(own_b, f);   // -1: none
                 const int hh = __builtin_amdgcn_readlane(hv[0], f);
@@ -682,6 +690,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 if (!lean_done) {
                     // the window ran dry (few entries, none of them a candidate): rebuild it once and look again
                     if (wcnt < 32 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
+                    BLANCE_QWHY(3);
                     break;
                 }
                 // the k smallest of the sorted pairs (ka, kb) and (t1, t2): which nodes leave, which enter
@@ -700,13 +709,38 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                         else { r2n = n2; rlast = t2; en2 = n2; lv1 = oa; lv2 = ob; }
                     } else lv1 = oa;
                 }
-                {   // a taken node that the partition holds in a lower priority state would be promoted (plan.go:294-297)
+                // a taken node that the partition holds in a lower priority state is promoted (plan.go:294-297): it leaves those
+                // lists, i.e. that state's counter of the node drops and the node's total does not grow.  np1 / np2: how many
+                // lower priority lists hold en1 / en2 (a node twice in one list counts once: misc.go:45); rare -- the record is
+                // only decoded when a taken node is among the step's lower priority nodes
+                int np1 = 0, np2 = 0;
+                bool promoted = false;
+                {
                     const int l0 = __builtin_amdgcn_readlane(ov0, f), l1 = __builtin_amdgcn_readlane(ov1, f);
-                    if ((en1 >= 0 && (en1 == l0 || en1 == l1)) || (en2 >= 0 && (en2 == l0 || en2 == l1))) break;
+                    promoted = (en1 >= 0 && (en1 == l0 || en1 == l1)) || (en2 >= 0 && (en2 == l0 || en2 == l1));
                 }
+                auto promotions = [&](bool apply) {
+                    const int* rf = recS + f * RW;
+                    for (int t = 0; t < M; t++) {
+                        if (t == s || ((q.higher_mask >> t) & 1)) continue;
+                        const int h = rf[kRecHead + t * SW];
+                        if ((h >> 16) == kListAbsent) continue;
+                        for (int jj = 0; jj < (h & 0xffff); jj++) {
+                            const int x = rf[kRecHead + t * SW + 1 + jj];
+                            bool first = true;
+                            for (int j2 = 0; j2 < jj; j2++) if (rf[kRecHead + t * SW + 1 + j2] == x) first = false;
+                            if (!first || x < 0 || (x != en1 && x != en2)) continue;
+                            if (apply) { if (lane == 0) q.cnt[t * NX + x] -= w; }
+                            else if (x == en1) np1++;
+                            else np2++;
+                        }
+                    }
+                };
+                if (promoted) promotions(false);
                 const int rlastn = k == 2 ? r2n : r1n;
                 if (rlastn == INT_MAX || !qless(rlast, rlastn, thK, thN)) {                  // beyond the window's reach
                     if (wcnt < 56 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
+                    BLANCE_QWHY(5);
                     break;
                 }
                 // lanes 0 .. 3 settle one node each: leaving, leaving, entering, entering
@@ -717,11 +751,12 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 if (hx >= 0) {
                     const int ds = lane < 2 ? -w : w;
                     c_new = cntL[hx] + ds;
-                    t_new = totL[hx] + ds;
+                    t_new = totL[hx] + ds - w * (lane == 2 ? np1 : lane == 3 ? np2 : 0);
                 }
                 int e_new = 0;
                 if (fold && hx >= 0) e_new = (int)ntL[hx] + (lane >= 2 ? 1 : 0);          // plan.go:238-245: the chosen nodes' entries of row ""
-                if (NP > 0 && __ballot(hx >= 0 && ((unsigned)t_new >= (unsigned)kFfTab || e_new >= kLpTab))) break;   // beyond the tables: the general code divides
+                if (NP > 0 && __ballot(hx >= 0 && ((unsigned)t_new >= (unsigned)kFfTab || e_new >= kLpTab))) { BLANCE_QWHY(6); break; }   // beyond the tables: the general code divides
+                if (promoted) promotions(true);               // (past the last way out of this step)
                 if (hx >= 0) {
                     double r = (double)c_new;                         // queue_score with no stickiness and a power-of-two weight
                     if (NP > 0) { r = r + lpT[e_new]; r = r + ffT[t_new]; }
@@ -750,13 +785,16 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 cur = f + 1;
                 retried = false;
 #ifndef BLANCE_SIMT_EMU
-                if (walk_asm && !fold) { back_to_asm = true; break; }
+                if (walk_asm) { back_to_asm = true; break; }
 #endif
             }
             PH(4);
             if (back_to_asm) continue;
             if (f >= B) break;
             cur = f;
+#ifdef BLANCE_QDEBUG4
+            if (fold && lane == 0) printf("[q4] folded walk left at step %d: reason %d (1 slow, 2 stale, 3 no candidate, 4 promotion, 5 beyond THETA, 6 tables) wcnt %d\n", oi + f, lean_why, wcnt);
+#endif
             if (fold) { stop_pos = oi + f; stop_why = kQStopShape; break; }        // (the general code reads the matrix, not the folded row)
             // lane-level views of the masks, and the front of the window, for the general code below
             bool stale = (stalemask >> lane) & 1;
@@ -844,6 +882,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                     // ---- the window cannot decide (its entries' exact scores lie above THETA: rows with many entries,
                     // many nodes of equal load): score every node exactly -- what the reference's sort sees
                     n_dense++;
+                    PHM(dense_begin);
+                    PH(12);
                     u64 lb[KM];
                     int ln[KM];
 #pragma unroll
@@ -884,6 +924,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 #pragma unroll
                             for (int u = 0; u < 8; u++) dirtycol |= (u64)((wv[u] >> (lane & 31)) & 1) << (i0 + u);
                         }
+                        PHM(dense_bits_done);
+                        PH(13);
                         for (int i0 = 0; i0 < G; i0 += 8) {
                             u64 kv[8];
 #pragma unroll
@@ -892,6 +934,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                             for (int u = 0; u < 8; u++)
                                 if (((cand & ~dirtycol) >> (i0 + u)) & 1) keep_local(kv[u], (i0 + u) * 64 + lane);
                         }
+                        PHM(dense_keys_done);
+                        PH(14);
                         u64 cK = ~0ull;                              // the k-th best clean key over the wave (~0: fewer than k)
                         {
                             u64 tb[KM];
@@ -908,6 +952,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                                 }
                             }
                         }
+                        PHM(dense_ck_done);
                         for (u64 dd = cand & dirtycol; dd; dd &= dd - 1) {
                             const int n = (__ffsll((long long)dd) - 1) * 64 + lane;
                             if (gB[n] > cK) continue;
@@ -934,6 +979,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                         }
                     }
                     }
+                    PHM(dense_dirty_done);
+                    PH(15);
                     for (int j = 0; j < k; j++) {
                         const QMin m = wave_min_key_node(lb[0], ln[0]);
                         if (m.node == INT_MAX) break;
@@ -944,6 +991,8 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                             lb[KM - 1] = ~0ull; ln[KM - 1] = INT_MAX;
                         }
                     }
+                    PHM(dense_end);
+                    PH(16);
                     n_out = 0;
 #pragma unroll
                     for (int j = 0; j < KM; j++) if (j < k && bN[j] != INT_MAX) n_out++;
@@ -965,6 +1014,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 const int cutoff = ck ? __ffsll((long long)ck) - 1 : 64;
                 const u64 upto = cutoff >= 63 ? ~0ull : ((2ull << cutoff) - 1);
                 const u64 dl = dm & upto;            // entries to read from the matrix
+                bool hopeless = false;
                 if (dl == 0) {
                     // ---- fast: the first k eligible entries, as they stand
                     u64 e2 = em & upto;
@@ -975,6 +1025,34 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, c);
                         insert(cb, __builtin_amdgcn_readlane(wn, c));
                     }
+                } else if ([&]() -> bool {
+                    // Can the window decide at all?  A pick is only final if it lies below THETA (a node outside the window
+                    // scores at least THETA).  An entry with its bit set scores at least what it would with an entry of 1
+                    // (plan.go:638-644 is monotone in the entry): when fewer than k of (own nodes, clean entries, such lower
+                    // bounds) lie below THETA, no reading of the matrix can make the window's answer final -- the regime of
+                    // many nodes at one load, where every entry of the window is held back by its matrix entry.
+                    if (thN == INT_MAX || !have_bits) return false;      // (without the bit map a set bit is no promise of an entry)
+                    bool can = false;
+                    if (((cm & upto) >> lane) & 1) can = qless(wk, wn, thK, thN);
+                    else if ((dl >> lane) & 1) {
+                        u64 lbk = wk;
+                        if (shL[wn] != 255) {
+                            const int tt = totL[wn];
+                            double r = (double)cntL[wn];
+                            r = r + lpT[1];
+                            r = r + ((unsigned)tt < (unsigned)kFfTab ? ffT[tt] : (0.001 * (double)tt) / (double)NP);
+                            r = ldexp(r, -(int)shL[wn]);
+                            r = r - 0.0;
+                            lbk = sortable_bits(r);
+                        }
+                        can = qless(lbk, wn, thK, thN);
+                    }
+                    int possible = __popcll(__ballot(can));
+#pragma unroll
+                    for (int j = 0; j < KM; j++) if (j < nown_f && qless(qK[j], qown[j], thK, thN)) possible++;
+                    return possible < k;
+                }()) {
+                    hopeless = true;
                 } else {
                     // ---- entries with their bit set in front of the k-th clean one: exact scores from the matrix
                     n_exact++;
@@ -1003,7 +1081,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                         if (!qless(bB[j], bN[j], thK, thN)) below = false;
                     }
                 }
-                if ((n_out == k && below) || thN == INT_MAX) break;
+                if (((n_out == k && below) || thN == INT_MAX) && !hopeless) break;
                 // the window does not reach far enough.  Run dry (few entries): rebuild it around the current keys and
                 // look again; full, or rebuilt already: its entries are held back by their matrix entries -- every node then
                 if (attempt == 0 && wcnt < 56) rebuild();
@@ -1114,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 #ifdef BLANCE_PHASE_PROF
     if (lane == 0) {
         printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild);
-        for (int i_ = 0; i_ < 12; i_++) printf("[queue phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
+        for (int i_ = 0; i_ < 17; i_++) printf("[queue phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
         printf("[queue rebuilds] %.0f kcycles, %lld column scans of lane 0 (first scans: %.0f kcycles)\n", (double)rb_cycles / 1e3, rb_scans, (double)rb_scan_cycles / 1e3);
     }
 #endif

@@ -1,5 +1,6 @@
-// queue_walk_k2: the lean walk of k_pass_queue (k_pass_queue.h) for k = 1 or 2, NumPartitions > 0, the row of nodeToNodeCounts
-// not folded -- the passes of BASELINE config 5 -- as hand-written gfx950 assembly.  Part of tu_queue.hip.
+// queue_walk_k2: the lean walk of k_pass_queue (k_pass_queue.h) for k = 1 or 2, NumPartitions > 0 -- the passes of BASELINE
+// config 5, and with the row of nodeToNodeCounts folded into the keys the runs of partitions that lost their primary in a
+// rebalance -- as hand-written gfx950 assembly.  Part of tu_queue.hip.
 //
 // Why: a lone wave issues one instruction per ~4.5 cycles whatever its kind (tools/dev_lat_micro.hip), so a moving step is
 // an instruction-count problem, and the compiler's rendering of the C++ walk (the twin of this text, `lean walk` in
@@ -24,7 +25,8 @@
 //   v206:207 lastK, v205 lastN, v208 / v209 sorted own nodes (-1: none), v210:211 / v212:213 their exact keys, v214 higher
 //   priority node, v215 weight, v216 lower priority nodes (two 16-bit fields, 0xffff: none), v217 lane id (in)
 //   s40 cur, s41 window count, s42:43 / s44 THETA, s46:47 stale lanes, s48:49 lanes that moved (in / out)
-//   s50:51 lanes that never stay, s52:53 lanes for the general code, s54:55 active lanes, s56..59 LDS layout (packed), s60 code,
+//   s50:51 lanes that never stay, s52:53 lanes for the general code, s54:55 active lanes, s56..59 LDS layout (packed; s59 bit 25:
+//   the row is folded), s45 where the folded row and the table of c / NumPartitions lie (packed), s60 code,
 //   s38:39 1 / NumPartitions (the nodeToNodeCounts term of an entry of 1, plan.go:638-644)
 // Temporaries: v218..v239, s61..s101, vcc, m0.
 #pragma once
@@ -178,6 +180,8 @@ namespace blance {
     "v_and_b32_e32 v219, 1, v219\n\t"                                            \
     "v_cmp_eq_u32_e64 s[76:77], 1, v219\n\t"                                     \
     "s_and_b64 s[76:77], s[76:77], s[74:75]\n\t"                                 \
+    "s_bitcmp1_b32 s59, 25\n\t"                 /* folded row (bit 25): every window key is exact, no entry to look up */ \
+    "s_cselect_b64 s[76:77], 0, s[76:77]\n\t"                                    \
     "s_andn2_b64 s[78:79], s[74:75], s[76:77]\n\t"                               \
     "s_add_u32 s90, s78, -1\n\t"                                                 \
     "s_addc_u32 s91, s79, -1\n\t"                                                \
@@ -332,6 +336,11 @@ namespace blance {
     "v_cvt_f64_i32_e32 v[234:235], v225\n\t"                                     \
     "v_sub_u32_e32 v231, 0, v227\n\t"                                            \
     "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+    /* folded row: the node's entry of row "" (u16 in LDS; one more for a chosen node, plan.go:238-245) is part of its key: \
+       + lpT[entry] before + ffT[tot] -- the order of nodeSorter.Score.  Beyond the table: the caller divides */           \
+    "s_bitcmp1_b32 s59, 25\n\t"                                                  \
+    "s_cbranch_scc1 61f\n"                     /* (out of line, behind the loop: the plain case falls through) */ \
+    "60:\n\t"                                                                    \
     "v_add_f64 v[234:235], v[234:235], v[232:233]\n\t"                           \
     "v_ldexp_f64 v[234:235], v[234:235], v231\n\t"                               \
     "v_cmp_eq_f64_e32 vcc, 0, v[234:235]\n\t"                                    \
@@ -357,6 +366,26 @@ namespace blance {
     "70:\n\t"                                                                    \
     "s_add_u32 s40, s73, 1\n\t"                                                  \
     "s_branch 10b\n"                                                             \
+    "61:\n\t"                                                                    \
+    "s_and_b32 s89, s45, 0xffff\n\t"                                             \
+    "s_lshl_b32 s89, s89, 2\n\t"                                                 \
+    "v_lshl_add_u32 v218, v220, 1, s89\n\t"                                      \
+    "ds_read_u16 v219, v218\n\t"                                                 \
+    "v_cmp_lt_u32_e32 vcc, 1, v217\n\t"                                          \
+    "v_cndmask_b32_e64 v229, 0, 1, vcc\n\t"                                      \
+    "s_lshr_b32 s89, s45, 16\n\t"                                                \
+    "s_lshl_b32 s89, s89, 2\n\t"                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+    "v_add_u32_e32 v219, v219, v229\n\t"                                         \
+    "v_cmp_le_u32_e32 vcc, 0x200, v219\n\t"                                      \
+    "s_cmp_lg_u64 vcc, 0\n\t"                                                    \
+    "s_cbranch_scc1 82f\n\t"                                                     \
+    "v_lshl_add_u32 v229, v219, 3, s89\n\t"                                      \
+    "ds_read_b64 v[236:237], v229\n\t"                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+    "v_add_f64 v[234:235], v[234:235], v[236:237]\n\t"                           \
+    "ds_write_b16 v218, v219\n"                                                  \
+    "s_branch 60b\n"                                                             \
     "79:\n\t"                                                                    \
     "s_mov_b32 s40, s68\n"                                                       \
     "80:\n\t"                                                                    \
@@ -382,7 +411,7 @@ struct QueueWalkState {
 __device__ __forceinline__ void queue_walk_k2(QueueWalkState& st, unsigned long long lastK, int lastN, int own_a, int own_b,
                                               unsigned long long ka, unsigned long long kb, int h0, int w, int ov, int lane,
                                               unsigned long long always, unsigned long long slow, unsigned long long act,
-                                              int cfa, int cfb, int cfc, int cfd, unsigned long long lp1_bits) {
+                                              int cfa, int cfb, int cfc, int cfd, int cfe, unsigned long long lp1_bits) {
     asm volatile(BLANCE_QW_TEXT
                  : "+{v[200:201]}"(st.wk), "+{v202}"(st.wn), "+{v203}"(st.o1), "+{v204}"(st.o2),
                    "+{s40}"(st.cur), "+{s41}"(st.wcnt), "+{s[42:43]}"(st.thK), "+{s44}"(st.thN),
@@ -390,7 +419,7 @@ __device__ __forceinline__ void queue_walk_k2(QueueWalkState& st, unsigned long 
                  : "{v[206:207]}"(lastK), "{v205}"(lastN), "{v208}"(own_a), "{v209}"(own_b), "{v[210:211]}"(ka), "{v[212:213]}"(kb),
                    "{v214}"(h0), "{v215}"(w), "{v216}"(ov), "{v217}"(lane),
                    "{s[50:51]}"(always), "{s[52:53]}"(slow), "{s[54:55]}"(act),
-                   "{s56}"(cfa), "{s57}"(cfb), "{s58}"(cfc), "{s59}"(cfd), "{s[38:39]}"(lp1_bits)
+                   "{s56}"(cfa), "{s57}"(cfb), "{s58}"(cfc), "{s59}"(cfd), "{s45}"(cfe), "{s[38:39]}"(lp1_bits)
                  : "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",
                    "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
                    "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",

@@ -224,6 +224,33 @@ def test_tree_pass_dense_mode(golden_cases):
     pl.close()
 
 
+@pytest.mark.parametrize("queue", ["on", "lean-cpp", "general"])
+def test_rowless_runs_folded_row(queue):
+    """Half of the nodes removed: hundreds of consecutive steps have no top priority node and share row "" of
+    nodeToNodeCounts; whole batches of them run with that row folded into the window keys -- through the assembly walk
+    (k_queue_walk.h, bit 25), through its C++ twin, and with the lean walk off (the launch then stops and k_pass_tree takes
+    the stretch).  Promotions inside such runs are taken by the lean walk itself."""
+    from test_tree_emulated import _rebalance as rebalance_case
+    pl = hip.Planner(device_id=0, queue=queue)
+    rebalance_case(pl, 400, 40, remove_frac=0.5, add_frac=0.3)
+    rebalance_case(pl, 260, 130, remove_frac=0.6, add_frac=0.1)
+    rebalance_case(pl, 700, 90, remove_frac=0.4, add_frac=0.4)
+    rebalance_case(pl, 5000, 600, remove_frac=0.3, add_frac=0.0)
+    pl.close()
+
+
+@pytest.mark.parametrize("P,N", [(16384, 512), (65536, 1024)])
+def test_config3_rebalance_reduced(planner, P, N):
+    """bench.py's general-regime workload (a) at reduced size: config 3's plan, every tenth node leaves.  The partitions that
+    lost their primary come first in the pass (plan.go:542-561) and have no top priority node: a run of folded batches with
+    promotions (the new primary is sometimes a node that holds a replica, plan.go:294-297)."""
+    fp = synth.config_flat(3, P, N)
+    res = planner.plan(fp)
+    _same(res, _oracle(fp), ("config3", P, N))
+    fp2 = synth.config3_rebalance_flat(fp, res)
+    _same(planner.plan(fp2), _oracle(fp2), ("config3 rebalance", P, N))
+
+
 @pytest.mark.parametrize("P,N", [(30000, 1000), (20000, 4096), (50000, 300)])
 def test_tree_pass_flat_weighted(planner, P, N):
     """Larger weighted flat instances (config 5's generator at reduced size): initial plan and rebalance."""

@@ -101,6 +101,23 @@ def test_rowless_runs_queue(emu_lib):
     pl.close()
 
 
+def test_config3_rebalance_reduced_queue(emu_lib):
+    """bench.py's general-regime workload (a) at 16,384 x 512: config 3's plan, every tenth node leaves -- the partitions that lost
+    their primary come first in the pass and share row "": folded batches, with promotions taken by the lean walk itself
+    (the new primary is sometimes a node that holds a replica of the partition, plan.go:294-297); no launch stops."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from blance_amd import hip, synth; from oracle import loader; "
+            "pl = hip.Planner(lib_path=%r); fp = synth.config_flat(3, 16384, 512); r = pl.plan(fp); assert r.digest() == loader.plan(fp).digest(); "
+            "fp2 = synth.config3_rebalance_flat(fp, r); r2 = pl.plan(fp2); w = loader.plan(fp2); "
+            "assert (r2.digest(), r2.iterations) == (w.digest(), w.iterations); pl.close()" % (os.path.dirname(HERE), HERE, build_emu()))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BLANCE_QUEUE_STATS="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import re
+    lines = [ln for ln in out.stderr.splitlines() if "k_pass_queue:" in ln]
+    assert lines, out.stderr
+    m = re.search(r"(\d+) launches, (\d+) stops, (\d+) moving steps", lines[-1])
+    assert m and int(m.group(2)) == 0 and int(m.group(3)) > 1000, lines[-1]
+
+
 def test_statistics_say_which_paths_ran():
     """BLANCE_QUEUE_STATS: the weighted rebalance on 300 nodes takes the lean walk for most moving steps, rebuilds its
     window, and the kernel is launched (no silent fall back to k_pass_tree)."""
