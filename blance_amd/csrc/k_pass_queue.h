@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
             if (lane == 0) printf("[q3] outer cur %d B %d wcnt %d\n", cur, B, wcnt);
 #endif
             int f = B;
-            bool retried = false, back_to_asm = false;
+            bool retried = false, back_to_asm = false, skip_lean = false;
 #ifdef BLANCE_QDEBUG4
             int lean_why = 0;
 #define BLANCE_QWHY(x) lean_why = (x)
@@ -608,9 +608,16 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                 n_moved += nm;
                 n_bulk += (c1_ - cur) - nm;
                 cur = c1_;
-                if (uni(st.code) == 0 || cur >= B) break;
+                const int code = uni(st.code);
+                if (code == 0 || cur >= B) break;
+                // code 1: the step at cur needs the general code (its lane's data is out of date, or no window entry can be
+                // taken as it stands) -- the C++ twin below would find the same and leave; code 2: the twin may still take it
+                // (promotion, a counter beyond the tables, a window to rebuild).  The folded row has no general code.
+                skip_lean = code == 1 && !fold;
             }
 #endif
+            if (skip_lean) f = cur;
+            else
             // ================= the lean walk: steps in order as long as they stay or move the plain way =================
             // (a step whose two best candidates are the first eligible entries of the window, none of them with a
             // nodeToNodeCounts entry, all nodes' weights powers of two: one pass of straight-line code per step)
@@ -917,23 +924,49 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                         for (int j = 0; j < KM; j++) if (qown[j] >= 0 && (qown[j] & 63) == lane) cand &= ~(1ull << (qown[j] >> 6));
 #pragma unroll
                         for (int j = 0; j < KH; j++) if (qh[j] >= 0 && (qh[j] & 63) == lane) cand &= ~(1ull << (qh[j] >> 6));
-                        for (int i0 = 0; i0 < G; i0 += 8) {            // (8 independent LDS reads at a time)
-                            unsigned wv[8];
+                        // One pass over the lane's nodes, no branch: the row's bits and the keys come in eights; a node that is no
+                        // candidate or has its bit set takes part with the key ~0; the lane's two smallest are kept by strict
+                        // less-than -- a lane's nodes ascend, so of equal keys the smaller node stays in front, the order of
+                        // plan.go:617-628.  (With a branch per node some lane of the 64 improves its pair in nearly every
+                        // round and the whole wave walks the update: measured 180 cycles per node of the lane, 11.5 K per step.)
+                        unsigned cand_w[2] = {(unsigned)cand, (unsigned)(cand >> 32)}, dirty_w[2] = {0u, 0u};
+                        u64 b0 = ~0ull, b1 = ~0ull;
+                        int n0 = INT_MAX, n1 = INT_MAX;
 #pragma unroll
-                            for (int u = 0; u < 8; u++) wv[u] = i0 + u < G ? bitsL[f * BW + 2 * (i0 + u) + (lane >> 5)] : 0u;
+                        for (int h = 0; h < 2; h++) {
+                            for (int j0 = 0; j0 < 32; j0 += 8) {
+                                const int i0 = h * 32 + j0;
+                                if (i0 >= G) break;
+                                unsigned wv[8];
+                                u64 kv[8];
 #pragma unroll
-                            for (int u = 0; u < 8; u++) dirtycol |= (u64)((wv[u] >> (lane & 31)) & 1) << (i0 + u);
+                                for (int u = 0; u < 8; u++) wv[u] = i0 + u < G ? bitsL[f * BW + 2 * (i0 + u) + (lane >> 5)] : 0u;
+#pragma unroll
+                                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+                                    const unsigned d = (wv[u] >> (lane & 31)) & 1u;
+                                    dirty_w[h] |= d << (j0 + u);
+                                    const bool ok = (((cand_w[h] >> (j0 + u)) & 1u) & (d ^ 1u)) != 0;
+                                    const u64 key = ok ? kv[u] : ~0ull;
+                                    const int n = (i0 + u) * 64 + lane;
+                                    const bool lt0 = key < b0;
+                                    if (k > 1) {                       // (wave uniform; k = 1 keeps one)
+                                        const bool lt1 = key < b1;
+                                        b1 = lt0 ? b0 : (lt1 ? key : b1);
+                                        n1 = lt0 ? n0 : (lt1 ? n : n1);
+                                    }
+                                    b0 = lt0 ? key : b0;
+                                    n0 = lt0 ? n : n0;
+                                }
+                            }
                         }
+                        dirtycol = ((u64)dirty_w[1] << 32) | dirty_w[0];
+                        lb[0] = b0; ln[0] = n0;
+                        static_assert(KM == 2, "the lane keeps a pair");
+                        lb[1] = b1; ln[1] = n1;
                         PHM(dense_bits_done);
                         PH(13);
-                        for (int i0 = 0; i0 < G; i0 += 8) {
-                            u64 kv[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
-#pragma unroll
-                            for (int u = 0; u < 8; u++)
-                                if (((cand & ~dirtycol) >> (i0 + u)) & 1) keep_local(kv[u], (i0 + u) * 64 + lane);
-                        }
                         PHM(dense_keys_done);
                         PH(14);
                         u64 cK = ~0ull;                              // the k-th best clean key over the wave (~0: fewer than k)

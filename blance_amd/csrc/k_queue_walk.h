@@ -18,7 +18,7 @@
 //   (a, b, t1, t2); below THETA (else leave); no promotion (else leave); commit: lanes 0..3 settle the leaving / entering
 //   nodes (new counters, new key: cvt, + ffT[tot], ldexp by the node's power-of-two weight, sortable image), the window
 //   removes and re-inserts them (DPP wave shifts), lanes that hold a changed node are marked stale, f's choice goes to its
-//   output registers.  Leaves with code 0 (the batch is done, cur = B) or 1 (cur = the lane to be handled by the caller).
+//   output registers.  Leaves with code 0 (the batch is done, cur = B), 1 (lane cur needs the general code) or 2 (lane cur may still be the C++ twin's).
 //
 // Registers are fixed by the operand constraints (an operand's halves have to be named):
 //   v200:201 window key, v202 window node, v203 / v204 output nodes of the lanes that moved (in / out)
@@ -150,7 +150,7 @@ namespace blance {
     "s_ff1_i32_b64 s73, s[74:75]\n\t"                                            \
     "s_or_b64 s[76:77], s[52:53], s[46:47]\n\t"                                  \
     "s_bitcmp1_b64 s[76:77], s73\n\t"                                            \
-    "s_cbranch_scc1 81f\n\t"                                                     \
+    "s_cbranch_scc1 84f\n\t"                                                     \
     /* the step's own data */                                                    \
     "v_readlane_b32 s80, v215, s73\n\t"                                          \
     "v_readlane_b32 s81, v208, s73\n\t"                                          \
@@ -189,7 +189,7 @@ namespace blance {
     "s_cmp_eq_u32 s69, 0\n\t"                   /* k = 1: the first clean entry bounds the search */ \
     "s_cselect_b64 s[90:91], s[78:79], s[90:91]\n\t"                             \
     "s_cmp_eq_u64 s[90:91], 0\n\t"                                               \
-    "s_cbranch_scc1 81f\n\t"                                                     \
+    "s_cbranch_scc1 83f\n\t"                                                     \
     "s_ff1_i32_b64 s92, s[78:79]\n\t"                                            \
     "s_ff1_i32_b64 s93, s[90:91]\n\t"                                            \
     "s_lshl_b64 s[90:91], 2, s93\n\t"                                            \
@@ -232,7 +232,7 @@ namespace blance {
     "v_cmp_ge_u64_e32 vcc, s[76:77], v[234:235]\n\t"                             \
     "s_mov_b64 exec, s[94:95]\n\t"                                               \
     "s_cmp_lg_u64 vcc, 0\n\t"                                                    \
-    "s_cbranch_scc1 81f\n"                                                        \
+    "s_cbranch_scc1 84f\n"                                                        \
     "15:\n\t"                                                                    \
     "v_readlane_b32 s74, v200, s92\n\t"                                          \
     "v_readlane_b32 s75, v201, s92\n\t"                                          \
@@ -393,7 +393,14 @@ namespace blance {
     "s_branch 89f\n"                                                             \
     "82:\n\t"                                                                    \
     "s_mov_b64 exec, s[94:95]\n"                                                 \
-    "81:\n\t"                                                                    \
+    "81:\n\t"                                 /* the C++ twin may take this step */  \
+    "s_mov_b32 s40, s73\n\t"                                                     \
+    "s_mov_b32 s60, 2\n\t"                                                       \
+    "s_branch 89f\n"                                                             \
+    "83:\n\t"                                 /* no clean entry: a window run dry is the twin's to rebuild */ \
+    "s_cmp_lt_u32 s41, 32\n\t"                                                   \
+    "s_cbranch_scc1 81b\n"                                                       \
+    "84:\n\t"                                 /* the general code */               \
     "s_mov_b32 s40, s73\n\t"                                                     \
     "s_mov_b32 s60, 1\n"                                                         \
     "89:\n"
