@@ -196,10 +196,68 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 #ifdef BLANCE_PHASE_PROF
     long long rb_cycles = 0, rb_scans = 0, rb_scan_cycles = 0;
 #endif
+    int stripe_skip = 0;                             // rebuilds for which the striped form is not tried (it just came out short)
+    long long n_striped = 0;
     auto rebuild = [&]() {
 #ifdef BLANCE_PHASE_PROF
         const long long rb_t0 = clock64();
 #endif
+        // The striped form first.  Lane l owns nodes l, 64 + l, ...; with m_l / s_l its smallest / second smallest (key, node):
+        // THETA = the smallest s_l, window = the m_l below THETA.  Every node outside it is a lane minimum >= THETA or lies
+        // behind its lane's second: >= s_l >= THETA -- the invariant, exactly.  One pass over the keys, a bitonic sort of the
+        // 64 minima, one wave minimum: a sixth of the exact selection below.  It comes out full when the smallest keys sit
+        // in different lanes -- many nodes of one load, consecutive ids: the regime that drains a window step after step --
+        // and short otherwise (two of the smallest in one lane cut it there); then the exact selection runs.
+        if (stripe_skip > 0) stripe_skip--;
+        else {
+            u64 b0 = ~0ull, b1 = ~0ull;
+            int n0 = INT_MAX, n1 = INT_MAX;
+            for (int i0 = 0; i0 < G; i0 += 8) {      // (8 independent LDS reads at a time; no branch: see the dense step)
+                u64 kv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const u64 key = kv[u];
+                    const int n = (i0 + u) * 64 + lane;
+                    const bool lt0 = key < b0, lt1 = key < b1;       // (strict: of equal keys the lower node stays in front)
+                    b1 = lt0 ? b0 : (lt1 ? key : b1);
+                    n1 = lt0 ? n0 : (lt1 ? n : n1);
+                    b0 = lt0 ? key : b0;
+                    n0 = lt0 ? n : n0;
+                }
+            }
+            u64 sk = b0;
+            int sn = n0;
+            for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    const u64 pk = ((u64)(unsigned)__shfl_xor((int)(unsigned)(sk >> 32), j, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)sk, j, 64);
+                    const int pn = __shfl_xor(sn, j, 64);
+                    const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
+                    const bool take = keep_min ? qless(pk, pn, sk, sn) : qless(sk, sn, pk, pn);
+                    sk = take ? pk : sk;
+                    sn = take ? pn : sn;
+                }
+            }
+            const QMin t = wave_min_key_node(b1, n1);
+            const u64 tk = t.node == INT_MAX ? ~0ull : (((u64)t.hi << 32) | t.lo);
+            const bool in = sn != INT_MAX && qless(sk, sn, tk, t.node);
+            const int cw = __popcll(__ballot(in));
+            if (cw >= 48 || t.node == INT_MAX) {
+                wk = in ? sk : ~0ull;
+                wn = in ? sn : INT_MAX;
+                wcnt = uni(cw);
+                thK = uni64(tk);
+                thN = uni(t.node);
+                n_rebuild++;
+                n_striped++;
+#ifdef BLANCE_PHASE_PROF
+                rb_cycles += clock64() - rb_t0;
+#endif
+                return;
+            }
+            stripe_skip = 16;
+        }
         // 64 + 1 successive minima of the keys in LDS; lane l owns nodes l, 64 + l, ... (bit i of `taken`: node 64 i + l)
         // and keeps its four smallest untaken keys, so that a column is scanned again only when all four are gone
         // (64 minima over 64 columns: a column with five of them is rare)
@@ -1002,13 +1060,25 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                             keep_local(b, n);
                         }
                     } else {
-                    for (int i = 0; i < G; i++) {
-                        const int n = i * 64 + lane;
-                        if (is_cand(n)) {
-                            const int nt = NP > 0 ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
-                            const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
-                                                                         q.booster_kind, lpT, ffT)) : gB[n];
-                            keep_local(b, n);
+                    // (no bit map for this step -- its row was bumped inside the batch: the row itself, eight entries of the
+                    // lane in flight at a time; one entry per round trip made such a step 64 round trips, ~140 us)
+                    for (int i0 = 0; i0 < G; i0 += 8) {
+                        int ntv[8];
+                        bool cv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int n = (i0 + u) * 64 + lane;
+                            cv[u] = i0 + u < G && is_cand(n);
+                            ntv[u] = (NP > 0 && cv[u]) ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int n = (i0 + u) * 64 + lane;
+                            if (cv[u]) {
+                                const u64 b = ntv[u] ? sortable_bits(queue_score(cntL[n], ntv[u], totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                                                 q.booster_kind, lpT, ffT)) : gB[n];
+                                keep_local(b, n);
+                            }
                         }
                     }
                     }
@@ -1224,7 +1294,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     }
 #ifdef BLANCE_PHASE_PROF
     if (lane == 0) {
-        printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild);
+        printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld (striped %lld)\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild, n_striped);
         for (int i_ = 0; i_ < 17; i_++) printf("[queue phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
         printf("[queue rebuilds] %.0f kcycles, %lld column scans of lane 0 (first scans: %.0f kcycles)\n", (double)rb_cycles / 1e3, rb_scans, (double)rb_scan_cycles / 1e3);
     }
