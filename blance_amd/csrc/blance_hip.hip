@@ -1321,7 +1321,8 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                 BLANCE_LAUNCH_NOSYNC(k_period_init, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
                 const int gf = cdiv(std::min(max_len, kPeriodCap + 1), 256);
                 BLANCE_LAUNCH_NOSYNC(k_period_find, gf * B, 256, 0, sm, B, gf, cq.reg_off, cq.crec, pb);
-                BLANCE_LAUNCH_NOSYNC(k_period_verify, gx * B, 256, 0, sm, B, gx, cq.reg_off, cq.crec, pb);
+                const int gv = cdiv((long long)max_len * (kCW / 4), 256);
+                BLANCE_LAUNCH_NOSYNC(k_period_verify, gv * B, 256, 0, sm, B, gv, cq.reg_off, cq.crec, pb);
                 if (c->periodic_cut > 0) BLANCE_LAUNCH_NOSYNC(k_period_clamp, cdiv(B, 64), 64, 0, sm, B, c->periodic_cut, pb);
                 BLANCE_LAUNCH_NOSYNC(k_period_segments, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
                 ChainParams sq = cq;

@@ -45,14 +45,23 @@ __global__ void k_period_find(int B, int gx, const int32_t* reg_off, const int32
     if (period_same_input(crec + (size_t)cbeg * kCW, crec + (size_t)(cbeg + t) * kCW)) atomicMin(pb + kPT * B + rg, t);
 }
 
-// limit[rg] = first step t >= T whose record differs from step t - T's (the chain's length if none)
+// limit[rg] = first step t >= T whose record differs from step t - T's (the chain's length if none).  One thread per 16 bytes
+// of the region's records (a record is kCW / 4 = 6 of them; word 0 of a record, the step's pass index, does not count): the
+// loads of a wave are one contiguous 1 KB, and the piece T records back is in the L2 (12 KB behind at T = 128) -- the 100 MB
+// of config 3's records cross the HBM interface once.  (One thread per RECORD, each reading its 96 bytes, ran at 0.5 TB/s.)
 __global__ void k_period_verify(int B, int gx, const int32_t* reg_off, const int32_t* crec, int32_t* pb) {
+    static_assert(kCW % 4 == 0, "records are whole 16-byte pieces");
+    constexpr int per = kCW / 4;
     const int rg = blockIdx.x / gx;
     const int cbeg = reg_off[rg], len = reg_off[rg + 1] - cbeg;
     const int T = pb[kPT * B + rg];
-    const int t = (blockIdx.x % gx) * blockDim.x + threadIdx.x;
+    const long long qi = (long long)(blockIdx.x % gx) * blockDim.x + threadIdx.x;
+    const long long t = qi / per;
     if (T < 1 || T > kPeriodCap || t < T || t >= len) return;
-    if (!period_same_input(crec + (size_t)(cbeg + t) * kCW, crec + (size_t)(cbeg + t - T) * kCW)) atomicMin(pb + kPLimit * B + rg, t);
+    const int4* r4 = (const int4*)(crec + (size_t)cbeg * kCW);
+    const int4 a = r4[qi], b = r4[qi - (long long)per * T];
+    const bool same = a.y == b.y && a.z == b.z && a.w == b.w && (qi % per == 0 || a.x == b.x);
+    if (!same) atomicMin(pb + kPLimit * B + rg, (int)t);
 }
 
 // test knob (BLANCE_PERIODIC_CUT=n): the periodic stretch ends after n steps at the latest -- any prefix of a periodic
