@@ -25,3 +25,4 @@ for cfg in 3 2 5; do
   bash tools/gpu_profile.sh config$cfg --config $cfg > "$out/profile_config$cfg.log" 2>&1
   tail -3 "$out/profile_config$cfg.log"
 done
+timeout 1500 python -m pytest tests -q -m gpu > "$out/test_gpu_full.log" 2>&1; tail -3 "$out/test_gpu_full.log"
