@@ -1480,6 +1480,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                              d.in_prev, d.never_equal);
     }
     int iterations = 0, converged = 0;
+    int32_t hs[26] = {0};                                            // the scalar words read back after every sweep
     for (int it = 0; it < h.max_iterations; it++) {                 // plan.go:32
         const bool first = it == 0;
         d.node_removed = first ? c->node_removed.as<uint8_t>() : c->zeros_nx.as<uint8_t>();   // plan.go:53-55
@@ -1633,7 +1634,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             BLANCE_LAUNCH(k_converge, cdiv(P, 256), 256, 0, sm, d, scal + 1);          // (uses a wave ballot)
             launches++;
         }
-        int32_t hs[4] = {0, 0, 0, 0};
+        // one readback per sweep: the convergence word with the warnings count, and -- complete with the last sweep --
+        // the statistics words behind them (steps k_pass_seq committed as verified stays, the queue kernel's counters)
         HIPTRY(hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipStreamSynchronize(sm));
         HIPTRY(hipGetLastError());
@@ -1642,13 +1644,11 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         if (!hs[1]) { converged = 1; break; }
     }
     HIPTRY(hipEventRecord(c->ev1, sm));
-    {                                              // steps k_pass_seq committed as verified stays
-        long long spec = 0;
-        HIPTRY(hipMemcpyAsync(&spec, scal + 12, sizeof spec, hipMemcpyDeviceToHost, sm));
+    {
+        long long spec = 0, qs[4] = {0, 0, 0, 0};
+        memcpy(&spec, hs + 12, sizeof spec);
+        memcpy(qs, hs + 18, sizeof qs);
         HIPTRY(hipEventSynchronize(c->ev1));
-        HIPTRY(hipStreamSynchronize(sm));
-        long long qs[4] = {0, 0, 0, 0};
-        HIPTRY(hipMemcpy(qs, scal + 18, sizeof qs, hipMemcpyDeviceToHost));
         c->queue_moved = qs[0]; c->queue_exact = qs[1]; c->queue_rebuilds = qs[2]; c->queue_dense = qs[3];
         if (c->trace || getenv("BLANCE_QUEUE_STATS"))
             fprintf(stderr, "[blance] k_pass_queue: %lld launches, %lld stops, %lld moving steps (%lld with matrix reads, %lld scoring every node), %lld window rebuilds\n",

@@ -17,9 +17,12 @@ namespace blance {
 //    whose g changed is removed (lanes above it move down one: one DPP wave shift per register) and, if
 //    its new key is below THETA, inserted at its place (lanes at and above move up one); a 65th entry is
 //    dropped and becomes THETA.  The smallest candidate is lane 0, no reduction over the wave -- k_pass_tree
-//    paid three to four wave minima (two DPP chains each) and a group rescan per moving step.  On BASELINE
-//    config 5 the window never runs dry (simulated on the oracle's trajectory: 0 rebuilds per pass after
-//    the first sweep; a taken node rises above THETA, a released node comes in below it).
+//    paid three to four wave minima (two DPP chains each) and a group rescan per moving step.  A window that has
+//    run dry, or whose entries cannot settle a step, is REBUILT from the keys in LDS: first in its striped form
+//    (every lane's smallest key, cut at the smallest of the lanes' second-smallest keys, sorted by a bitonic
+//    network: exact whenever it applies, a sixth of the cost), else by selecting the 65 smallest one by one.
+//    Measured on BASELINE config 5: one rebuild per ~500 moving steps; with many nodes of one load (a
+//    rebalance after nodes left, Zipf weights) one per 64 to 120.
 //  * ROW BIT MAPS: "is nodeToNodeCounts[row][n] zero" for the 64 rows of a batch sits in LDS (ntn_bits:
 //    one bit per matrix entry, maintained next to the matrix), so a candidate whose bit is clear has its
 //    exact score = its window key without touching the matrix -- k_pass_tree waited ~1 us for an entry
@@ -30,9 +33,16 @@ namespace blance {
 //    eligible window entries), valid if all of them lie below THETA -- otherwise the window is rebuilt
 //    (from the g keys kept in LDS) and the step repeated.
 //
+//  * FOLDED ROW: a batch whose steps all belong to partitions without a top priority node (they lost their
+//    primary: plan.go:134-138 gives them row "") keeps that row in LDS as part of the keys; no step of it reads
+//    the matrix.  PROMOTIONS (the taken node holds the partition in a lower priority state, plan.go:294-297) are
+//    settled where they occur: that state's counter of the node drops, its total does not grow.
+//  * The step loop for the plain case is hand-written assembly (k_queue_walk.h); its C++ twin below is what the
+//    SIMT emulator runs and what takes the steps the assembly leaves.
+//
 // What the kernel does not do it does not guess: a step that needs the general machinery of k_pass_tree
-// (a node held in two lists, promotions / demotions, more higher-priority nodes than it keeps, fewer
-// candidates than constraints) STOPS the
+// (a node held in two lists, more higher-priority nodes than it keeps, fewer candidates than constraints,
+// a general step inside a folded batch) STOPS the
 // launch there -- everything before it is committed, q.stop[0] says where -- and the host lets
 // k_pass_tree do a few steps before it relaunches this kernel.
 // ============================================================================

@@ -1,5 +1,6 @@
 // k_period: an all-blank chain pass (k_pass_chain_planes) whose step records repeat with a period T.
-// Part of blance_hip.hip (one translation unit); DESIGN.md section 4.1c.  OPT-IN (options.reserved[2] & 256).
+// Part of blance_hip.hip (one translation unit); DESIGN.md section 4.1c.  On by default (options.reserved[2] & 256 or
+// BLANCE_PERIODIC=0 turn it off).
 #pragma once
 
 namespace blance {
