@@ -1341,7 +1341,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                                          cq.alive, c->cnt_p1.as<int32_t>(), cq.cnt, pb);
                     BLANCE_LAUNCH_NOSYNC(k_period_state_check, gl * B, 64, 0, sm, B, gl, m, N, NX, cq.reg_lo, cq.reg_hi, cq.leaf_node,
                                          cq.alive, c->cnt_p1.as<int32_t>(), cq.cnt, pb);
-                    BLANCE_LAUNCH_NOSYNC(k_period_verdict, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, pb);
+                    BLANCE_LAUNCH_NOSYNC(k_period_verdict, cdiv(B, 64), 64, 0, sm, B, cq.reg_off, cq.flags, pb);
                     BLANCE_LAUNCH_NOSYNC(k_period_replicate, gx * B, 256, 0, sm, B, gx, OW, cq.reg_off, pb, cq.out);
                     BLANCE_LAUNCH(k_period_counts, B, 256, 0, sm, B, m, N, NX, OW, cq.reg_off, cq.reg_lo, cq.reg_hi, cq.leaf_node,
                                   cq.alive, cq.crec, cq.out, pb, cq.cnt);

@@ -125,14 +125,18 @@ __global__ void k_period_state_check(int B, int gx, int s, int N, int NX, const 
     if (n >= 0 && n < N && alive[n] && cnt2[s * NX + n] - cnt1[s * NX + n] != pb[kPD * B + rg]) atomicMin(pb + kPOk * B + rg, 0);
 }
 
-__global__ void k_period_verdict(int B, const int32_t* reg_off, int32_t* pb) {
+// (flags[1]: a chain of the walks so far had to escape -- it published nothing, the host will redo the whole pass with
+// k_pass_chain from the saved counters: then nothing is copied either.  Without this a walk that escaped in its second
+// period left the counters where the first period had put them, "the same d = 0 on every leaf" passed for a verdict, and
+// the outputs of steps nobody had written were replicated and counted -- node ids out of whatever the buffer held.)
+__global__ void k_period_verdict(int B, const int32_t* reg_off, const int32_t* flags, int32_t* pb) {
     const int rg = blockIdx.x * blockDim.x + threadIdx.x;
     if (rg >= B) return;
     const int cbeg = reg_off[rg], cend = reg_off[rg + 1];
     const int T = pb[kPT * B + rg], limit = pb[kPLimit * B + rg], d = pb[kPD * B + rg];
     const bool joined = T >= 1 && T <= kPeriodCap && (long long)limit >= (long long)kPeriodMinRounds * T;
     if (!joined) return;                            // (segment 1 was the whole chain, segments 2 and 3 are empty)
-    const bool ok = pb[kPOk * B + rg] != 0 && d != INT_MIN && d >= 0;
+    const bool ok = pb[kPOk * B + rg] != 0 && d != INT_MIN && d >= 0 && flags[1] == 0;
     pb[kPOk * B + rg] = ok ? 1 : 0;
     pb[kPBeg3 * B + rg] = ok ? cbeg + limit : cbeg + 2 * T;
     pb[kPEnd3 * B + rg] = cend;
@@ -171,7 +175,10 @@ __global__ void k_period_counts(int B, int s, int N, int NX, int OW, const int32
     for (int j = threadIdx.x; j < rest; j += blockDim.x) {
         const int32_t* o = out + (size_t)(cbeg + T + j) * OW;
         const int n_out = o[0] & 0xffff;
-        for (int c = 0; c < n_out; c++) atomicAdd(cnt + s * NX + o[1 + c], w0);
+        for (int c = 0; c < n_out; c++) {
+            const int n = o[1 + c];
+            if (n >= 0 && n < NX) atomicAdd(cnt + s * NX + n, w0);
+        }
     }
 }
 
