@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/periodic
 mkdir -p "$out"
-timeout 900 python -m pytest tests/test_zz_periodic_gpu.py -q -m gpu -rxX > "$out/test.log" 2>&1; tail -5 "$out/test.log"
+timeout 900 python -m pytest tests/test_periodic_gpu.py -q -m gpu > "$out/test.log" 2>&1; tail -5 "$out/test.log"
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sharded > "$out/bench_default.json" 2> "$out/bench_default.err"
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sharded --periodic > "$out/bench_periodic.json" 2> "$out/bench_periodic.err"
 python - <<'PY'
