@@ -107,6 +107,7 @@ struct blance_ctx {
     bool queue_general = false;     // test knob (& 1024): k_pass_queue without its lean walk
     bool queue_no_asm = false;      // test knob (& 4096): k_pass_queue's lean walk as compiled C++ only
     bool queue_force_dense = false; // test knob (& 2048): every general step of k_pass_queue scores every node
+    bool queue_one_wave = false;    // test knob (& 8192): k_pass_queue without its helper waves
     DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
     bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
     // nodeToNodeCounts (67 MB at config 3) is zeroed lazily: only a pass that reads or bumps the matrix in HBM pays for it
@@ -323,6 +324,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->queue_general = opt && (opt->reserved[2] & 1024);
     c->queue_force_dense = opt && (opt->reserved[2] & 2048);
     c->queue_no_asm = opt && (opt->reserved[2] & 4096);
+    c->queue_one_wave = opt && (opt->reserved[2] & 8192);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->periodic = !(opt && (opt->reserved[2] & 256));
@@ -671,13 +673,13 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
     q.ntn_bits = c->ntn_bits.as<uint32_t>();
     q.stop = scal + 16;
     q.qstats = (long long*)(scal + 18);
-    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0);
+    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0) | (c->queue_one_wave ? 64 : 0);
     int pos = q0.beg, chunk = 64;
     while (pos < q0.end) {
         q.beg = pos; q.end = q0.end;
         if (q.NP > 0 && c->bits_stale) {
             const long long words = (long long)queue_bits_words(q.NX);
-            BLANCE_LAUNCH_NOSYNC(k_ntn_bits, cdiv(words, 256), 256, 0, c->stream, q.N, q.NX + 1, (int)(words / (q.NX + 1)), q.ntn, q.ntn_bits);
+            BLANCE_LAUNCH(k_ntn_bits, cdiv(q.NX + 1, 4), 256, 0, c->stream, q.N, q.NX + 1, (int)(words / (q.NX + 1)), q.ntn, q.ntn_bits);
             c->bits_stale = false;
         }
         if (!launch_pass_queue(c->stream, q)) { q.beg = pos; return dispatch_pass_tree_or_seq(c, q); }

@@ -23,7 +23,10 @@ struct Hdr {
     std::atomic<int64_t> live;                  // objects handed out and not yet deleted (+ kBias while the chunk is being filled)
 };
 
-uintptr_t g_lo = 1, g_hi = 0;                   // the reserved range; empty until reserve() ran
+// The reserved range [g_lo, g_hi); empty (g_hi == 0) until reserve() ran.  operator delete on any thread reads the pair
+// while the first Scope of the process may still be reserving: g_lo is stored first, g_hi is published with release and
+// read with acquire, so a reader sees either an empty range or both bounds.
+std::atomic<uintptr_t> g_lo{1}, g_hi{0};
 uint32_t g_chunks = 0;                          // chunks the range holds
 std::once_flag g_once;
 std::mutex g_mu;                                // the pool
@@ -37,8 +40,8 @@ void reserve() {
         if (p == MAP_FAILED) continue;
         const uintptr_t lo = ((uintptr_t)p + kChunk - 1) & ~(uintptr_t)(kChunk - 1);
         g_chunks = (uint32_t)(want / kChunk);
-        g_hi = lo + want;
-        g_lo = lo;
+        g_lo.store(lo, std::memory_order_relaxed);
+        g_hi.store(lo + want, std::memory_order_release);
         return;
     }
 }
@@ -52,7 +55,7 @@ struct ThreadState {
 thread_local ThreadState t;
 
 void recycle(Hdr* h) {
-    const uint32_t idx = (uint32_t)(((uintptr_t)h - g_lo) / kChunk);
+    const uint32_t idx = (uint32_t)(((uintptr_t)h - g_lo.load(std::memory_order_relaxed)) / kChunk);
     std::lock_guard<std::mutex> g(g_mu);
     g_pool[g_npool++] = idx;
     g_in_use.fetch_sub(1, std::memory_order_relaxed);
@@ -77,7 +80,7 @@ bool next_chunk() {
         else return false;
         g_in_use.fetch_add(1, std::memory_order_relaxed);
     }
-    t.cur = (char*)(g_lo + (uintptr_t)idx * kChunk);
+    t.cur = (char*)(g_lo.load(std::memory_order_relaxed) + (uintptr_t)idx * kChunk);
     ((Hdr*)t.cur)->live.store(kBias, std::memory_order_release);
     t.off = kHdr;
     t.count = 0;
@@ -106,7 +109,8 @@ inline void* take(size_t n) {                   // nullptr: not from the region
 
 inline bool give(void* p) {                     // true: it was the region's
     const uintptr_t a = (uintptr_t)p;
-    if (a < g_lo || a >= g_hi) return false;
+    const uintptr_t hi = g_hi.load(std::memory_order_acquire);       // (0 while nothing is reserved: nothing is the region's)
+    if (a >= hi || a < g_lo.load(std::memory_order_relaxed)) return false;
     Hdr* h = (Hdr*)(a & ~(uintptr_t)(kChunk - 1));
     if (h->live.fetch_sub(1, std::memory_order_acq_rel) == 1) recycle(h);
     return true;
@@ -116,7 +120,7 @@ inline bool give(void* p) {                     // true: it was the region's
 
 bool available() {
     std::call_once(g_once, reserve);
-    return g_hi > g_lo;
+    return g_hi.load(std::memory_order_acquire) > g_lo.load(std::memory_order_relaxed);
 }
 
 Scope::Scope() {
@@ -134,7 +138,7 @@ Stats stats() {
 
 void trim() {
     std::lock_guard<std::mutex> g(g_mu);
-    for (uint32_t i = 0; i < g_npool; i++) madvise((void*)(g_lo + (uintptr_t)g_pool[i] * kChunk), kChunk, MADV_DONTNEED);
+    for (uint32_t i = 0; i < g_npool; i++) madvise((void*)(g_lo.load(std::memory_order_relaxed) + (uintptr_t)g_pool[i] * kChunk), kChunk, MADV_DONTNEED);
 }
 
 void* allocate(size_t n) { return take(n); }

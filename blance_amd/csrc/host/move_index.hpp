@@ -80,18 +80,20 @@ public:
     }
 
 private:
+    // an op outside the enum (a caller with other numbering, a replayed file) is filed as "unknown", as the Go twin does
+    static int op_class(int op) { return (unsigned)op < (unsigned)kMoveOpClasses ? op : (int)kOpUnknown; }
     void insert(int32_t p) {
         const NextMovesId& nm = (*all_)[p];
         if (nm.next >= (int32_t)nm.moves.size()) { where_[p] = -1; return; }     // nothing left for this partition
         const NodeStateOpId& m = nm.moves[nm.next];
-        std::vector<int32_t>& b = buckets_[(size_t)m.node * kMoveOpClasses + m.op];
+        std::vector<int32_t>& b = buckets_[(size_t)m.node * kMoveOpClasses + op_class(m.op)];
         where_[p] = (int32_t)b.size();
         b.push_back(p);
         if (pending_[m.node]++ == 0) { active_pos_[m.node] = (int32_t)active_.size(); active_.push_back(m.node); }
         total_++;
     }
     void remove(int32_t p, int node, int op) {
-        std::vector<int32_t>& b = buckets_[(size_t)node * kMoveOpClasses + op];
+        std::vector<int32_t>& b = buckets_[(size_t)node * kMoveOpClasses + op_class(op)];
         const int32_t at = where_[p];
         if (at < 0 || at >= (int32_t)b.size() || b[at] != p) return;     // not filed: nothing to take out
         const int32_t last = b.back();

@@ -134,13 +134,24 @@ __device__ __forceinline__ QMin wave_min_key_node(unsigned long long key, int no
 #include "k_queue_walk.h"
 namespace blance {
 
+// HELPER WAVES (round 5).  The walk is one wave; what it cannot do alone at a reasonable price is look at EVERY node: the
+// dense step (a row whose entries cover the whole window: ~17 K cycles of one wave for 4,096 nodes) and the window rebuild.
+// The kernel therefore runs as ONE workgroup of kQueueWaves waves -- one per SIMD of the CU, so the walk keeps the register
+// file it has (a fifth wave would halve it).  Waves 1.. park on s_barrier, which costs the walk nothing; wave 0 posts a
+// command in LDS, joins the barrier, every wave scans its share of the nodes out of the LDS tables (keys, row bits,
+// counters -- all of them already there), leaves its k best (key, node) in LDS, second barrier, wave 0 merges.
+constexpr int kQueueWaves = 4;
+constexpr int kQCmdExit = 0, kQCmdDense = 1;
+constexpr int kQCmdWords = 32, kQResWords = 4;      // a command block; one (key hi, key lo, node, -) result per wave and pick
+
 template <int KM>
-__global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
+__global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     static_assert(KM == 2, "k <= 2");
     typedef unsigned long long u64;
     constexpr int KH = 2;                            // higher priority nodes a step may carry
     BLANCE_DYN_LDS(lds);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6)), NW = uni((int)(blockDim.x >> 6));
     const int N = q.N, NX = q.NX, M = q.M, L = q.L, NP = q.NP, s = q.s, k = q.k, RW = q.RW;
     const int SW = 1 + L;
     const int G = (NX + 63) >> 6, NXp = G << 6, BW = ((NXp >> 5) + 3) & ~3;     // words per row bit map (16-byte rows)
@@ -159,6 +170,136 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
     unsigned char* rowTag = flL + NXp;               // [NXp + 64] a lane of the batch with this row (any of them)
     unsigned char* shL = rowTag + NXp + 64;          // [NXp] e when the node's score is divided by 2^e (no weight, weight 0: e = 0)
     unsigned short* ntL = (unsigned short*)(shL + NXp);      // [NXp] folded mode: row "" of nodeToNodeCounts
+    int* hcmd = (int*)(ntL + NXp);                   // [kQCmdWords] wave 0's command to the helper waves
+    int* hres = hcmd + kQCmdWords;                   // [kQueueWaves * KM * kQResWords] their answers
+
+    // ---- the dense step's share of one wave: the k best (key, node) among the candidates 64 i + lane, i in this wave's
+    // columns, for the step the command describes -- clean entries by their keys in LDS, entries with their bit set read
+    // from the matrix unless even an entry of 1 would put them behind `bound` (an upper bound of the step's k-th pick).
+    // Every wave of the workgroup runs this between the two barriers of a dense step; results in hres[wave].
+    auto dense_part = [&]() {
+        const int f = hcmd[1], kk = hcmd[2], o0 = hcmd[3], o1 = hcmd[4], h0 = hcmd[5], h1 = hcmd[6], hb = hcmd[7], rowf = hcmd[8];
+        const u64 U = ((u64)(unsigned)hcmd[10] << 32) | (unsigned)hcmd[11];
+        const int CJ = (G + NW - 1) / NW, ib = wave * CJ, ie = ib + CJ < G ? ib + CJ : G;
+        u64 lb[KM];
+        int ln[KM];
+#pragma unroll
+        for (int j = 0; j < KM; j++) { lb[j] = ~0ull; ln[j] = INT_MAX; }
+        auto keep_local = [&](u64 b, int n) {               // the lane's own k best, ascending
+            if (!qless(b, n, lb[KM - 1], ln[KM - 1])) return;       // (most nodes: not among them)
+#pragma unroll
+            for (int j = KM - 1; j >= 0; j--) {
+                const bool here = qless(b, n, lb[j], ln[j]);
+                const bool above = j > 0 && qless(b, n, lb[j - 1], ln[j - 1]);
+                if (here) {
+                    if (above) { lb[j] = lb[j - 1]; ln[j] = ln[j - 1]; }
+                    else { lb[j] = b; ln[j] = n; }
+                }
+            }
+        };
+        if (NP > 0 && hb) {
+            // One pass over the lane's nodes, no branch: the row's bits and the keys come in eights; a node that is no
+            // candidate (its key is ~0, or it is one of the step's own / higher priority nodes) or has its bit set takes part
+            // with the key ~0; the lane's two smallest are kept by strict less-than -- a lane's nodes ascend, so of equal keys
+            // the smaller node stays in front, the order of plan.go:617-628.
+            u64 b0 = ~0ull, b1 = ~0ull, dmask = 0;
+            int n0 = INT_MAX, n1 = INT_MAX;
+            for (int i0 = ib; i0 < ie; i0 += 8) {
+                unsigned wv[8];
+                u64 kv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) wv[u] = i0 + u < ie ? bitsL[f * BW + 2 * (i0 + u) + (lane >> 5)] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) kv[u] = i0 + u < ie ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int n = (i0 + u) * 64 + lane;
+                    const bool cnd = kv[u] != ~0ull && n != o0 && n != o1 && n != h0 && n != h1;
+                    const bool d = ((wv[u] >> (lane & 31)) & 1u) != 0;
+                    if (cnd && d) dmask |= 1ull << (i0 + u - ib);
+                    const u64 key = (cnd && !d) ? kv[u] : ~0ull;
+                    const bool lt0 = key < b0;
+                    if (kk > 1) {                       // (wave uniform; k = 1 keeps one)
+                        const bool lt1 = key < b1;
+                        b1 = lt0 ? b0 : (lt1 ? key : b1);
+                        n1 = lt0 ? n0 : (lt1 ? n : n1);
+                    }
+                    b0 = lt0 ? key : b0;
+                    n0 = lt0 ? n : n0;
+                }
+            }
+            lb[0] = b0; ln[0] = n0;
+            static_assert(KM == 2, "the lane keeps a pair");
+            lb[1] = b1; ln[1] = n1;
+            // entries with their bit set: behind the bound even with an entry of 1 (plan.go:638-644 is monotone in the entry)?
+            // The bound: the step's k-th pick is no worse than the k-th of its own nodes (U), nor than this lane's k-th clean key.
+            for (u64 dd = dmask; dd; dd &= dd - 1) {
+                const int n = (ib + __ffsll((long long)dd) - 1) * 64 + lane;
+                const u64 lk = kk > 1 ? lb[1] : lb[0];
+                const u64 bound = U < lk ? U : lk;
+                if (gB[n] > bound) continue;
+                if (shL[n] != 255) {
+                    const int tt = totL[n];
+                    double r = (double)cntL[n];
+                    r = r + lpT[1];
+                    r = r + ((unsigned)tt < (unsigned)kFfTab ? ffT[tt] : (0.001 * (double)tt) / (double)NP);
+                    r = ldexp(r, -(int)shL[n]);
+                    r = r - 0.0;
+                    if (sortable_bits(r) > bound) continue;
+                }
+                const int nt = BLANCE_QLD(q.ntn + (size_t)rowf * N + n);
+                const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                             q.booster_kind, lpT, ffT)) : gB[n];
+                keep_local(b, n);
+            }
+        } else {
+            // (no bit map for this step -- its row was bumped inside the batch -- or no NumPartitions terms at all: the row
+            // itself, eight entries of the lane in flight at a time)
+            for (int i0 = ib; i0 < ie; i0 += 8) {
+                int ntv[8];
+                bool cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int n = (i0 + u) * 64 + lane;
+                    cv[u] = i0 + u < ie && n < N && (flL[n] & 1) && n != o0 && n != o1 && n != h0 && n != h1;
+                    ntv[u] = (NP > 0 && cv[u]) ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int n = (i0 + u) * 64 + lane;
+                    if (cv[u]) {
+                        const u64 b = ntv[u] ? sortable_bits(queue_score(cntL[n], ntv[u], totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
+                                                                         q.booster_kind, lpT, ffT)) : gB[n];
+                        keep_local(b, n);
+                    }
+                }
+            }
+        }
+        // the wave's k best, ascending, into its slots
+        for (int j = 0; j < kk; j++) {
+            const QMin m = wave_min_key_node(lb[0], ln[0]);
+            if (lane == 0) {
+                int* r = hres + (wave * KM + j) * kQResWords;
+                r[0] = (int)m.hi; r[1] = (int)m.lo; r[2] = m.node;
+            }
+            if (ln[0] == m.node) {
+#pragma unroll
+                for (int e = 0; e + 1 < KM; e++) { lb[e] = lb[e + 1]; ln[e] = ln[e + 1]; }
+                lb[KM - 1] = ~0ull; ln[KM - 1] = INT_MAX;
+            }
+        }
+    };
+    if (wave != 0) {
+        // ---- a helper wave: wait for a command, do its share, wait again
+        for (;;) {
+            lds_barrier();                           // (1) the command is posted, the tables are as the step sees them
+            const int op = uni(hcmd[0]);
+            if (op == kQCmdExit) break;
+            if (op == kQCmdDense) dense_part();
+            lds_barrier();                           // (2) the answers are in
+        }
+        return;
+    }
 
     for (int i = lane; i < kLpTab; i += 64) lpT[i] = NP > 0 ? (double)i / (double)NP : 0.0;
     for (int i = lane; i < kFfTab; i += 64) ffT[i] = NP > 0 ? (0.001 * (double)i) / (double)NP : 0.0;
@@ -957,151 +1098,61 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
                     // ---- the window cannot decide (its entries' exact scores lie above THETA: rows with many entries,
                     // many nodes of equal load): score every node exactly -- what the reference's sort sees
                     n_dense++;
+#ifdef BLANCE_QDIAG
+                    if ((n_dense & 511) == 1 && n_dense < 512 * 120) {      // developer aid: why could the window not decide?
+                        bool el_ = lane < wcnt;
+                        for (int j = 0; j < KM; j++) el_ = el_ && wn != qown[j];
+                        const bool bt_ = el_ && NP > 0 && have_bits && ((bitsL[f * BW + (wn >> 5)] >> (wn & 31)) & 1);
+                        const u64 fK_ = wcnt > 0 ? (((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wk >> 32), 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wk, 0)) : ~0ull;
+                        int tied_ = 0, below_ = 0, rowbits_ = 0, tiedclean_ = 0, lvl_ = 0;
+                        const int c0_ = wcnt > 0 ? cntL[__builtin_amdgcn_readlane(wn, 0)] : -1;
+                        for (int i = 0; i < G; i++) {
+                            const int n = i * 64 + lane;
+                            const bool a_ = n < N && (flL[n] & 1);
+                            const bool b_ = have_bits && ((bitsL[f * BW + (n >> 5)] >> (n & 31)) & 1);
+                            if (a_ && gB[n] == fK_) { tied_++; if (!b_) tiedclean_++; }
+                            if (a_ && gB[n] < thK) below_++;
+                            if (a_ && b_) rowbits_++;
+                            if (a_ && cntL[n] == c0_) lvl_++;
+                        }
+                        for (int o = 32; o; o >>= 1) { tied_ += __shfl_xor(tied_, o, 64); below_ += __shfl_xor(below_, o, 64); rowbits_ += __shfl_xor(rowbits_, o, 64); tiedclean_ += __shfl_xor(tiedclean_, o, 64); lvl_ += __shfl_xor(lvl_, o, 64); }
+                        const int ne_ = __popcll(__ballot(el_)), nd_ = __popcll(__ballot(bt_));
+                        if (lane == 0) printf("[qdiag] step %d dense#%lld wcnt %d elig %d dirty %d theta_inf %d front==theta %d tied %d (clean %d) below_theta %d rowbits %d level(cnt %d) %d row %d own %d ownkey-front %lld have_bits %d\n",
+                                              oi + f, n_dense, wcnt, ne_, nd_, (int)(thN == INT_MAX), (int)(fK_ == thK), tied_, tiedclean_, below_, rowbits_, c0_, lvl_, rowf, qown[0], (long long)(qK[0] - fK_), (int)have_bits);
+                    }
+#endif
                     PHM(dense_begin);
                     PH(12);
-                    u64 lb[KM];
-                    int ln[KM];
-#pragma unroll
-                    for (int j = 0; j < KM; j++) { lb[j] = ~0ull; ln[j] = INT_MAX; }
-                    auto keep_local = [&](u64 b, int n) {               // the lane's own k best, ascending
-                        if (!qless(b, n, lb[KM - 1], ln[KM - 1])) return;       // (most nodes: not among them)
-#pragma unroll
-                        for (int j = KM - 1; j >= 0; j--) {
-                            const bool here = qless(b, n, lb[j], ln[j]);
-                            const bool above = j > 0 && qless(b, n, lb[j - 1], ln[j - 1]);
-                            if (here) {
-                                if (above) { lb[j] = lb[j - 1]; ln[j] = ln[j - 1]; }
-                                else { lb[j] = b; ln[j] = n; }
-                            }
-                        }
-                    };
-                    auto is_cand = [&](int n) -> bool {
-                        bool el = n < N && (flL[n] & 1);
-#pragma unroll
-                        for (int j = 0; j < KM; j++) if (qown[j] == n) el = false;      // own: scored above
-#pragma unroll
-                        for (int j = 0; j < KH; j++) if (qh[j] == n) el = false;        // plan.go:146-154
-                        return el;
-                    };
-                    if (NP > 0 && have_bits) {
-                        // the row's bit map says which entries are zero: (A) the k best of those, by their keys in LDS; (B) a node
-                        // with an entry is read from the matrix only if its score with an entry of 1 -- a lower bound -- does
-                        // not lie above the k-th of (A).  Lane l looks at nodes l, 64 + l, ...: bit i of the masks = node 64 i + l.
-                        u64 cand = alivecol, dirtycol = 0;
-#pragma unroll
-                        for (int j = 0; j < KM; j++) if (qown[j] >= 0 && (qown[j] & 63) == lane) cand &= ~(1ull << (qown[j] >> 6));
-#pragma unroll
-                        for (int j = 0; j < KH; j++) if (qh[j] >= 0 && (qh[j] & 63) == lane) cand &= ~(1ull << (qh[j] >> 6));
-                        // One pass over the lane's nodes, no branch: the row's bits and the keys come in eights; a node that is no
-                        // candidate or has its bit set takes part with the key ~0; the lane's two smallest are kept by strict
-                        // less-than -- a lane's nodes ascend, so of equal keys the smaller node stays in front, the order of
-                        // plan.go:617-628.  (With a branch per node some lane of the 64 improves its pair in nearly every
-                        // round and the whole wave walks the update: measured 180 cycles per node of the lane, 11.5 K per step.)
-                        unsigned cand_w[2] = {(unsigned)cand, (unsigned)(cand >> 32)}, dirty_w[2] = {0u, 0u};
-                        u64 b0 = ~0ull, b1 = ~0ull;
-                        int n0 = INT_MAX, n1 = INT_MAX;
-#pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            for (int j0 = 0; j0 < 32; j0 += 8) {
-                                const int i0 = h * 32 + j0;
-                                if (i0 >= G) break;
-                                unsigned wv[8];
-                                u64 kv[8];
-#pragma unroll
-                                for (int u = 0; u < 8; u++) wv[u] = i0 + u < G ? bitsL[f * BW + 2 * (i0 + u) + (lane >> 5)] : 0u;
-#pragma unroll
-                                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
-#pragma unroll
-                                for (int u = 0; u < 8; u++) {
-                                    const unsigned d = (wv[u] >> (lane & 31)) & 1u;
-                                    dirty_w[h] |= d << (j0 + u);
-                                    const bool ok = (((cand_w[h] >> (j0 + u)) & 1u) & (d ^ 1u)) != 0;
-                                    const u64 key = ok ? kv[u] : ~0ull;
-                                    const int n = (i0 + u) * 64 + lane;
-                                    const bool lt0 = key < b0;
-                                    if (k > 1) {                       // (wave uniform; k = 1 keeps one)
-                                        const bool lt1 = key < b1;
-                                        b1 = lt0 ? b0 : (lt1 ? key : b1);
-                                        n1 = lt0 ? n0 : (lt1 ? n : n1);
-                                    }
-                                    b0 = lt0 ? key : b0;
-                                    n0 = lt0 ? n : n0;
-                                }
-                            }
-                        }
-                        dirtycol = ((u64)dirty_w[1] << 32) | dirty_w[0];
-                        lb[0] = b0; ln[0] = n0;
-                        static_assert(KM == 2, "the lane keeps a pair");
-                        lb[1] = b1; ln[1] = n1;
-                        PHM(dense_bits_done);
-                        PH(13);
-                        PHM(dense_keys_done);
-                        PH(14);
-                        u64 cK = ~0ull;                              // the k-th best clean key over the wave (~0: fewer than k)
-                        {
-                            u64 tb[KM];
-                            int tn[KM];
-#pragma unroll
-                            for (int j = 0; j < KM; j++) { tb[j] = lb[j]; tn[j] = ln[j]; }
-                            for (int j = 0; j < k; j++) {
-                                const QMin m = wave_min_key_node(tb[0], tn[0]);
-                                cK = m.node == INT_MAX ? ~0ull : (((u64)m.hi << 32) | m.lo);
-                                if (tn[0] == m.node) {
-#pragma unroll
-                                    for (int e = 0; e + 1 < KM; e++) { tb[e] = tb[e + 1]; tn[e] = tn[e + 1]; }
-                                    tb[KM - 1] = ~0ull; tn[KM - 1] = INT_MAX;
-                                }
-                            }
-                        }
-                        PHM(dense_ck_done);
-                        for (u64 dd = cand & dirtycol; dd; dd &= dd - 1) {
-                            const int n = (__ffsll((long long)dd) - 1) * 64 + lane;
-                            if (gB[n] > cK) continue;
-                            const int tt = totL[n];
-                            double r = (double)cntL[n];
-                            r = r + lpT[1];
-                            r = r + ((unsigned)tt < (unsigned)kFfTab ? ffT[tt] : (0.001 * (double)tt) / (double)NP);
-                            bool maybe = true;
-                            if (shL[n] != 255) { r = ldexp(r, -(int)shL[n]); r = r - 0.0; maybe = !(sortable_bits(r) > cK); }
-                            if (!maybe) continue;
-                            const int nt = BLANCE_QLD(q.ntn + (size_t)rowf * N + n);
-                            const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
-                                                                         q.booster_kind, lpT, ffT)) : gB[n];
-                            keep_local(b, n);
-                        }
-                    } else {
-                    // (no bit map for this step -- its row was bumped inside the batch: the row itself, eight entries of the
-                    // lane in flight at a time; one entry per round trip made such a step 64 round trips, ~140 us)
-                    for (int i0 = 0; i0 < G; i0 += 8) {
-                        int ntv[8];
-                        bool cv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int n = (i0 + u) * 64 + lane;
-                            cv[u] = i0 + u < G && is_cand(n);
-                            ntv[u] = (NP > 0 && cv[u]) ? BLANCE_QLD(q.ntn + (size_t)rowf * N + n) : 0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int n = (i0 + u) * 64 + lane;
-                            if (cv[u]) {
-                                const u64 b = ntv[u] ? sortable_bits(queue_score(cntL[n], ntv[u], totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
-                                                                                 q.booster_kind, lpT, ffT)) : gB[n];
-                                keep_local(b, n);
-                            }
-                        }
+                    // every wave of the workgroup takes a share of the nodes (dense_part above); the command:
+                    if (lane == 0) {
+                        hcmd[0] = kQCmdDense; hcmd[1] = f; hcmd[2] = k;
+                        hcmd[3] = qown[0]; hcmd[4] = qown[1]; hcmd[5] = qh[0]; hcmd[6] = qh[1];
+                        hcmd[7] = (NP > 0 && have_bits) ? 1 : 0; hcmd[8] = rowf;
+                        // the step's k-th pick is no worse than the k-th best of its own nodes
+                        u64 U = ~0ull;
+                        if (nown_f >= k) { U = qK[0]; if (k > 1 && qK[1] > U) U = qK[1]; }
+                        hcmd[10] = (int)(unsigned)(U >> 32); hcmd[11] = (int)(unsigned)U;
                     }
-                    }
-                    PHM(dense_dirty_done);
+                    BLANCE_QWAIT_BUMPS();            // (rows bumped by this wave are read by the others)
+                    if (NW > 1) lds_barrier(); else BLANCE_WAVE_SYNC();
+                    dense_part();
+                    PH(13);
+                    if (NW > 1) lds_barrier(); else BLANCE_WAVE_SYNC();
                     PH(15);
-                    for (int j = 0; j < k; j++) {
-                        const QMin m = wave_min_key_node(lb[0], ln[0]);
-                        if (m.node == INT_MAX) break;
-                        insert(((u64)m.hi << 32) | m.lo, m.node);
-                        if (ln[0] == m.node) {
-#pragma unroll
-                            for (int e = 0; e + 1 < KM; e++) { lb[e] = lb[e + 1]; ln[e] = ln[e + 1]; }
-                            lb[KM - 1] = ~0ull; ln[KM - 1] = INT_MAX;
+                    {
+                        u64 ek = ~0ull;
+                        int en = INT_MAX;
+                        if (lane < NW * k) {
+                            const int* r = hres + ((lane / k) * KM + (lane % k)) * kQResWords;
+                            ek = ((u64)(unsigned)r[0] << 32) | (unsigned)r[1];
+                            en = r[2];
+                            if (en == INT_MAX) ek = ~0ull;
+                        }
+                        for (int j = 0; j < k; j++) {
+                            const QMin m = wave_min_key_node(ek, en);
+                            if (m.node == INT_MAX) break;
+                            insert(((u64)m.hi << 32) | m.lo, m.node);
+                            if (en == m.node) { ek = ~0ull; en = INT_MAX; }
                         }
                     }
                     PHM(dense_end);
@@ -1309,6 +1360,10 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
         printf("[queue rebuilds] %.0f kcycles, %lld column scans of lane 0 (first scans: %.0f kcycles)\n", (double)rb_cycles / 1e3, rb_scans, (double)rb_scan_cycles / 1e3);
     }
 #endif
+    if (NW > 1) {                                    // the helper waves leave
+        if (lane == 0) hcmd[0] = kQCmdExit;
+        lds_barrier();
+    }
     if (lane == 0) {
         q.stop[0] = stop_pos;
         q.stop[1] = stop_why;
@@ -1326,7 +1381,7 @@ __global__ __launch_bounds__(64) void k_pass_queue(PassParams q) {
 static inline size_t queue_lds_bytes(int NX, int RW) {
     const size_t NXp = (size_t)((NX + 63) / 64) * 64, BW = ((NXp >> 5) + 3) & ~(size_t)3;
     return NXp * (8 + 4 + 4 + 4 + 1 + 1 + 1 + 2) + 64 + sizeof(double) * (kLpTab + kFfTab) + sizeof(int32_t) * (size_t)(64 * RW) +
-           sizeof(int32_t) * 64 * 3 + sizeof(int32_t) * 64 * BW + 64;
+           sizeof(int32_t) * 64 * 3 + sizeof(int32_t) * 64 * BW + 64 + sizeof(int32_t) * (kQCmdWords + kQueueWaves * 2 * kQResWords);
 }
 
 }  // namespace blance

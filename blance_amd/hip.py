@@ -98,8 +98,10 @@ class Planner:
         # 512 = flat passes with k <= 2 never on k_pass_queue (k_pass_tree / k_pass_seq take them, as before round 4);
         # 1024 = k_pass_queue without its lean walk (every step that does not stay through its general code)
         # 2048 = ... and every general step of it scoring every node; 4096 = its lean walk as compiled C++ only (the device
-        # build walks the plain k = 2 steps in hand-written assembly, k_queue_walk.h)
-        qbits = {True: 0, "on": 0, False: 512, "off": 512, "general": 1024, "dense": 1024 | 2048, "lean-cpp": 4096}[queue]
+        # build walks the plain k = 2 steps in hand-written assembly, k_queue_walk.h); 8192 = k_pass_queue as ONE wave, without
+        # the helper waves that share the dense step (round 5)
+        qbits = {True: 0, "on": 0, False: 512, "off": 512, "general": 1024, "dense": 1024 | 2048, "lean-cpp": 4096,
+                 "one-wave": 8192, "dense-one-wave": 1024 | 2048 | 8192}[queue]
         opt.reserved[2] = qbits | (0 if periodic else 256) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()

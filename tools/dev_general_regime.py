@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer aid: config 3 with scrambled names + Zipf partition weights (bench.py's general_regime workload b) at P x N
-through devbuild/libblance_prof.so when it exists (per-launch statistics and phase clocks of k_pass_queue), BLANCE_TRACE style;
+through devbuild/libblance_prof.so (or the library BLANCE_DEV_LIB names) when it exists (per-launch statistics and phase clocks of k_pass_queue), BLANCE_TRACE style;
 BLANCE_DEV_PRODUCT=1: through the product library.
     python tools/dev_general_regime.py [P N]"""
 import os
@@ -13,7 +13,7 @@ from blance_amd import hip, synth          # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 2 else 1 << 20
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-lib = os.path.join(ROOT, "devbuild", "libblance_prof.so")
+lib = os.environ.get("BLANCE_DEV_LIB") or os.path.join(ROOT, "devbuild", "libblance_prof.so")
 pl = hip.Planner(lib_path=lib if (os.path.exists(lib) and not os.environ.get("BLANCE_DEV_PRODUCT")) else None)
 fp = synth.config3_named_weighted_flat(P, N)
 t = time.time()
