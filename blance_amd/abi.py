@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -145,6 +145,17 @@ class FlatProblem:
             self._struct = s
         return self._struct
 
+    def pin(self, arena):
+        """Move every array into page-locked memory of `arena` (hip.HostArena): blance_upload then copies by DMA from where
+        they lie instead of staging them."""
+        for n in list(self.arrays):
+            a = self.arrays[n]
+            if a.size:
+                self.arrays[n] = arena.copy_of(a)
+        self._struct = None
+        self._arena = arena
+        return self
+
     def result_capacity(self):
         P, M = self.scalars["n_parts"], self.scalars["n_states"]
         if P * M == 0:
@@ -157,14 +168,16 @@ class FlatProblem:
 class FlatResult:
     """Caller-owned output buffers for one blance_plan call."""
 
-    def __init__(self, prob):
+    def __init__(self, prob, arena=None):
         P, M = prob.scalars["n_parts"], prob.scalars["n_states"]
         cap = prob.result_capacity()
-        self.out_off = np.zeros(P * M + 1, dtype=np.int32)
-        self.out_nodes = np.zeros(max(cap, 1), dtype=np.int32)
-        self.out_kind = np.zeros(max(P * M, 1), dtype=np.uint8)
-        self.warn_part = np.zeros(max(P * M, 1), dtype=np.int32)
-        self.warn_state = np.zeros(max(P * M, 1), dtype=np.int32)
+        new = (lambda n, dt: np.zeros(n, dtype=dt)) if arena is None else arena.empty
+        self._arena = arena
+        self.out_off = new(P * M + 1, np.int32)
+        self.out_nodes = new(max(cap, 1), np.int32)
+        self.out_kind = new(max(P * M, 1), np.uint8)
+        self.warn_part = new(max(P * M, 1), np.int32)
+        self.warn_state = new(max(P * M, 1), np.int32)
         s = Result()
         s.out_off = _ptr(self.out_off, C.c_int32)
         s.out_nodes = _ptr(self.out_nodes, C.c_int32)

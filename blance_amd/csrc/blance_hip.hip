@@ -8,8 +8,10 @@
 #include "dev_prelude.h"
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -61,6 +63,116 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// ---- page-locked host memory (include/blance_hip.h: blance_host_alloc).  hipHostMalloc costs milliseconds for the
+// sizes of a plan, so freed blocks are kept (up to kPinCacheMax bytes) and handed out again.
+struct CopySeg { void* dst; const void* src; size_t bytes; };
+namespace {
+constexpr size_t kPinCacheMax = (size_t)2 << 30;
+struct PinBlock { void* p; size_t cap; };
+std::mutex g_pin_mu;
+std::vector<PinBlock> g_pin_free;
+std::map<uintptr_t, size_t> g_pin_live;          // blocks handed out: base -> capacity
+size_t g_pin_cached = 0;
+
+void* pin_alloc(size_t bytes) {
+    const size_t want = ((bytes ? bytes : 1) + 65535) & ~(size_t)65535;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        size_t best = g_pin_free.size();
+        for (size_t i = 0; i < g_pin_free.size(); i++)
+            if (g_pin_free[i].cap >= want && g_pin_free[i].cap <= 2 * want + (1u << 20) &&
+                (best == g_pin_free.size() || g_pin_free[i].cap < g_pin_free[best].cap)) best = i;
+        if (best < g_pin_free.size()) {
+            PinBlock b = g_pin_free[best];
+            g_pin_free.erase(g_pin_free.begin() + (long)best);
+            g_pin_cached -= b.cap;
+            g_pin_live[(uintptr_t)b.p] = b.cap;
+            return b.p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    g_pin_live[(uintptr_t)p] = want;
+    return p;
+}
+void pin_free(void* p) {
+    if (!p) return;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        auto it = g_pin_live.find((uintptr_t)p);
+        if (it == g_pin_live.end()) return;          // not one of ours
+        cap = it->second;
+        g_pin_live.erase(it);
+        if (g_pin_cached + cap <= kPinCacheMax) { g_pin_free.push_back(PinBlock{p, cap}); g_pin_cached += cap; return; }
+    }
+    (void)hipHostFree(p);
+}
+// does [p, p + bytes) lie in page-locked memory the device can copy from / to directly?
+bool host_ptr_pinned(const void* p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        auto it = g_pin_live.upper_bound(a);
+        if (it != g_pin_live.begin()) {
+            --it;
+            if (a >= it->first && a + bytes <= it->first + it->second) return true;
+        }
+    }
+#ifndef BLANCE_SIMT_EMU
+    if (bytes >= ((size_t)1 << 20)) {                // (memory the caller registered itself: worth a query for big arrays only)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    }
+#endif
+    return false;
+}
+
+// n bytes copied by a few threads (a pageable array on its way into / out of the staging buffer: one core moves ~10 GB/s,
+// the link five times that)
+void copy_threaded(const std::vector<CopySeg>& segs) {
+    size_t total = 0;
+    for (const CopySeg& g : segs) total += g.bytes;
+    unsigned T = 1;
+    if (total >= ((size_t)4 << 20)) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        T = hw >= 16 ? 6 : hw >= 8 ? 4 : hw >= 4 ? 2 : 1;
+        const unsigned by_size = (unsigned)(total >> 21);
+        if (by_size < T) T = by_size ? by_size : 1;
+    }
+    auto work = [&](unsigned t) {
+        const size_t lo = total * t / T, hi = total * (t + 1) / T;
+        size_t pos = 0;
+        for (const CopySeg& g : segs) {
+            const size_t b = pos, e = pos + g.bytes;
+            pos = e;
+            if (e <= lo || b >= hi) continue;
+            const size_t from = lo > b ? lo - b : 0, to = (hi < e ? hi : e) - b;
+            memcpy((char*)g.dst + from, (const char*)g.src + from, to - from);
+        }
+    };
+    std::vector<std::thread> th;
+    struct Join { std::vector<std::thread>& v; ~Join() { for (auto& t : v) if (t.joinable()) t.join(); } } join{th};
+    unsigned started = 1;
+    try {
+        for (unsigned t = 1; t < T; t++) { th.emplace_back(work, t); started++; }
+    } catch (...) {}                                  // (no more threads: this one does the rest)
+    work(0);
+    for (unsigned t = started; t < T; t++) work(t);
+}
+}  // namespace
+
+extern "C" void* blance_host_alloc(size_t bytes) { return pin_alloc(bytes); }
+extern "C" void blance_host_free(void* p) { pin_free(p); }
+
+struct HostStage {                                   // a page-locked staging buffer of the context
+    void* p = nullptr;
+    size_t cap = 0, used = 0;
+    void release() { if (p) pin_free(p); p = nullptr; cap = used = 0; }
+};
+
 struct blance_ctx {
     int device = 0;
     int engine = BLANCE_ENGINE_AUTO;
@@ -87,6 +199,8 @@ struct blance_ctx {
     bool trace = false;             // BLANCE_TRACE, read once at context creation
     int dump_sweep = -1;            // BLANCE_DUMP_SWEEP (developer aid), likewise
     DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
+    HostStage stage;                // pageable arrays of the caller pass through this page-locked buffer
+    DevBuf vres, vseen;             // blance_upload: the device's part of the validation (k_validate_parts)
     DevBuf mv[11];                  // blance_calc_moves: inputs, per-partition slices, offsets, compacted outputs (kept between calls)
     int64_t comm_calls = 0, comm_bytes = 0;
 
@@ -107,7 +221,7 @@ struct blance_ctx {
     bool queue_general = false;     // test knob (& 1024): k_pass_queue without its lean walk
     bool queue_no_asm = false;      // test knob (& 4096): k_pass_queue's lean walk as compiled C++ only
     bool queue_force_dense = false; // test knob (& 2048): every general step of k_pass_queue scores every node
-    bool queue_one_wave = false;    // test knob (& 8192): k_pass_queue without its helper waves
+    bool queue_exact_rebuild = false; // test knob (& 8192): k_pass_queue's window always rebuilt by the exact selection
     DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
     bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
     // nodeToNodeCounts (67 MB at config 3) is zeroed lazily: only a pass that reads or bumps the matrix in HBM pays for it
@@ -166,7 +280,8 @@ struct blance_ctx {
         rule_regions.clear();
         topkey.release(); top_counts.release(); top_off.release(); top_order.release();
         cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release(); ntn_bits.release();
-        dl_off.release(); dl_nodes.release();
+        dl_off.release(); dl_nodes.release(); vres.release(); vseen.release();
+        stage.release();
         for (DevBuf& b : mv) b.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &period, &cnt_p1, &n_ev, &chain_oi,
                           &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
@@ -204,8 +319,10 @@ extern "C" int64_t blance_result_capacity(const blance_problem* pb) {
     return cap;
 }
 
-extern "C" int blance_validate(const blance_problem* pb) {
-    return guarded([&]() -> int {
+// blance_validate in four parts, in the order of its checks: head (sizes, pointers), parts (the O(P) loops: CSR shape, ids,
+// the order's permutation -- blance_upload runs these on the device, k_validate_parts), tail_a (loads, rules, hierarchy),
+// tail_b (what needs the longest list and the weight sums).
+static int validate_head(const blance_problem* pb) {
     if (!pb) return fail(BLANCE_ERR_BAD_ARG, "null problem");
     const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
     if (N < 0 || NX < N || M < 0 || P < 0 || pb->n_prev < 0 || pb->n_loads < 0 || pb->n_rules < 0 ||
@@ -221,8 +338,15 @@ extern "C" int blance_validate(const blance_problem* pb) {
                           pb->prev_kind, pb->load_state, pb->load_node, pb->load_weight, pb->load_first_sweep_only,
                           pb->rule_off, pb->rule_inc, pb->rule_exc, pb->node_leaf_pos};
     for (const void* q : need) if (!q) return fail(BLANCE_ERR_BAD_ARG, "null array pointer");
-    const int64_t PM = (int64_t)P * M;
     if (pb->assign_off[0] != 0 || pb->prev_off[0] != 0) return fail(BLANCE_ERR_BAD_ARG, "CSR offsets must start at 0");
+    return BLANCE_OK;
+}
+
+struct PartsSummary { int L; long long fresh, cap, sumw, aprev; };
+
+static int validate_parts_host(const blance_problem* pb, PartsSummary* ps) {
+    const int NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
+    const int64_t PM = (int64_t)P * M;
     for (int64_t i = 0; i < PM; i++) {
         if (pb->assign_off[i + 1] < pb->assign_off[i] || pb->prev_off[i + 1] < pb->prev_off[i])
             return fail(BLANCE_ERR_BAD_ARG, "CSR offsets not monotone");
@@ -243,6 +367,26 @@ extern "C" int blance_validate(const blance_problem* pb) {
             seen[p] = 1;
         }
     }
+    ps->L = 0; ps->fresh = ps->cap = ps->sumw = ps->aprev = 0;
+    for (int64_t i = 0; i < PM; i++) {
+        int a = pb->assign_off[i + 1] - pb->assign_off[i], b = pb->prev_off[i + 1] - pb->prev_off[i];
+        if (a > ps->L) ps->L = a;
+        if (b > ps->L) ps->L = b;
+        const int k = pb->state_constraints[i % M];
+        ps->cap += a > k ? a : k;
+    }
+    auto la = [](long long v) { return v < 0 ? -v : v; };
+    for (int p = 0; p < P; p++) {
+        const long long w = (!pb->partition_weights_nil && pb->part_has_weight[p]) ? la(pb->part_weight[p]) : 1;
+        ps->sumw += w;
+        if (pb->part_in_prev[p]) ps->aprev += w * (pb->prev_off[(int64_t)(p + 1) * M] - pb->prev_off[(int64_t)p * M]);
+        else ps->fresh++;
+    }
+    return BLANCE_OK;
+}
+
+static int validate_tail_a(const blance_problem* pb) {
+    const int NX = pb->n_nodes_ext, M = pb->n_states;
     for (int i = 0; i < pb->n_loads; i++)
         if (pb->load_state[i] < 0 || pb->load_state[i] > M || pb->load_node[i] < 0 || pb->load_node[i] >= NX)
             return fail(BLANCE_ERR_BAD_ARG, "load entry out of range");
@@ -274,29 +418,35 @@ extern "C" int blance_validate(const blance_problem* pb) {
     if (pb->booster_kind != BLANCE_BOOSTER_NONE && pb->booster_kind != BLANCE_BOOSTER_CBGT)
         return fail(BLANCE_ERR_UNSUPPORTED, "unknown booster kind");
     if (NX > 1024 * 8) return fail(BLANCE_ERR_UNSUPPORTED, "more than 8192 node names (register-resident tables)");
+    return BLANCE_OK;
+}
+
+static int validate_tail_b(const blance_problem* pb, const PartsSummary& ps) {
+    const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states;
     int L = 1;
     for (int m = 0; m < M; m++) if (pb->state_constraints[m] > L) L = pb->state_constraints[m];
-    for (int64_t i = 0; i < PM; i++) {
-        int a = pb->assign_off[i + 1] - pb->assign_off[i], b = pb->prev_off[i + 1] - pb->prev_off[i];
-        if (a > L) L = a;
-        if (b > L) L = b;
-    }
+    if (ps.L > L) L = ps.L;
     if (kRecHead + M * (1 + L) > 64) return fail(BLANCE_ERR_UNSUPPORTED, "step record wider than 64 words (states x list length)");
     {   // the load tables are int32: bound every sum a plan can form (a shim doing its own interning gets the check too)
-        long long abs_load = 0, sumw = 0, ksum = 0;
+        long long abs_load = ps.aprev, ksum = 0;
         auto la = [](long long v) { return v < 0 ? -v : v; };
-        for (int p = 0; p < P; p++) {
-            const long long w = (!pb->partition_weights_nil && pb->part_has_weight[p]) ? la(pb->part_weight[p]) : 1;
-            sumw += w;
-            if (pb->part_in_prev[p]) abs_load += w * (pb->prev_off[(int64_t)(p + 1) * M] - pb->prev_off[(int64_t)p * M]);
-        }
         for (int i = 0; i < pb->n_loads; i++) abs_load += la(pb->load_weight[i]);
         for (int m = 0; m < M; m++) ksum += pb->state_constraints[m] > 0 ? pb->state_constraints[m] : 0;
-        abs_load += sumw * (ksum > 1 ? ksum : 1) * 2;
+        abs_load += ps.sumw * (ksum > 1 ? ksum : 1) * 2;
         if (abs_load > 2147483647LL) return fail(BLANCE_ERR_UNSUPPORTED, "partition weights overflow the int32 load tables");
     }
     if ((int64_t)(NX + 1) * (N > 0 ? N : 1) * 4 > (int64_t)64 << 30) return fail(BLANCE_ERR_UNSUPPORTED, "nodeToNodeCounts matrix > 64 GiB");
     return BLANCE_OK;
+}
+
+extern "C" int blance_validate(const blance_problem* pb) {
+    return guarded([&]() -> int {
+    int st = validate_head(pb);
+    if (st) return st;
+    PartsSummary ps;
+    if ((st = validate_parts_host(pb, &ps))) return st;
+    if ((st = validate_tail_a(pb))) return st;
+    return validate_tail_b(pb, ps);
     });
 }
 
@@ -324,7 +474,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->queue_general = opt && (opt->reserved[2] & 1024);
     c->queue_force_dense = opt && (opt->reserved[2] & 2048);
     c->queue_no_asm = opt && (opt->reserved[2] & 4096);
-    c->queue_one_wave = opt && (opt->reserved[2] & 8192);
+    c->queue_exact_rebuild = opt && (opt->reserved[2] & 8192);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->periodic = !(opt && (opt->reserved[2] & 256));
@@ -354,19 +504,96 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     delete c;
 }
 
-template <class T>
-static int put(blance_ctx* c, DevBuf& b, const T* src, size_t n) {
-    if (b.reserve(n * sizeof(T))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
-    if (n) HIPTRY(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+// ---- host <-> device copies.  An array in page-locked memory (blance_host_alloc, or registered by the caller) is copied by
+// DMA where it lies; a pageable one passes through the context's page-locked staging buffer -- small ones at once, big ones
+// (>= 1 MB) by a few threads at flush().  Nothing of the caller's is read after the stream synchronisation that ends the call.
+struct Mover {
+    blance_ctx* c;
+    bool to_device;
+    std::vector<CopySeg> host_copy;                 // pending host side copies (caller <-> staging)
+    std::vector<CopySeg> dma;                       // the DMAs that go with them (to_device: after the host copy; else before)
+    Mover(blance_ctx* ctx, bool up) : c(ctx), to_device(up) {}
+    int reserve(size_t bytes);                       // staging space for `bytes` more
+    int copy(void* dst, const void* src, size_t bytes);
+    int flush();                                     // to_device: host copies done and DMAs enqueued on return
+    int finish();                                    // device -> host: DMAs done, then the host copies
+};
+static int stage_grow(blance_ctx* c, size_t need) {  // (the stream is idle, nothing pending)
+    HostStage& st = c->stage;
+    size_t cap = st.cap * 2 > need ? st.cap * 2 : need;
+    cap = (cap + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    st.release();
+    st.p = pin_alloc(cap);
+    if (!st.p) return fail(BLANCE_ERR_DEVICE, "page-locked staging buffer: hipHostMalloc failed");
+    st.cap = cap;
+    st.used = 0;
     return 0;
 }
-#define PUT(buf, src, n) do { int e__ = put(c, c->buf, src, (size_t)(n)); if (e__) return e__; } while (0)
+int Mover::reserve(size_t bytes) {
+    HostStage& st = c->stage;
+    if (st.used + bytes <= st.cap) return 0;
+    int e = to_device ? flush() : finish();
+    if (e) return e;
+    HIPTRY(hipStreamSynchronize(c->stream));
+    if (bytes <= st.cap) { st.used = 0; return 0; }
+    return stage_grow(c, bytes);
+}
+int Mover::copy(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return 0;
+    const void* host = to_device ? src : dst;
+    if (host_ptr_pinned(host, bytes)) {
+        HIPTRY(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c->stream));
+        return 0;
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    int e = reserve(need);
+    if (e) return e;
+    HostStage& st = c->stage;
+    char* at = (char*)st.p + st.used;
+    st.used += need;
+    if (to_device) {
+        if (bytes < ((size_t)1 << 20)) {
+            memcpy(at, src, bytes);
+            HIPTRY(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            host_copy.push_back(CopySeg{at, src, bytes});
+            dma.push_back(CopySeg{dst, at, bytes});
+        }
+    } else {
+        HIPTRY(hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        host_copy.push_back(CopySeg{dst, at, bytes});
+    }
+    return 0;
+}
+int Mover::flush() {
+    if (!to_device) return 0;
+    if (!host_copy.empty()) copy_threaded(host_copy);
+    host_copy.clear();
+    for (const CopySeg& g : dma) HIPTRY(hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, c->stream));
+    dma.clear();
+    return 0;
+}
+int Mover::finish() {
+    if (to_device) return flush();
+    if (host_copy.empty()) return 0;
+    HIPTRY(hipStreamSynchronize(c->stream));
+    copy_threaded(host_copy);
+    host_copy.clear();
+    return 0;
+}
+
+template <class T>
+static int put(Mover& mv, DevBuf& b, const T* src, size_t n) {
+    if (b.reserve(n * sizeof(T))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    return mv.copy(b.p, src, n * sizeof(T));
+}
+#define PUT(buf, src, n) do { int e__ = put(up, c->buf, src, (size_t)(n)); if (e__) return e__; } while (0)
 #define RESERVE(buf, bytes) do { if (c->buf.reserve((size_t)(bytes))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed"); } while (0)
 
 static inline int cdiv(int64_t a, int b) { return (int)((a + b - 1) / b); }
 
 static int upload_inner(blance_ctx* c, const blance_problem* pb);
-// hipMemcpyAsync may still be reading the caller's arrays (and this function's staging tables) when an
+// copies may still be reading the caller's arrays (and the staging buffer) when an
 // error cuts the upload short: never return with copies in flight
 static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     int st = upload_inner(c, pb);
@@ -375,7 +602,7 @@ static int upload_locked(blance_ctx* c, const blance_problem* pb) {
 }
 
 static int upload_inner(blance_ctx* c, const blance_problem* pb) {
-    int st = blance_validate(pb);
+    int st = validate_head(pb);
     if (st) return st;
     HIPTRY(hipSetDevice(c->device));
     c->uploaded = false;
@@ -387,26 +614,21 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     c->state_priority.assign(pb->state_priority, pb->state_priority + M);
     c->state_constraints.assign(pb->state_constraints, pb->state_constraints + M);
     c->rule_off.assign(pb->rule_off, pb->rule_off + M + 1);
-    int L = 1;
-    for (int m = 0; m < M; m++) if (pb->state_constraints[m] > L) L = pb->state_constraints[m];
-    for (int64_t i = 0; i < PM; i++) {
-        int a = pb->assign_off[i + 1] - pb->assign_off[i], b = pb->prev_off[i + 1] - pb->prev_off[i];
-        if (a > L) L = a;
-        if (b > L) L = b;
-    }
-    c->L = L;
-    int fresh = 0;
-    for (int p = 0; p < P; p++) if (!pb->part_in_prev[p]) fresh++;
-    c->np_later = pb->n_prev + fresh;                      // plan.go:50
-    std::vector<uint8_t> alive((size_t)NX + 1, 0);   // lives to the hipStreamSynchronize at the end of this function
+    std::vector<uint8_t> alive((size_t)NX + 1, 0);
     c->n_alive = 0;
     c->any_removed = 0;
     for (int n = 0; n < NX; n++) {
         if (pb->node_removed[n]) c->any_removed = 1;
         if (n < N && !pb->node_removed[n]) { alive[n] = 1; c->n_alive++; }
     }
-    c->out_capacity = blance_result_capacity(pb);
 
+    Mover up(c, true);
+    c->stage.used = 0;                               // (the stream is idle between calls)
+    {   // staging space for everything that may be pageable, asked for once
+        const size_t per_part = 4 + 4 + 1 + 1 + 1, per_pm = 4 + 1 + 4 + 1;
+        const size_t want = (size_t)P * per_part + (size_t)(PM + 1) * per_pm + (size_t)NX * 32 + (size_t)pb->n_loads * 13 + ((size_t)4 << 20);
+        if (c->stage.cap < want && (st = stage_grow(c, want))) return st;
+    }
     PUT(node_removed, pb->node_removed, NX);
     PUT(node_added, pb->node_added, NX);
     PUT(node_weight, pb->node_weight, NX);
@@ -421,10 +643,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     PUT(part_in_prev, pb->part_in_prev, P);
     PUT(part_never_equal, pb->part_prev_never_equal, P);
     PUT(a_off, pb->assign_off, PM + 1);
-    PUT(a_nodes, pb->assign_nodes, pb->assign_off[PM]);
     PUT(a_kind, pb->assign_kind, PM);
     PUT(p_off, pb->prev_off, PM + 1);
-    PUT(p_nodes, pb->prev_nodes, pb->prev_off[PM]);
     PUT(p_kind, pb->prev_kind, PM);
     PUT(load_state, pb->load_state, pb->n_loads);
     PUT(load_node, pb->load_node, pb->n_loads);
@@ -434,6 +654,65 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     PUT(state_has_stick, pb->state_has_stickiness, M);
     PUT(rule_inc, pb->rule_inc, pb->n_rules);
     PUT(rule_exc, pb->rule_exc, pb->n_rules);
+    if ((st = up.flush())) return st;
+
+    // ---- the O(P) checks of blance_validate and the sizes they yield, on the device (k_validate_parts)
+    RESERVE(vres, 64);
+    RESERVE(vseen, sizeof(uint32_t) * ((size_t)P / 32 + 2));
+    HIPTRY(hipMemsetAsync(c->vres.p, 0, 64, c->stream));
+    HIPTRY(hipMemsetAsync(c->vseen.p, 0, sizeof(uint32_t) * ((size_t)P / 32 + 1), c->stream));
+    if (P > 0) {
+        ValidateParams vp;
+        memset(&vp, 0, sizeof vp);
+        vp.P = P; vp.M = M; vp.weights_nil = pb->partition_weights_nil;
+        for (int m = 0; m < M; m++) vp.k[m] = pb->state_constraints[m];
+        vp.a_off = c->a_off.as<int32_t>(); vp.a_kind = c->a_kind.as<uint8_t>();
+        vp.p_off = c->p_off.as<int32_t>(); vp.p_kind = c->p_kind.as<uint8_t>();
+        vp.part_order = c->part_order.as<int32_t>(); vp.part_weight = c->part_weight.as<int32_t>();
+        vp.part_has_weight = c->part_has_weight.as<uint8_t>(); vp.part_in_prev = c->part_in_prev.as<uint8_t>();
+        vp.seen = c->vseen.as<uint32_t>(); vp.res = c->vres.as<int32_t>();
+        BLANCE_LAUNCH(k_validate_parts, cdiv(PM > P ? PM : P, 256), 256, 0, c->stream, vp);
+    }
+    int32_t vr[16] = {0};
+    HIPTRY(hipMemcpyAsync(vr, c->vres.p, sizeof vr, hipMemcpyDeviceToHost, c->stream));
+    const int tail_a = validate_tail_a(pb);          // (the host's share, while the device works)
+    const std::string tail_a_text = g_last_error;
+    HIPTRY(hipStreamSynchronize(c->stream));
+    if (vr[3]) {                                      // the first list the host's loop would have refused, and why
+        const int check = (INT_MAX - vr[3]) & 3;
+        if (check == 0) return fail(BLANCE_ERR_BAD_ARG, "CSR offsets not monotone");
+        if (check == 1) return fail(BLANCE_ERR_BAD_ARG, "bad list kind");
+        return fail(BLANCE_ERR_UNSUPPORTED, "state list longer than 65535");
+    }
+    // the lists' payloads: their lengths are the last offsets, which are sound now
+    const int64_t na = pb->assign_off[PM], np = pb->prev_off[PM];
+    PUT(a_nodes, pb->assign_nodes, na);
+    PUT(p_nodes, pb->prev_nodes, np);
+    if ((st = up.flush())) return st;
+    if (na > 0) BLANCE_LAUNCH(k_validate_ids, cdiv(na, 256), 256, 0, c->stream, (long long)na, NX, c->a_nodes.as<int32_t>(), kVErrAssignId, c->vres.as<int32_t>());
+    if (np > 0) BLANCE_LAUNCH(k_validate_ids, cdiv(np, 256), 256, 0, c->stream, (long long)np, NX, c->p_nodes.as<int32_t>(), kVErrPrevId, c->vres.as<int32_t>());
+    if (na > 0 || np > 0) {
+        HIPTRY(hipMemcpyAsync(vr, c->vres.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPTRY(hipStreamSynchronize(c->stream));
+    }
+    if (vr[0] & kVErrAssignId) return fail(BLANCE_ERR_BAD_ARG, "assign node id out of range");
+    if (vr[0] & kVErrPrevId) return fail(BLANCE_ERR_BAD_ARG, "prev node id out of range");
+    if (vr[0] & kVErrOrder) return fail(BLANCE_ERR_BAD_ARG, "part_order is not a permutation");
+    if (tail_a) { g_last_error = tail_a_text; return tail_a; }
+    PartsSummary ps;
+    {
+        long long r64[3];
+        memcpy(r64, vr + 4, sizeof r64);
+        ps.L = vr[1]; ps.fresh = vr[2]; ps.cap = r64[0]; ps.sumw = r64[1]; ps.aprev = r64[2];
+    }
+    if ((st = validate_tail_b(pb, ps))) return st;
+    int L = 1;
+    for (int m = 0; m < M; m++) if (pb->state_constraints[m] > L) L = pb->state_constraints[m];
+    if (ps.L > L) L = ps.L;
+    c->L = L;
+    c->np_later = pb->n_prev + (int)ps.fresh;              // plan.go:50
+    c->out_capacity = ps.cap;
+
     for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
     c->rule_regions.clear();
     c->any_node_weight = 0;
@@ -538,17 +817,17 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
                     for (int ch = 0; ch * 64 < rhi[g] - rlo[g]; ch++) { wg_region.push_back((int32_t)g); wg_chunk.push_back(ch); }
             rr.n_stay_wgs = (int)wg_region.size();
             if (ok) {
-                if (put(c, rr.wg_region, wg_region.data(), wg_region.size())) return BLANCE_ERR_DEVICE;
-                if (put(c, rr.wg_chunk, wg_chunk.data(), wg_chunk.size())) return BLANCE_ERR_DEVICE;
-                if (put(c, rr.node_region, node_region.data(), node_region.size())) return BLANCE_ERR_DEVICE;
-                if (put(c, rr.reg_lo, rlo.data(), rlo.size())) return BLANCE_ERR_DEVICE;
-                if (put(c, rr.reg_hi, rhi.data(), rhi.size())) return BLANCE_ERR_DEVICE;
-                if (put(c, rr.leaf_cls, leaf_cls.data(), leaf_cls.size())) return BLANCE_ERR_DEVICE;
-                if (put(c, rr.cls_size, cls_size.data(), cls_size.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.wg_region, wg_region.data(), wg_region.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.wg_chunk, wg_chunk.data(), wg_chunk.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.node_region, node_region.data(), node_region.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.reg_lo, rlo.data(), rlo.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.reg_hi, rhi.data(), rhi.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.leaf_cls, leaf_cls.data(), leaf_cls.size())) return BLANCE_ERR_DEVICE;
+                if (put(up, rr.cls_size, cls_size.data(), cls_size.size())) return BLANCE_ERR_DEVICE;
             }
-            HIPTRY(hipStreamSynchronize(c->stream));      // this rule's staging vectors go out of scope
+            if ((st = up.flush())) return st;             // this rule's staging vectors go out of scope (their bytes are in the staging buffer)
         }
-        HIPTRY(hipStreamSynchronize(c->stream));          // ... and the anchor / leaf tables
+        if ((st = up.flush())) return st;                 // ... and the anchor / leaf tables
     }
     const int RW = kRecHead + M * (1 + L);       // header + per-state lists
     int kmax = 1;
@@ -603,7 +882,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
             PUT(fl_one, one.data(), one.size());
             PUT(fl_reglo, &lo0, 1);
             PUT(fl_reghi, &hi0, 1);
-            HIPTRY(hipStreamSynchronize(c->stream));      // iota / zero / one / lo0 / hi0 are locals
+            if ((st = up.flush())) return st;             // iota / zero / one / lo0 / hi0 are locals
         }
         RESERVE(f_tot, sizeof(int32_t) * ((size_t)NX + 1));
         RESERVE(f_g, sizeof(double) * ((size_t)NX + 1));
@@ -618,6 +897,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
         RESERVE(f_vals_b, sizeof(int32_t) * (2 * (size_t)P + 4));
         RESERVE(f_hist, sizeof(int32_t) * 256 * ((size_t)cdiv(2 * (int64_t)P + 4, kSortTile) + 1));
     }
+    if ((st = up.flush())) return st;
     HIPTRY(hipStreamSynchronize(c->stream));
     // the caller's arrays are not retained: drop the host pointers
     blance_problem& h = c->h;
@@ -673,7 +953,7 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
     q.ntn_bits = c->ntn_bits.as<uint32_t>();
     q.stop = scal + 16;
     q.qstats = (long long*)(scal + 18);
-    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0) | (c->queue_one_wave ? 64 : 0);
+    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0) | (c->queue_exact_rebuild ? 64 : 0);
     int pos = q0.beg, chunk = 64;
     while (pos < q0.end) {
         q.beg = pos; q.end = q0.end;
@@ -1725,8 +2005,12 @@ static int download_locked(blance_ctx* c, blance_result* res) {
         return BLANCE_OK;
     }
     res->out_off[0] = 0;
+    Mover down(c, false);
+    c->stage.used = 0;
+    int e = 0;
     if (PM) {
-        // the CSR is made on the device (lengths -> exclusive scan -> gather) and lands in the caller's arrays directly
+        // the CSR is made on the device (lengths -> exclusive scan -> gather) and lands in the caller's arrays: directly when
+        // they are page-locked, through the staging buffer otherwise
         DevProblem d = dev_problem(c);
         RESERVE(dl_off, sizeof(int32_t) * (PM + 2));
         BLANCE_LAUNCH_NOSYNC(k_result_len, cdiv((int64_t)PM + 1, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>());
@@ -1738,14 +2022,15 @@ static int download_locked(blance_ctx* c, blance_result* res) {
         RESERVE(dl_nodes, sizeof(int32_t) * ((size_t)total + 1));
         BLANCE_LAUNCH_NOSYNC(k_result_gather, cdiv((int64_t)PM, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>(),
                              c->dl_nodes.as<int32_t>());
-        HIPTRY(hipMemcpyAsync(res->out_off, c->dl_off.p, sizeof(int32_t) * (PM + 1), hipMemcpyDeviceToHost, c->stream));
-        if (total) HIPTRY(hipMemcpyAsync(res->out_nodes, c->dl_nodes.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipMemcpyAsync(res->out_kind, c->live_kind.p, PM, hipMemcpyDeviceToHost, c->stream));
+        if ((e = down.copy(res->out_off, c->dl_off.p, sizeof(int32_t) * (PM + 1)))) return e;
+        if (total && (e = down.copy(res->out_nodes, c->dl_nodes.p, sizeof(int32_t) * (size_t)total))) return e;
+        if ((e = down.copy(res->out_kind, c->live_kind.p, PM))) return e;
     }
     if (c->n_warnings) {
-        HIPTRY(hipMemcpyAsync(res->warn_part, c->warn_part.p, sizeof(int32_t) * (size_t)c->n_warnings, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipMemcpyAsync(res->warn_state, c->warn_state.p, sizeof(int32_t) * (size_t)c->n_warnings, hipMemcpyDeviceToHost, c->stream));
+        if ((e = down.copy(res->warn_part, c->warn_part.p, sizeof(int32_t) * (size_t)c->n_warnings))) return e;
+        if ((e = down.copy(res->warn_state, c->warn_state.p, sizeof(int32_t) * (size_t)c->n_warnings))) return e;
     }
+    if ((e = down.finish())) return e;
     HIPTRY(hipStreamSynchronize(c->stream));
     res->n_warnings = c->n_warnings;
     res->iterations = c->iterations;

@@ -846,10 +846,12 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
         out.why = u.why;
         return out;
     }
-    if (abi.validate(&f.pb) != BLANCE_OK) { out.why = abi.last_error(); return out; }
+    // (no blance_validate / blance_result_capacity here: blance_plan makes the same checks itself -- the O(P) ones on the
+    // device, ABI 5 -- and refuses with the same text; two more walks over two million offsets were 4 ms of the call)
     const int M = f.pb.n_states, P = f.pb.n_parts;
     const size_t PM = (size_t)P * M;
-    int64_t cap = abi.result_capacity(&f.pb);
+    int64_t cap = (int64_t)f.a_nodes.size();                 // sum of max(k, len) <= sum of len + P * sum of k
+    for (int m = 0; m < M; m++) cap += (int64_t)P * (f.state_constraints[m] > 0 ? f.state_constraints[m] : 0);
     std::vector<int32_t>&out_off = sc.out_off, &out_nodes = sc.out_nodes, &warn_part = sc.warn_part, &warn_state = sc.warn_state;
     std::vector<uint8_t>& out_kind = sc.out_kind;
     out_off.resize(PM + 1); out_nodes.resize((size_t)cap + 1); warn_part.resize(PM + 1); warn_state.resize(PM + 1);

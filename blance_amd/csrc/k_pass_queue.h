@@ -141,7 +141,8 @@ namespace blance {
 // command in LDS, joins the barrier, every wave scans its share of the nodes out of the LDS tables (keys, row bits,
 // counters -- all of them already there), leaves its k best (key, node) in LDS, second barrier, wave 0 merges.
 constexpr int kQueueWaves = 4;
-constexpr int kQCmdExit = 0, kQCmdDense = 1;
+constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdStripe = 2, kQCmdExact = 3;
+constexpr int kQScratch = 5632;                    // bytes the cooperative rebuild needs (aliases rowTag, which only a batch's validation uses)
 constexpr int kQCmdWords = 32, kQResWords = 4;      // a command block; one (key hi, key lo, node, -) result per wave and pick
 
 template <int KM>
@@ -168,8 +169,19 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     unsigned* bitsL = (unsigned*)(outS + 64 * (KM + 1));   // [64 * BW] row bit maps of the batch's steps
     unsigned char* flL = (unsigned char*)(bitsL + 64 * BW);       // [NXp] 1: in nodesNext, 2: has a weight
     unsigned char* rowTag = flL + NXp;               // [NXp + 64] a lane of the batch with this row (any of them)
-    unsigned char* shL = rowTag + NXp + 64;          // [NXp] e when the node's score is divided by 2^e (no weight, weight 0: e = 0)
+    const int RT = NXp + 64 > kQScratch ? NXp + 64 : kQScratch;
+    unsigned char* shL = rowTag + RT;                // [NXp] e when the node's score is divided by 2^e (no weight, weight 0: e = 0)
     unsigned short* ntL = (unsigned short*)(shL + NXp);      // [NXp] folded mode: row "" of nodeToNodeCounts
+    // the cooperative rebuild's scratch, over rowTag (no rebuild runs between a batch's writes and reads of rowTag)
+    u64* runK = (u64*)rowTag;                        // [2 (kQueueWaves - 1) * 64] the sorted runs: keys ...
+    int* runN = (int*)(runK + 2 * (kQueueWaves - 1) * 64);     // ... and nodes
+    u64* winK = (u64*)(runN + 2 * (kQueueWaves - 1) * 64);     // [64] the new window
+    int* winN = (int*)(winK + 64);
+    int* thw = winN + 64;                            // [kQueueWaves * 4] every wave's smallest third minimum (hi, lo, node)
+    int* th65 = thw + kQueueWaves * 4;               // [4] the 65th smallest candidate (hi, lo, node)
+    int* cntw = th65 + 4;                            // [kQueueWaves] candidates below the bound, per wave
+    int* thT = cntw + kQueueWaves;                   // [4] the bound T' (hi, lo, node)
+    static_assert(2 * (kQueueWaves - 1) * 64 * 12 + 64 * 12 + kQueueWaves * 16 + 16 + kQueueWaves * 4 + 16 <= kQScratch, "scratch");
     int* hcmd = (int*)(ntL + NXp);                   // [kQCmdWords] wave 0's command to the helper waves
     int* hres = hcmd + kQCmdWords;                   // [kQueueWaves * KM * kQResWords] their answers
 
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     auto dense_part = [&]() {
         const int f = hcmd[1], kk = hcmd[2], o0 = hcmd[3], o1 = hcmd[4], h0 = hcmd[5], h1 = hcmd[6], hb = hcmd[7], rowf = hcmd[8];
         const u64 U = ((u64)(unsigned)hcmd[10] << 32) | (unsigned)hcmd[11];
-        const int CJ = (G + NW - 1) / NW, ib = wave * CJ, ie = ib + CJ < G ? ib + CJ : G;
+        const int NH = NW - 1, hw = wave - 1;        // the workers are waves 1 .. NW - 1
+        const int CJ = (G + NH - 1) / NH, ib = hw * CJ, ie = ib + CJ < G ? ib + CJ : G;
         u64 lb[KM];
         int ln[KM];
 #pragma unroll
@@ -213,11 +226,12 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 for (int u = 0; u < 8; u++) kv[u] = i0 + u < ie ? gB[(i0 + u) * 64 + lane] : ~0ull;
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
+                    // (the step's own and higher priority nodes have their bits set in this row copy -- the walking wave did
+                    // that before it posted the command --, a node outside nodesNext has the key ~0: no test per node)
                     const int n = (i0 + u) * 64 + lane;
-                    const bool cnd = kv[u] != ~0ull && n != o0 && n != o1 && n != h0 && n != h1;
                     const bool d = ((wv[u] >> (lane & 31)) & 1u) != 0;
-                    if (cnd && d) dmask |= 1ull << (i0 + u - ib);
-                    const u64 key = (cnd && !d) ? kv[u] : ~0ull;
+                    if (d) dmask |= 1ull << (i0 + u - ib);
+                    const u64 key = d ? ~0ull : kv[u];
                     const bool lt0 = key < b0;
                     if (kk > 1) {                       // (wave uniform; k = 1 keeps one)
                         const bool lt1 = key < b1;
@@ -231,13 +245,35 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             lb[0] = b0; ln[0] = n0;
             static_assert(KM == 2, "the lane keeps a pair");
             lb[1] = b1; ln[1] = n1;
-            // entries with their bit set: behind the bound even with an entry of 1 (plan.go:638-644 is monotone in the entry)?
-            // The bound: the step's k-th pick is no worse than the k-th of its own nodes (U), nor than this lane's k-th clean key.
+            // The wave's k best CLEAN nodes first: the k-th of them bounds the step's k-th pick from above (so does U, the k-th
+            // of the step's own nodes), and an entry with its bit set is out of the race when even an entry of 1 (plan.go:638-644
+            // is monotone in the entry) puts it behind that bound -- in the tie regime all of them are, and nobody reads the
+            // matrix.  (Round 5's first form bounded by U and the LANE's clean keys only: U carries the own node's entry, which
+            // stays have raised, and hundreds of set entries per row went to the matrix, a round trip each.)
+            u64 rK[KM];
+            int rN[KM];
+            {
+                u64 tb[KM];
+                int tn[KM];
+#pragma unroll
+                for (int j = 0; j < KM; j++) { tb[j] = lb[j]; tn[j] = ln[j]; rK[j] = ~0ull; rN[j] = INT_MAX; }
+                for (int j = 0; j < kk; j++) {
+                    const QMin m = wave_min_key_node(tb[0], tn[0]);
+#pragma unroll
+                    for (int e = 0; e < KM; e++) if (e == j) { rK[e] = m.node == INT_MAX ? ~0ull : (((u64)m.hi << 32) | m.lo); rN[e] = m.node; }
+                    if (tn[0] == m.node) {
+#pragma unroll
+                        for (int e = 0; e + 1 < KM; e++) { tb[e] = tb[e + 1]; tn[e] = tn[e + 1]; }
+                        tb[KM - 1] = ~0ull; tn[KM - 1] = INT_MAX;
+                    }
+                }
+            }
+            const u64 cK = kk > 1 ? rK[1] : rK[0];
+            const u64 bound = U < cK ? U : cK;
+            bool read_any = false;
             for (u64 dd = dmask; dd; dd &= dd - 1) {
                 const int n = (ib + __ffsll((long long)dd) - 1) * 64 + lane;
-                const u64 lk = kk > 1 ? lb[1] : lb[0];
-                const u64 bound = U < lk ? U : lk;
-                if (gB[n] > bound) continue;
+                if (gB[n] > bound || n >= N || !(flL[n] & 1) || n == o0 || n == o1 || n == h0 || n == h1) continue;
                 if (shL[n] != 255) {
                     const int tt = totL[n];
                     double r = (double)cntL[n];
@@ -251,6 +287,19 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 const u64 b = nt ? sortable_bits(queue_score(cntL[n], nt, totL[n], (flL[n] >> 1) & 1, wL[n], NP, 0.0,
                                                              q.booster_kind, lpT, ffT)) : gB[n];
                 keep_local(b, n);
+                read_any = true;
+            }
+            if (__ballot(read_any) == 0) {           // the common case: the clean minima are the wave's answer
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < KM; j++) {
+                        if (j < kk) {
+                            int* r = hres + (hw * KM + j) * kQResWords;
+                            r[0] = (int)(unsigned)(rK[j] >> 32); r[1] = (int)(unsigned)rK[j]; r[2] = rN[j];
+                        }
+                    }
+                }
+                return;
             }
         } else {
             // (no bit map for this step -- its row was bumped inside the batch -- or no NumPartitions terms at all: the row
@@ -279,7 +328,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         for (int j = 0; j < kk; j++) {
             const QMin m = wave_min_key_node(lb[0], ln[0]);
             if (lane == 0) {
-                int* r = hres + (wave * KM + j) * kQResWords;
+                int* r = hres + (hw * KM + j) * kQResWords;
                 r[0] = (int)m.hi; r[1] = (int)m.lo; r[2] = m.node;
             }
             if (ln[0] == m.node) {
@@ -289,6 +338,144 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             }
         }
     };
+    // ---- the cooperative rebuild (the helper waves between the barriers of a kQCmdStripe command).  Cell (wave, lane) owns
+    // the nodes 64 i + lane of the wave's columns; with m1 <= m2 <= m3 its three smallest (key, node): T' = the smallest m3 of
+    // all cells, candidates = the m1 and m2 below T' -- the window is the 64 smallest of them, the 65th then is THETA, else
+    // T' is.  Every node outside is a candidate >= THETA or lies behind its cell's third: >= m3 >= T' >= THETA -- the
+    // invariant, exactly.  (With the minima alone two of the smallest nodes in one cell cut the window there: ~20 entries
+    // out of 192 cells on scattered keys, and three times the rebuilds; with two per cell it takes three in one cell.)
+    // Each wave sorts its minima and its second minima (bitonic networks over the lanes): 2 (NW - 1) sorted runs; an
+    // element's rank among all candidates is its place in its own run plus, by binary search, the elements of the other
+    // runs in front of it.
+    auto stripe_part = [&]() {
+        const int NH = NW - 1, hw = wave - 1;
+        const int CJ = (G + NH - 1) / NH, ib = hw * CJ, ie = ib + CJ < G ? ib + CJ : G;
+        u64 b0 = ~0ull, b1 = ~0ull, b2 = ~0ull;     // the cell's three smallest keys (nodes ascend: strict compares keep the lower node in front)
+        int n0 = INT_MAX, n1 = INT_MAX, n2 = INT_MAX;
+        for (int i0 = ib; i0 < ie; i0 += 8) {        // (8 independent LDS reads at a time; no branch)
+            u64 kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kv[u] = i0 + u < ie ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u64 key = kv[u];
+                const int n = (i0 + u) * 64 + lane;
+                const bool lt0 = key < b0, lt1 = key < b1, lt2 = key < b2;
+                b2 = lt1 ? b1 : (lt2 ? key : b2);
+                n2 = lt1 ? n1 : (lt2 ? n : n2);
+                b1 = lt0 ? b0 : (lt1 ? key : b1);
+                n1 = lt0 ? n0 : (lt1 ? n : n1);
+                b0 = lt0 ? key : b0;
+                n0 = lt0 ? n : n0;
+            }
+        }
+        if (b0 == ~0ull) n0 = INT_MAX;               // (no candidate)
+        if (b1 == ~0ull) n1 = INT_MAX;
+        if (b2 == ~0ull) n2 = INT_MAX;
+        // the wave's minima and its second minima, each sorted across the lanes: runs 2 hw and 2 hw + 1
+        u64 sk[2] = {b0, b1};
+        int sn[2] = {n0, n1};
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    const u64 pk = ((u64)(unsigned)__shfl_xor((int)(unsigned)(sk[c2] >> 32), j, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)sk[c2], j, 64);
+                    const int pn = __shfl_xor(sn[c2], j, 64);
+                    const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
+                    const bool take = keep_min ? qless(pk, pn, sk[c2], sn[c2]) : qless(sk[c2], sn[c2], pk, pn);
+                    sk[c2] = take ? pk : sk[c2];
+                    sn[c2] = take ? pn : sn[c2];
+                }
+            }
+            runK[(2 * hw + c2) * 64 + lane] = sk[c2];
+            runN[(2 * hw + c2) * 64 + lane] = sn[c2];
+        }
+        const QMin t = wave_min_key_node(b2, n2);
+        if (lane == 0) { thw[hw * 4] = (int)t.hi; thw[hw * 4 + 1] = (int)t.lo; thw[hw * 4 + 2] = t.node; }
+        lds_barrier();                               // (the walking wave passes this one too)
+        u64 tk = ~0ull;
+        int tn = INT_MAX;
+        for (int w2 = 0; w2 < NH; w2++) {
+            const int xn = thw[w2 * 4 + 2];
+            const u64 xk = ((u64)(unsigned)thw[w2 * 4] << 32) | (unsigned)thw[w2 * 4 + 1];
+            if (xn != INT_MAX && qless(xk, xn, tk, tn)) { tk = xk; tn = xn; }
+        }
+        int cw = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            int rank = lane;
+            for (int r2 = 0; r2 < 2 * NH; r2++) {
+                if (r2 == 2 * hw + c2) continue;
+                const u64* rk = runK + r2 * 64;
+                const int* rn = runN + r2 * 64;
+                int pos = 0;                         // elements of run r2 in front of this one: lower bound over 64 sorted entries
+#pragma unroll
+                for (int st = 32; st >= 1; st >>= 1) pos += qless(rk[pos + st - 1], rn[pos + st - 1], sk[c2], sn[c2]) ? st : 0;
+                pos += qless(rk[pos], rn[pos], sk[c2], sn[c2]) ? 1 : 0;
+                rank += pos;
+            }
+            const bool in = sn[c2] != INT_MAX && (tn == INT_MAX || qless(sk[c2], sn[c2], tk, tn));
+            cw += __popcll(__ballot(in));
+            if (in && rank < 64) { winK[rank] = sk[c2]; winN[rank] = sn[c2]; }
+            if (in && rank == 64) { th65[0] = (int)(unsigned)(sk[c2] >> 32); th65[1] = (int)(unsigned)sk[c2]; th65[2] = sn[c2]; }
+        }
+        if (lane == 0) cntw[hw] = cw;
+        if (hw == 0 && lane == 0) { thT[0] = (int)(unsigned)(tk >> 32); thT[1] = (int)(unsigned)tk; thT[2] = tn; }     // the bound T'
+    };
+    // ---- the exact selection (worker 0 alone, when the striped form came out short): 64 + 1 successive minima of the keys
+    // in LDS; lane l owns nodes l, 64 + l, ... (bit i of `taken`: node 64 i + l) and keeps its four smallest untaken keys, so
+    // that a column is scanned again only when all four are gone (64 minima over 64 columns: a column with five is rare).
+    // Results as stripe_part leaves them: winK / winN, cntw[0] = entries, th65 = THETA ((~0, INT_MAX): fewer than 65 candidates).
+    auto exact_part = [&]() {
+        constexpr int RC = 4;
+        u64 taken = 0;
+        int wc = 0;
+        u64 tK = ~0ull;
+        int tN = INT_MAX;
+        u64 ca[RC];
+        int cm[RC];
+        bool exhausted = false;
+        auto scan4 = [&]() {
+#pragma unroll
+            for (int j = 0; j < RC; j++) { ca[j] = ~0ull; cm[j] = INT_MAX; }
+            for (int i0 = 0; i0 < G; i0 += 8) {      // (8 independent LDS reads at a time)
+                u64 kv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    u64 v = kv[u];
+                    int n = (i0 + u) * 64 + lane;
+                    if (((taken >> (i0 + u)) & 1) || v == ~0ull) continue;
+                    bool placed = false;             // ascending i: ties keep the lower node in front; what follows moves down
+#pragma unroll
+                    for (int j = 0; j < RC; j++) {
+                        if (placed || v < ca[j]) { const u64 tv = ca[j]; const int tn = cm[j]; ca[j] = v; cm[j] = n; v = tv; n = tn; placed = true; }
+                    }
+                }
+            }
+            if (cm[0] == INT_MAX) exhausted = true;
+        };
+        scan4();
+        for (int e = 0; e <= 64; e++) {
+            const QMin m = wave_min_key_node(ca[0], cm[0]);
+            if (m.node == INT_MAX) break;            // fewer than 65 candidates: THETA stays infinite
+            const u64 mk = ((u64)m.hi << 32) | m.lo;
+            if (e < 64) {
+                if (lane == 0) { winK[e] = mk; winN[e] = m.node; }
+                wc = e + 1;
+            } else { tK = mk; tN = m.node; }
+            if (cm[0] == m.node) {
+                taken |= 1ull << (m.node >> 6);
+#pragma unroll
+                for (int j = 0; j + 1 < RC; j++) { ca[j] = ca[j + 1]; cm[j] = cm[j + 1]; }
+                ca[RC - 1] = ~0ull; cm[RC - 1] = INT_MAX;
+            }
+            const bool dry = cm[0] == INT_MAX && !exhausted;
+            if (__ballot(dry)) { if (dry) scan4(); }
+        }
+        if (lane == 0) { cntw[0] = wc; th65[0] = (int)(unsigned)(tK >> 32); th65[1] = (int)(unsigned)tK; th65[2] = tN; }
+    };
     if (wave != 0) {
         // ---- a helper wave: wait for a command, do its share, wait again
         for (;;) {
@@ -296,6 +483,8 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             const int op = uni(hcmd[0]);
             if (op == kQCmdExit) break;
             if (op == kQCmdDense) dense_part();
+            if (op == kQCmdStripe) stripe_part();
+            if (op == kQCmdExact && wave == 1) exact_part();
             lds_barrier();                           // (2) the answers are in
         }
         return;
@@ -348,124 +537,50 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     long long rb_cycles = 0, rb_scans = 0, rb_scan_cycles = 0;
 #endif
     int stripe_skip = 0;                             // rebuilds for which the striped form is not tried (it just came out short)
+    int rb_wcnt = 0;                                 // entries the last rebuild left: a window that has not drained since is not rebuilt again
     long long n_striped = 0;
+    // The window is rebuilt by the helper waves (stripe_part; if that comes out short, exact_part): this wave posts the
+    // command, passes the barriers, and loads the new window out of LDS.
     auto rebuild = [&]() {
 #ifdef BLANCE_PHASE_PROF
         const long long rb_t0 = clock64();
 #endif
-        // The striped form first.  Lane l owns nodes l, 64 + l, ...; with m_l / s_l its smallest / second smallest (key, node):
-        // THETA = the smallest s_l, window = the m_l below THETA.  Every node outside it is a lane minimum >= THETA or lies
-        // behind its lane's second: >= s_l >= THETA -- the invariant, exactly.  One pass over the keys, a bitonic sort of the
-        // 64 minima, one wave minimum: a sixth of the exact selection below.  It comes out full when the smallest keys sit
-        // in different lanes -- many nodes of one load, consecutive ids: the regime that drains a window step after step --
-        // and short otherwise (two of the smallest in one lane cut it there); then the exact selection runs.
-        if (stripe_skip > 0) stripe_skip--;
+        bool got = false;
+        if (q.spec & 64) {}                          // (test knob: every rebuild by the exact selection)
+        else if (stripe_skip > 0) stripe_skip--;
         else {
-            u64 b0 = ~0ull, b1 = ~0ull;
-            int n0 = INT_MAX, n1 = INT_MAX;
-            for (int i0 = 0; i0 < G; i0 += 8) {      // (8 independent LDS reads at a time; no branch: see the dense step)
-                u64 kv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const u64 key = kv[u];
-                    const int n = (i0 + u) * 64 + lane;
-                    const bool lt0 = key < b0, lt1 = key < b1;       // (strict: of equal keys the lower node stays in front)
-                    b1 = lt0 ? b0 : (lt1 ? key : b1);
-                    n1 = lt0 ? n0 : (lt1 ? n : n1);
-                    b0 = lt0 ? key : b0;
-                    n0 = lt0 ? n : n0;
-                }
-            }
-            u64 sk = b0;
-            int sn = n0;
-            for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-                for (int j = k2 >> 1; j > 0; j >>= 1) {
-                    const u64 pk = ((u64)(unsigned)__shfl_xor((int)(unsigned)(sk >> 32), j, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)sk, j, 64);
-                    const int pn = __shfl_xor(sn, j, 64);
-                    const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
-                    const bool take = keep_min ? qless(pk, pn, sk, sn) : qless(sk, sn, pk, pn);
-                    sk = take ? pk : sk;
-                    sn = take ? pn : sn;
-                }
-            }
-            const QMin t = wave_min_key_node(b1, n1);
-            const u64 tk = t.node == INT_MAX ? ~0ull : (((u64)t.hi << 32) | t.lo);
-            const bool in = sn != INT_MAX && qless(sk, sn, tk, t.node);
-            const int cw = __popcll(__ballot(in));
-            if (cw >= 48 || t.node == INT_MAX) {
-                wk = in ? sk : ~0ull;
-                wn = in ? sn : INT_MAX;
-                wcnt = uni(cw);
-                thK = uni64(tk);
-                thN = uni(t.node);
-                n_rebuild++;
+            if (lane == 0) hcmd[0] = kQCmdStripe;
+            lds_barrier();                           // (1) posted
+            lds_barrier();                           //     (the workers' own: minima sorted, bounds known)
+            lds_barrier();                           // (2) done
+            int cw = 0;
+            for (int w2 = 0; w2 < NW - 1; w2++) cw += cntw[w2];
+            cw = uni(cw);
+            const int tn = uni(thT[2]);
+            if (cw >= 40 || tn == INT_MAX) {         // (a short window is exact all the same, it only lasts a few steps)
+                const int wc = cw < 64 ? cw : 64;
+                wk = lane < wc ? winK[lane] : ~0ull;
+                wn = lane < wc ? winN[lane] : INT_MAX;
+                wcnt = uni(wc);
+                if (cw > 64) { thK = uni64(((u64)(unsigned)th65[0] << 32) | (unsigned)th65[1]); thN = uni(th65[2]); }
+                else { thK = uni64(((u64)(unsigned)thT[0] << 32) | (unsigned)thT[1]); thN = tn; }
                 n_striped++;
-#ifdef BLANCE_PHASE_PROF
-                rb_cycles += clock64() - rb_t0;
-#endif
-                return;
-            }
-            stripe_skip = 16;
+                got = true;
+            } else stripe_skip = 16;
         }
-        // 64 + 1 successive minima of the keys in LDS; lane l owns nodes l, 64 + l, ... (bit i of `taken`: node 64 i + l)
-        // and keeps its four smallest untaken keys, so that a column is scanned again only when all four are gone
-        // (64 minima over 64 columns: a column with five of them is rare)
-        constexpr int RC = 4;
-        u64 taken = 0;
-        wk = ~0ull; wn = INT_MAX; wcnt = 0; thK = ~0ull; thN = INT_MAX;
-        u64 ca[RC];
-        int cm[RC];
-        bool exhausted = false;
-        auto scan4 = [&]() {
-#pragma unroll
-            for (int j = 0; j < RC; j++) { ca[j] = ~0ull; cm[j] = INT_MAX; }
-            for (int i0 = 0; i0 < G; i0 += 8) {      // (8 independent LDS reads at a time)
-                u64 kv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    u64 v = kv[u];
-                    int n = (i0 + u) * 64 + lane;
-                    if (((taken >> (i0 + u)) & 1) || v == ~0ull) continue;
-                    bool placed = false;             // ascending i: ties keep the lower node in front; what follows moves down
-#pragma unroll
-                    for (int j = 0; j < RC; j++) {
-                        if (placed || v < ca[j]) { const u64 tv = ca[j]; const int tn = cm[j]; ca[j] = v; cm[j] = n; v = tv; n = tn; placed = true; }
-                    }
-                }
-            }
-            if (cm[0] == INT_MAX) exhausted = true;
-#ifdef BLANCE_PHASE_PROF
-            rb_scans++;
-#endif
-        };
-#ifdef BLANCE_PHASE_PROF
-        const long long rb_t1 = clock64();
-#endif
-        scan4();
-#ifdef BLANCE_PHASE_PROF
-        rb_scan_cycles += clock64() - rb_t1;
-#endif
-        for (int e = 0; e <= 64; e++) {
-            const QMin m = wave_min_key_node(ca[0], cm[0]);
-            if (m.node == INT_MAX) break;            // fewer than 65 candidates: THETA stays infinite
-            const u64 mk = ((u64)m.hi << 32) | m.lo;
-            if (e < 64) {
-                if (lane == e) { wk = mk; wn = m.node; }
-                wcnt = uni(e + 1);
-            } else { thK = uni64(mk); thN = uni(m.node); }
-            if (cm[0] == m.node) {
-                taken |= 1ull << (m.node >> 6);
-#pragma unroll
-                for (int j = 0; j + 1 < RC; j++) { ca[j] = ca[j + 1]; cm[j] = cm[j + 1]; }
-                ca[RC - 1] = ~0ull; cm[RC - 1] = INT_MAX;
-            }
-            const bool dry = cm[0] == INT_MAX && !exhausted;
-            if (__ballot(dry)) { if (dry) scan4(); }
+        if (!got) {
+            if (lane == 0) hcmd[0] = kQCmdExact;
+            lds_barrier();
+            lds_barrier();
+            const int wc = uni(cntw[0]);
+            wk = lane < wc ? winK[lane] : ~0ull;
+            wn = lane < wc ? winN[lane] : INT_MAX;
+            wcnt = wc;
+            thK = uni64(((u64)(unsigned)th65[0] << 32) | (unsigned)th65[1]);
+            thN = uni(th65[2]);
         }
+        BLANCE_WAVE_SYNC();                          // (the scratch is rowTag's again after this)
+        rb_wcnt = wcnt;
         n_rebuild++;
 #ifdef BLANCE_PHASE_PROF
         rb_cycles += clock64() - rb_t0;
@@ -905,7 +1020,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 }
                 if (!lean_done) {
                     // the window ran dry (few entries, none of them a candidate): rebuild it once and look again
-                    if (wcnt < 32 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
+                    if (wcnt < 32 && wcnt * 4 < rb_wcnt * 3 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
                     BLANCE_QWHY(3);
                     break;
                 }
@@ -955,7 +1070,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 if (promoted) promotions(false);
                 const int rlastn = k == 2 ? r2n : r1n;
                 if (rlastn == INT_MAX || !qless(rlast, rlastn, thK, thN)) {                  // beyond the window's reach
-                    if (wcnt < 56 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
+                    if (wcnt < 56 && wcnt * 8 < rb_wcnt * 7 && thN != INT_MAX && !retried) { rebuild(); retried = true; n_bulk -= f - cur; continue; }
                     BLANCE_QWHY(5);
                     break;
                 }
@@ -1128,21 +1243,26 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                         hcmd[0] = kQCmdDense; hcmd[1] = f; hcmd[2] = k;
                         hcmd[3] = qown[0]; hcmd[4] = qown[1]; hcmd[5] = qh[0]; hcmd[6] = qh[1];
                         hcmd[7] = (NP > 0 && have_bits) ? 1 : 0; hcmd[8] = rowf;
+                        if (NP > 0 && have_bits) {       // no candidates: they count as entries with their bit set (row f is this step's alone)
+#pragma unroll
+                            for (int j = 0; j < KM; j++) if (qown[j] >= 0 && qown[j] < NXp) bitsL[f * BW + (qown[j] >> 5)] |= 1u << (qown[j] & 31);
+#pragma unroll
+                            for (int j = 0; j < KH; j++) if (qh[j] >= 0 && qh[j] < NXp) bitsL[f * BW + (qh[j] >> 5)] |= 1u << (qh[j] & 31);
+                        }
                         // the step's k-th pick is no worse than the k-th best of its own nodes
                         u64 U = ~0ull;
                         if (nown_f >= k) { U = qK[0]; if (k > 1 && qK[1] > U) U = qK[1]; }
                         hcmd[10] = (int)(unsigned)(U >> 32); hcmd[11] = (int)(unsigned)U;
                     }
                     BLANCE_QWAIT_BUMPS();            // (rows bumped by this wave are read by the others)
-                    if (NW > 1) lds_barrier(); else BLANCE_WAVE_SYNC();
-                    dense_part();
+                    lds_barrier();                   // (1) posted
                     PH(13);
-                    if (NW > 1) lds_barrier(); else BLANCE_WAVE_SYNC();
+                    lds_barrier();                   // (2) the workers' k best each are in
                     PH(15);
                     {
                         u64 ek = ~0ull;
                         int en = INT_MAX;
-                        if (lane < NW * k) {
+                        if (lane < (NW - 1) * k) {
                             const int* r = hres + ((lane / k) * KM + (lane % k)) * kQResWords;
                             ek = ((u64)(unsigned)r[0] << 32) | (unsigned)r[1];
                             en = r[2];
@@ -1248,7 +1368,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 if (((n_out == k && below) || thN == INT_MAX) && !hopeless) break;
                 // the window does not reach far enough.  Run dry (few entries): rebuild it around the current keys and
                 // look again; full, or rebuilt already: its entries are held back by their matrix entries -- every node then
-                if (attempt == 0 && wcnt < 56) rebuild();
+                if (attempt == 0 && wcnt < 56 && wcnt * 8 < rb_wcnt * 7) rebuild();
                 else attempt = 1;
             }
             PH(6);
@@ -1360,10 +1480,8 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         printf("[queue rebuilds] %.0f kcycles, %lld column scans of lane 0 (first scans: %.0f kcycles)\n", (double)rb_cycles / 1e3, rb_scans, (double)rb_scan_cycles / 1e3);
     }
 #endif
-    if (NW > 1) {                                    // the helper waves leave
-        if (lane == 0) hcmd[0] = kQCmdExit;
-        lds_barrier();
-    }
+    if (lane == 0) hcmd[0] = kQCmdExit;              // the helper waves leave
+    lds_barrier();
     if (lane == 0) {
         q.stop[0] = stop_pos;
         q.stop[1] = stop_why;
@@ -1380,7 +1498,8 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
 // dynamic LDS of k_pass_queue for a pass
 static inline size_t queue_lds_bytes(int NX, int RW) {
     const size_t NXp = (size_t)((NX + 63) / 64) * 64, BW = ((NXp >> 5) + 3) & ~(size_t)3;
-    return NXp * (8 + 4 + 4 + 4 + 1 + 1 + 1 + 2) + 64 + sizeof(double) * (kLpTab + kFfTab) + sizeof(int32_t) * (size_t)(64 * RW) +
+    const size_t RT = NXp + 64 > (size_t)kQScratch ? NXp + 64 : (size_t)kQScratch;      // rowTag / the cooperative rebuild's scratch
+    return NXp * (8 + 4 + 4 + 4 + 1 + 1 + 2) + RT + sizeof(double) * (kLpTab + kFfTab) + sizeof(int32_t) * (size_t)(64 * RW) +
            sizeof(int32_t) * 64 * 3 + sizeof(int32_t) * 64 * BW + 64 + sizeof(int32_t) * (kQCmdWords + kQueueWaves * 2 * kQResWords);
 }
 

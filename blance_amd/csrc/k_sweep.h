@@ -20,6 +20,80 @@ struct DevProblem {   // device pointers + sizes shared by the elementwise kerne
     uint8_t* in_prev; uint8_t* never_equal;
 };
 
+// ---- blance_upload: the O(P) part of blance_validate and the sizes the host needs, computed where the arrays have just
+// landed (round 5: the host's loops over two million offsets and a million partitions were half of an upload).
+// Result block: [0] error bits, [1] longest list (L), [2] partitions not in prevMap, [3] INT_MAX - (4 i + check) of the first
+// list i whose shape is wrong (0: none); 64-bit words from byte 16:
+// [2] result capacity (sum of max(k, len)), [3] sum of |weights|, [4] |weight| * prev entries.
+constexpr int kVErrMonotone = 1, kVErrKind = 2, kVErrLong = 4, kVErrOrder = 8, kVErrAssignId = 16, kVErrPrevId = 32;
+struct ValidateParams {
+    int32_t P, M, weights_nil;
+    int32_t k[kMaxStates];
+    const int32_t* a_off; const uint8_t* a_kind;
+    const int32_t* p_off; const uint8_t* p_kind;
+    const int32_t* part_order; const int32_t* part_weight; const uint8_t* part_has_weight; const uint8_t* part_in_prev;
+    uint32_t* seen;                // [(P + 31) / 32] zeroed: part_order as a permutation
+    int32_t* res;
+};
+__global__ void k_validate_parts(ValidateParams v) {
+    const long long PM = (long long)v.P * v.M;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int err = 0, L = 0, fresh = 0, first = 0;
+    unsigned long long cap = 0, sumw = 0, aprev = 0;
+    if (idx < PM) {
+        const int a = v.a_off[idx + 1] - v.a_off[idx], b = v.p_off[idx + 1] - v.p_off[idx];
+        // the host's loop reports the first (list, check) that fails: INT_MAX - (4 idx + check), largest wins
+        if (a > 0xffff || b > 0xffff) { err |= kVErrLong; first = INT_MAX - (int)(4 * idx + 2); }
+        if (v.a_kind[idx] > kListSet || v.p_kind[idx] > kListSet) { err |= kVErrKind; first = INT_MAX - (int)(4 * idx + 1); }
+        if (a < 0 || b < 0) { err |= kVErrMonotone; first = INT_MAX - (int)(4 * idx); }
+        L = a > b ? a : b;
+        const int k = v.k[idx % v.M];
+        if (a >= 0) cap = (unsigned long long)(a > k ? a : k);
+    }
+    if (idx < v.P) {
+        const int p = (int)idx;
+        const int o = v.part_order[p];
+        if (o < 0 || o >= v.P) err |= kVErrOrder;
+        else if (atomicOr((int*)v.seen + (o >> 5), (int)(1u << (o & 31))) & (int)(1u << (o & 31))) err |= kVErrOrder;
+        long long w = (!v.weights_nil && v.part_has_weight[p]) ? (long long)v.part_weight[p] : 1;
+        if (w < 0) w = -w;
+        sumw = (unsigned long long)w;
+        if (v.part_in_prev[p]) {
+            long long n = (long long)v.p_off[(long long)(p + 1) * v.M] - v.p_off[(long long)p * v.M];
+            if (n < 0) n = 0;                       // (reported as not monotone)
+            aprev = (unsigned long long)(w * n);
+        } else fresh = 1;
+    }
+    // wave totals, then one atomic per wave and word
+    for (int o = 32; o; o >>= 1) {
+        err |= __shfl_xor(err, o, 64);
+        const int f2 = __shfl_xor(first, o, 64);
+        first = f2 > first ? f2 : first;
+        const int l2 = __shfl_xor(L, o, 64);
+        L = l2 > L ? l2 : L;
+        fresh += __shfl_xor(fresh, o, 64);
+        cap += ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(cap >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)cap, o, 64);
+        sumw += ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(sumw >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)sumw, o, 64);
+        aprev += ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(aprev >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)aprev, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* r64 = (unsigned long long*)(v.res + 4);
+        if (err) atomicOr(v.res, err);
+        if (first) atomicMax(v.res + 3, first);
+        if (L) atomicMax(v.res + 1, L);
+        if (fresh) atomicAdd(v.res + 2, fresh);
+        if (cap) atomicAdd(r64, cap);
+        if (sumw) atomicAdd(r64 + 1, sumw);
+        if (aprev) atomicAdd(r64 + 2, aprev);
+    }
+}
+// node ids of a CSR's payload in [0, NX)
+__global__ void k_validate_ids(long long n, int NX, const int32_t* ids, int bit, int32_t* res) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = i < n && (ids[i] < 0 || ids[i] >= NX);
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(res, bit);
+}
+
 // nextPartitions = copy of partitionsToAssign minus nodesToRemove (plan.go:83-88)
 __global__ void k_live_init(DevProblem d, const int32_t* a_off, const int32_t* a_nodes,
                             const uint8_t* a_kind, const int32_t* p_off, const int32_t* p_nodes,

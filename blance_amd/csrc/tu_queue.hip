@@ -15,9 +15,8 @@ bool launch_pass_queue(hipStream_t stream, PassParams q) {
     const size_t lds = queue_lds_bytes(q.NX, q.RW);
     if (lds > 160 * 1024) return false;
     auto kern = k_pass_queue<2>;
-    // one workgroup: the walking wave and its helper waves (q.spec & 64: test knob, the walking wave alone)
-    const int waves = (q.spec & 64) ? 1 : kQueueWaves;
-    BLANCE_LAUNCH(kern, 1, 64 * waves, lds, stream, q);
+    // one workgroup: the walking wave and its helper waves
+    BLANCE_LAUNCH(kern, 1, 64 * kQueueWaves, lds, stream, q);
     return true;
 }
 

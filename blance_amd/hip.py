@@ -18,7 +18,7 @@ EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", 
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
            "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get",
            "blance_comm_unique_id", "blance_comm_init_rccl", "blance_comm_set", "blance_comm_stats",
-           "blance_is_emulated"]
+           "blance_is_emulated", "blance_host_alloc", "blance_host_free"]
 
 _libs = {}
 
@@ -70,10 +70,50 @@ def load_library(path=None):
     lib.blance_comm_stats.restype = C.c_int
     lib.blance_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.blance_is_emulated.restype = C.c_int
+    lib.blance_host_alloc.restype = C.c_void_p
+    lib.blance_host_alloc.argtypes = [C.c_size_t]
+    lib.blance_host_free.restype = None
+    lib.blance_host_free.argtypes = [C.c_void_p]
     if lib.blance_abi_version() != abi.ABI_VERSION:
         raise ImportError("ABI version mismatch")
     _libs[path] = lib
     return lib
+
+
+class HostArena:
+    """Page-locked host arrays from blance_host_alloc (include/blance_hip.h, ABI 5): numpy views the device copies from / to
+    by DMA where they lie.  The blocks go back to the library when the arena is closed or collected."""
+
+    def __init__(self, lib_path=None):
+        self.lib = load_library(lib_path)
+        self._blocks = []
+
+    def empty(self, n, dtype):
+        import numpy as np
+        dt = np.dtype(dtype)
+        nbytes = max(int(n), 1) * dt.itemsize
+        p = self.lib.blance_host_alloc(nbytes)
+        if not p:
+            raise MemoryError("blance_host_alloc(%d) failed" % nbytes)
+        self._blocks.append(p)
+        buf = (C.c_char * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dt, count=int(n))
+
+    def copy_of(self, arr):
+        a = self.empty(arr.size, arr.dtype)
+        a[...] = arr.reshape(-1)
+        return a
+
+    def close(self):
+        for p in self._blocks:
+            self.lib.blance_host_free(p)
+        self._blocks = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Planner:
@@ -98,10 +138,10 @@ class Planner:
         # 512 = flat passes with k <= 2 never on k_pass_queue (k_pass_tree / k_pass_seq take them, as before round 4);
         # 1024 = k_pass_queue without its lean walk (every step that does not stay through its general code)
         # 2048 = ... and every general step of it scoring every node; 4096 = its lean walk as compiled C++ only (the device
-        # build walks the plain k = 2 steps in hand-written assembly, k_queue_walk.h); 8192 = k_pass_queue as ONE wave, without
-        # the helper waves that share the dense step (round 5)
+        # build walks the plain k = 2 steps in hand-written assembly, k_queue_walk.h); 8192 = its window always rebuilt by the
+        # exact selection (one helper wave), never by the helper waves' striped form
         qbits = {True: 0, "on": 0, False: 512, "off": 512, "general": 1024, "dense": 1024 | 2048, "lean-cpp": 4096,
-                 "one-wave": 8192, "dense-one-wave": 1024 | 2048 | 8192}[queue]
+                 "exact-rebuild": 8192}[queue]
         opt.reserved[2] = qbits | (0 if periodic else 256) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
@@ -224,7 +264,8 @@ class Planner:
         self._check(self.lib.blance_plan_resident(self._h, C.byref(r)))
         return r
 
-    def download(self):
-        res = abi.FlatResult(self._fp)
+    def download(self, arena=None):
+        """arena: a HostArena -- the result's arrays in page-locked memory (the device writes them by DMA)."""
+        res = abi.FlatResult(self._fp, arena)
         self._check(self.lib.blance_download(self._h, C.byref(res.struct)))
         return res

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define BLANCE_ABI_VERSION 4
+#define BLANCE_ABI_VERSION 5
 
 /* status codes */
 #define BLANCE_OK                0
@@ -217,6 +217,17 @@ int blance_plan(blance_ctx* ctx, const blance_problem* pb, blance_result* res);
 int blance_upload(blance_ctx* ctx, const blance_problem* pb);
 int blance_plan_resident(blance_ctx* ctx, blance_result* res /* timings+stats only */);
 int blance_download(blance_ctx* ctx, blance_result* res);
+
+/* ---- host buffers the device reaches at link speed (ABI 5) ------------------------------------
+ * the caller owns every buffer.  blance_host_alloc() hands out page-locked host
+ * memory that stays the caller's (free it with blance_host_free(); freed blocks are kept for the
+ * next allocation, pinning costs milliseconds).  The arrays of a blance_problem / blance_result
+ * that lie in such memory -- or in memory the caller registered with the HIP runtime itself -- are
+ * copied by DMA where they lie; every other (pageable) array passes through a page-locked buffer
+ * of the context, moved by a few host threads.  Either way nothing of the caller's is touched
+ * after the call returns.  NULL when the runtime cannot provide the memory (use malloc then). */
+void* blance_host_alloc(size_t bytes);
+void blance_host_free(void* p);
 
 /* ---- CalcPartitionMoves for every partition at once (moves.go:41-136) ---------
  * The planner's consumer (orchestrate.go:273-287 calls it per partition): the

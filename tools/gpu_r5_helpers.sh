@@ -10,7 +10,7 @@ sys.path.insert(0, os.getcwd())
 from blance_amd import hip, synth
 want = json.load(open("tests/golden/config3_general_regime.json"))["named_weighted"]["digest"]
 fp = synth.config3_named_weighted_flat(1 << 20, 4096)
-for mode in (True, "one-wave"):
+for mode in (True, "exact-rebuild"):
     pl = hip.Planner(queue=mode)
     r = pl.plan(fp)
     print("regime (b) queue=%s: sweeps %d device %.1f ms digest ok %s" % (mode, r.iterations, r.struct.device_ms, r.digest() == want), flush=True)
