@@ -86,7 +86,7 @@ def cpu_baseline(parts, nodes, cfg, full=False):
     else:
         info["sample"] = ("oracle/blance_oracle.c, %s (%d sweeps) on %d partitions x %d nodes (%s of the partitions, same "
                           "nodes/hierarchy/model; per-step cost is O(nodes), so assignments/s carries over: EXTRAPOLATED "
-                          "from the sample -- bench.py --cpu-full runs all of them, %s), %.1f s"
+                          "from the sample -- bench.py without --cpu-sample runs all of them, %s), %.1f s"
                           % (what, res.iterations, sample_parts, nodes, frac,
                              {5: "8 minutes", 3: "about 2 minutes"}.get(cfg, "under a second"), dt))
     # config 2 in full (65,536 x 256, not sampled), same port, same core
@@ -155,7 +155,7 @@ def live_pmc(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(work, counter), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "1", "--warmup", "0",
-                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc"]
+                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc", "--no-other-configs"]
             if args.parts:
                 cmd += ["--parts", str(args.parts)]
             if args.nodes:
@@ -230,6 +230,62 @@ def general_regime(pl, fp3, res3, steps):
     return out
 
 
+def other_configs(pl, steps):
+    """BASELINE.json's other single-GPU configurations under the same clock as the headline: config 2 in full
+    (65,536 x 256) and config 5 at its named size -- the initial plan over the old nodes, then the rebalance after a tenth of
+    the nodes left and a tenth joined (the configuration BASELINE names for 8 GPUs: its flat passes are ONE dependency chain
+    per pass, so one GPU plans it).  Each: uploaded, timed resident calls, digest against the CPU oracle's
+    (tests/golden/config_digests.json), and the whole call against the HBM roofline by SURVEY.md 8(d)'s dense-scan bytes."""
+    from blance_amd import synth
+    with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+        gold = json.load(f)
+    out = []
+
+    def one(label, cfg, fp, n_steps, warm, want):
+        pl.upload(fp)
+        for _ in range(warm):
+            pl.plan_resident()
+        t0 = time.perf_counter()
+        dev = pm = fm = 0.0
+        r = None
+        for _ in range(n_steps):
+            r = pl.plan_resident()
+            dev += r.device_ms
+            pm += r.pass_kernel_ms
+            fm += r.flat_pass_ms
+        dt = (time.perf_counter() - t0) / n_steps
+        res = pl.download()
+        digest = res.digest()
+        a = synth.assignments(fp)
+        dense = synth.algorithmic_bytes_per_sweep(fp) * r.iterations
+        gbps = dense / (dev / n_steps * 1e-3) / 1e9
+        out.append({"config": cfg, "workload": label, "partitions": fp.n_parts, "nodes": fp.n_nodes, "steps": n_steps, "warmup": warm,
+                    "ms_per_step": dt * 1e3, "device_ms_per_step": dev / n_steps, "value": a / dt, "unit": "assignments/s",
+                    "sweeps_per_call": r.iterations, "converged": bool(r.converged),
+                    "pass_kernel_ms_per_step": pm / n_steps, "flat_pass_ms_per_step": fm / n_steps,
+                    "steps_bulk": int(r.steps_batched), "steps_one_by_one": int(r.steps_sequential),
+                    "roofline": {"bound": "hbm", "model": "SURVEY.md 8(d): the reference's dense scan, N x 16 B + 40 B per step and sweep, whole call",
+                                 "bytes_per_call": float(dense), "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS},
+                    "result_sha256": digest, "matches_oracle_digest": (want["digest"] == digest and want["iterations"] == r.iterations) if want else None})
+        return res
+    try:
+        one("BASELINE.json config 2: 65536 partitions x 256 nodes, primary+1 replica, flat", 2, synth.config_flat(2), max(steps, 5), 1, gold.get("config2"))
+    except Exception as e:
+        out.append({"config": 2, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    try:
+        c5 = gold.get("config5") or {}
+        fp1 = synth.config5_initial(1 << 20, 4096)
+        r1 = one("BASELINE.json config 5, setup: the initial plan of 1048576 Zipf-weighted partitions over the 3686 old nodes (node "
+                 "weights, stickiness; flat)", 5, fp1, 1, 0, c5.get("initial"))
+        fp2 = synth.config5_rebalance(fp1, r1, 1 << 20, 4096)
+        del fp1
+        one("BASELINE.json config 5: the rebalance after a tenth of the nodes left and a tenth joined (prevMap = the initial plan)",
+            5, fp2, 1, 0, c5.get("rebalance"))
+    except Exception as e:
+        out.append({"config": 5, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks."""
     port = 29400 + os.getpid() % 500
@@ -253,8 +309,10 @@ def main():
                     "k_period.h, the default since round 4): every step walked; not the headline")
     ap.add_argument("--no-extra", action="store_true", help="skip the general_regime block (two more workloads of config 3's size)")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
-    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on ALL partitions of the configuration (config 3: about two minutes) "
-                    "instead of the quarter sample that is extrapolated")
+    ap.add_argument("--cpu-sample", action="store_true", help="cpu_baseline on a quarter of the partitions, extrapolated (14 s) -- the default "
+                    "times the oracle on ALL partitions of config 3 (about a minute on the GPU box's EPYC, two here)")
+    ap.add_argument("--cpu-full", action="store_true", help="(the default since round 5; kept so that old command lines still parse)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (BASELINE configs 2 and 5 timed with digests, about 40 s)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -279,6 +337,7 @@ def main():
         world = dist.get_world_size()               # what RCCL's communicator reports
 
     from blance_amd import dist_util, hip, synth
+    rot = 0
     if rehearsal:
         pl = hip.Planner(lib_path=rehearsal, chain_min_parts=8, periodic=not args.no_periodic)
     else:
@@ -288,7 +347,11 @@ def main():
         fp = synth.config5_rebalance(fp1, pl.plan(fp1), args.parts or 1 << 20, args.nodes or 4096)
         del fp1
     else:
-        fp = synth.config_flat(args.config, P=args.parts or None, N=args.nodes or None)
+        # N > 1: the replicas plan DIFFERENT instances of the shape (a node serving several indexes): rank r's nodesAll
+        # starts 512 r names further on -- other per-node hierarchy tables on every rank, the same plan as ids (zones stay
+        # aligned blocks), so every rank's digest is still the oracle's
+        rot = (512 * rank) % (args.nodes or 4096) if (world > 1 and args.config == 3) else 0
+        fp = synth.config_flat(args.config, P=args.parts or None, N=args.nodes or None, **({"rotate": rot} if rot else {}))
     P, N = fp.n_parts, fp.n_nodes
     t0 = time.perf_counter()
     pl.upload(fp)
@@ -305,7 +368,8 @@ def main():
             pl.plan_resident()
         barrier()
         t0 = time.perf_counter()
-        acc = {"pass_ms": 0.0, "pass_launches": 0, "flat_ms": 0.0, "flat_passes": 0, "device_ms": 0.0, "blank_ms": 0.0, "blank_launches": 0}
+        acc = {"pass_ms": 0.0, "pass_launches": 0, "flat_ms": 0.0, "flat_passes": 0, "device_ms": 0.0, "blank_ms": 0.0, "blank_launches": 0,
+               "stay_ms": 0.0, "stay_launches": 0}
         r = None
         for _ in range(steps):
             r = pl.plan_resident()                  # returns after the device finished the call
@@ -315,6 +379,8 @@ def main():
             acc["flat_passes"] += r.flat_passes
             acc["blank_ms"] += r.blank_pass_ms
             acc["blank_launches"] += r.blank_pass_launches
+            acc["stay_ms"] += r.stay_pass_ms
+            acc["stay_launches"] += r.stay_pass_launches
             acc["device_ms"] += r.device_ms
         barrier()
         dt = time.perf_counter() - t0
@@ -331,6 +397,52 @@ def main():
     res = pl.download()                             # (every rank: the sharded leg compares with it)
     download_s = time.perf_counter() - t1
     digest_all = res.digest()
+    replicas_ok = None
+    if dist is not None:
+        box_ = [None] * world
+        dist.all_gather_object(box_, digest_all)
+        replicas_ok = len(set(box_)) == 1
+    # ---- what the boundary costs in steady state (reported beside the resident number, never as `value`):
+    # the same problem uploaded again and the result downloaded again into buffers that exist -- pageable arrays (staged
+    # through the context's page-locked buffer by a few threads) and arrays from blance_host_alloc (DMA where they lie)
+    xfer = None
+    if rank == 0 and not rehearsal:
+        try:
+            def again(f, arena):
+                r_ = None
+                ups, downs = [], []
+                for _ in range(3):
+                    t_ = time.perf_counter()
+                    pl.upload(f)
+                    ups.append(time.perf_counter() - t_)
+                    pl.plan_resident()
+                    if r_ is None:
+                        r_ = pl.download(arena)
+                    t_ = time.perf_counter()
+                    pl.download(arena, into=r_)
+                    downs.append(time.perf_counter() - t_)
+                return min(ups[1:]), min(downs[1:]), r_.digest()
+            up_pg, down_pg, d_pg = again(fp, None)
+            arena = hip.HostArena()
+            import copy
+            fpp = copy.copy(fp)
+            fpp.arrays = dict(fp.arrays)
+            fpp._struct = None
+            fpp.pin(arena)
+            up_pin, down_pin, d_pin = again(fpp, arena)
+            nb = sum(a.nbytes for a in fp.arrays.values())
+            ob = res.out_off.nbytes + res.out_nodes.nbytes + res.out_kind.nbytes
+            xfer = {"upload_bytes": nb, "download_bytes": ob,
+                    "pageable": {"upload_s": up_pg, "download_s": down_pg, "what": "numpy arrays: staged through the context's page-locked buffer"},
+                    "page_locked": {"upload_s": up_pin, "download_s": down_pin, "what": "arrays from blance_host_alloc: DMA where they lie",
+                                    "upload_GBps": nb / up_pin / 1e9, "download_GBps": ob / down_pin / 1e9},
+                    "same_digest_both_ways": d_pg == d_pin == digest_all,
+                    "upload_includes": "the O(P) checks of blance_validate on the device and every table the planner derives at upload"}
+            pl.upload(fp)                               # (the legs below plan the resident problem again)
+            pl.plan_resident()
+            arena.close()
+        except Exception as e:
+            xfer = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     out = None
     if rank == 0:
         digest = digest_all
@@ -416,10 +528,13 @@ def main():
                                        "hierarchy region; with k_period.h two periods walked and the periodic stretch copied)",
                                        ("k_pass_chain_planes", "k_pass_chain_blank", "k_period"), K_CW + 1 + kmax, acc["blank_ms"],
                                        acc["blank_launches"], zones, dense_pass))
-            kernels.append(kernel_line("k_pass_chain / k_stay_by_top (replica passes of the later sweeps: verified stays -- one wave64 per "
-                                       "hierarchy region, or, in a converged sweep, one thread per top priority node incl. its grouping)",
-                                       ("k_pass_chainI", "k_stay_by_top"), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"],
-                                       acc["pass_launches"] - acc["blank_launches"], zones, dense_pass))
+            kernels.append(kernel_line("k_pass_chain<2,2,false> (the replica pass of a later sweep that still moves steps: one wave64 per "
+                                       "hierarchy region walks its steps in order, verified stays 64 at a time)",
+                                       ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"] - acc["stay_ms"],
+                                       acc["pass_launches"] - acc["blank_launches"] - acc["stay_launches"], zones, dense_pass))
+            kernels.append(kernel_line("k_stay_by_top (the replica pass of a converged sweep: every step verified as a stay by one thread per "
+                                       "top priority node; the time includes the counting sort that groups the steps by top node)",
+                                       ("k_stay_by_top",), K_CW + 1 + kmax, acc["stay_ms"], acc["stay_launches"], None, dense_pass))
         kernels.append(kernel_line("flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)",
                                    ("k_flat", "k_fresh", "k_sort"), RW + 2, acc["flat_ms"], acc["flat_passes"], None, dense_flat))
         kernels = [k for k in kernels if k]
@@ -448,6 +563,9 @@ def main():
                                       .get(args.config, "primary+1 replica, flat")),
                        "partitions": P, "nodes": N, "assignments_per_call": assignments,
                        "sweeps_per_call": iterations, "parallelism": "replicas x%d" % world,
+                       **({"replicas": "every rank plans its own instance of the shape: rank r's nodesAll starts 512 r names further on "
+                                       "(other per-node hierarchy tables, the same plan as ids); every rank's digest checked against the oracle's: %s"
+                                       % replicas_ok} if world > 1 and args.config == 3 else {}),
                        "steps_bulk": int(batched), "steps_one_by_one": int(sequential),
                        "headline": bool(args.config == 3 and headline_shape and not args.no_periodic),
                        **({"not_default": "--no-periodic: the all-blank chain pass walks every step (the default copies the periodic stretch, k_period.h)"}
@@ -466,8 +584,13 @@ def main():
             "roofline_per_kernel": kernels,
             "device_ms_per_step": acc["device_ms"] / args.steps,
             "pass_kernel_ms_per_step": acc["pass_ms"] / args.steps, "flat_pass_ms_per_step": acc["flat_ms"] / args.steps,
-            "transfers": {"upload_s": upload_s, "download_s": download_s,
-                          "value_incl_transfers": assignments / (dt / args.steps + upload_s + download_s)},
+            "transfers": dict(xfer or {}, **{
+                "first_upload_s": upload_s, "first_download_s": download_s,
+                "first_call_note": "the first upload allocates every device buffer, the first download the result arrays: one-time costs",
+                "value_incl_transfers": (assignments / (dt / args.steps + xfer["page_locked"]["upload_s"] + xfer["page_locked"]["download_s"])
+                                         if xfer and "page_locked" in xfer else assignments / (dt / args.steps + upload_s + download_s)),
+                "value_incl_transfers_pageable": (assignments / (dt / args.steps + xfer["pageable"]["upload_s"] + xfer["pageable"]["download_s"])
+                                                  if xfer and "pageable" in xfer else None)}),
             "result_sha256": digest,
         }
         ref = os.path.join(ROOT, "tests", "golden", "config_digests.json")
@@ -483,8 +606,11 @@ def main():
                 out["sharded_on_one_gpu"] = sharded_on_one_gpu(fp, digest, local_rank, dt / args.steps)
         if world == 1 and args.config == 3 and not args.no_extra:
             out["general_regime"] = general_regime(pl, fp, res, max(1, min(args.steps, 5)))
+        if world == 1 and args.config == 3 and headline_shape and not args.no_other_configs and not rehearsal:
+            out["other_configs"] = other_configs(pl, max(1, min(args.steps, 5)))
+            pl.upload(fp)                               # (what follows plans the headline problem)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config, full=args.cpu_full)
+            out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config, full=not args.cpu_sample)
         if world == 1 and not args.no_extra and not rehearsal:
             out["host_end_to_end"] = host_end_to_end(args.config)
     # ---- one plan over all ranks (config 4).  The line of the replicas is ready before this starts: RCCL is bound at
@@ -512,9 +638,13 @@ def main():
                     pl.comm_set_callback(rank, world, ar, ag)
                 else:
                     dist_util.shard_plan_rccl(pl, dist)
+                if rot:                                 # one plan on all ranks: every rank holds the SAME problem
+                    pl.upload(synth.config_flat(args.config, P=args.parts or None, N=args.nodes or None))
                 calls0, words0 = pl.comm_stats()
+                cms0 = 0.0 if rehearsal else pl.comm_time_ms()
                 sdt, sacc, sr = timed(args.steps, args.warmup)
                 calls1, words1 = pl.comm_stats()
+                cms1 = 0.0 if rehearsal else pl.comm_time_ms()
                 n_plans = args.steps + args.warmup
                 sdig = pl.download().digest()
                 box = [None] * world
@@ -524,6 +654,10 @@ def main():
                            "comm_calls_per_plan": (calls1 - calls0) / float(n_plans),
                            "comm_bytes_per_plan": 4.0 * (words1 - words0) / n_plans,
                            "rccl_world_size": world, "ms_per_step": sdt * 1e3 / args.steps,
+                           "comm_device_ms_per_plan": (cms1 - cms0) / n_plans,
+                           "us_per_collective": ((cms1 - cms0) * 1e3 / (calls1 - calls0)) if calls1 > calls0 else None,
+                           "comm_timing": "hipEvents on either side of every ncclAllReduce / ncclAllGather on the planner's stream, rank 0"
+                                          if not rehearsal else "not measured in the rehearsal (gloo on the host)",
                            "value": assignments * args.steps / sdt, "unit": "assignments/s", "scaling": "strong",
                            "device_ms_per_step": sacc["device_ms"] / args.steps,
                            "same_digest_on_every_rank": len(set(box)) == 1,

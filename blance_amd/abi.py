@@ -61,6 +61,7 @@ class Result(C.Structure):
         ("pass_kernel_ms", C.c_double), ("pass_kernel_launches", C.c_int64),
         ("flat_pass_ms", C.c_double), ("flat_passes", C.c_int64),
         ("blank_pass_ms", C.c_double), ("blank_pass_launches", C.c_int64),
+        ("stay_pass_ms", C.c_double), ("stay_pass_launches", C.c_int64),
     ]
 
 

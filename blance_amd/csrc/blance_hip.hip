@@ -203,6 +203,9 @@ struct blance_ctx {
     DevBuf vres, vseen;             // blance_upload: the device's part of the validation (k_validate_parts)
     DevBuf mv[11];                  // blance_calc_moves: inputs, per-partition slices, offsets, compacted outputs (kept between calls)
     int64_t comm_calls = 0, comm_bytes = 0;
+    std::vector<hipEvent_t> comm_events;     // begin / end pairs around the collectives of the current plan (RCCL path)
+    size_t comm_events_used = 0;
+    double comm_ms = 0.0;                    // device time between those pairs, all plans so far
 
     // host copy of the small parts of the problem
     blance_problem h{};
@@ -263,8 +266,8 @@ struct blance_ctx {
     double device_ms = 0.0, pass_ms = 0.0;
     std::vector<hipEvent_t> pass_events;     // begin/end pairs around every pass kernel
     std::vector<int> pass_kind;              // 0 = one pass kernel, 1 = flat bulk driver
-    double flat_ms = 0.0, blank_ms = 0.0;
-    int64_t flat_passes = 0, blank_launches = 0;
+    double flat_ms = 0.0, blank_ms = 0.0, stay_ms = 0.0;
+    int64_t flat_passes = 0, blank_launches = 0, stay_launches = 0;
 
     void free_all() {
         DevBuf* all[] = {&node_removed, &node_added, &node_weight, &node_has_weight, &alive, &zeros_nx,
@@ -498,6 +501,7 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     comm_release(c);
     c->free_all();
     for (hipEvent_t e : c->pass_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->comm_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1326,6 +1330,13 @@ extern "C" int blance_comm_stats(blance_ctx* c, int64_t* calls, int64_t* words) 
     return BLANCE_OK;
 }
 
+extern "C" int blance_comm_time_ms(blance_ctx* c, double* ms) {
+    if (!c || !ms) return fail(BLANCE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    *ms = c->comm_ms;
+    return BLANCE_OK;
+}
+
 static void comm_release(blance_ctx* c) {
 #ifndef BLANCE_SIMT_EMU
     if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
@@ -1342,6 +1353,25 @@ static void comm_abort(blance_ctx* c) {
     (void)c;
 }
 
+// the device time a collective takes on the planner's stream: an event on either side (summed up when the plan ends)
+static int comm_mark(blance_ctx* c) {
+    if (c->comm_events_used == c->comm_events.size()) {
+        hipEvent_t ev;
+        HIPTRY(hipEventCreate(&ev));
+        c->comm_events.push_back(ev);
+    }
+    HIPTRY(hipEventRecord(c->comm_events[c->comm_events_used++], c->stream));
+    return 0;
+}
+static void comm_sum_up(blance_ctx* c) {            // (after the stream has been synchronised)
+    for (size_t i = 0; i + 1 < c->comm_events_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->comm_events[i], c->comm_events[i + 1]) == hipSuccess) c->comm_ms += ms;
+        else (void)hipGetLastError();
+    }
+    c->comm_events_used = 0;
+}
+
 // in-place int32 sum over the ranks, ordered with the kernels of the planner's stream
 static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
     if (c->comm.n_ranks <= 1 || n <= 0) return 0;
@@ -1354,8 +1384,10 @@ static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
     }
 #ifndef BLANCE_SIMT_EMU
     if (!c->rccl_comm) return fail(BLANCE_ERR_COMM, "no communicator");
+    if (comm_mark(c)) return BLANCE_ERR_DEVICE;
     int e = g_rccl.AllReduce(buf, buf, (size_t)n, kNcclInt32, kNcclSum, c->rccl_comm, c->stream);
     if (e) return fail(BLANCE_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    if (comm_mark(c)) return BLANCE_ERR_DEVICE;
     return 0;
 #else
     return fail(BLANCE_ERR_COMM, "no communicator");
@@ -1375,8 +1407,10 @@ static int comm_allgather(blance_ctx* c, int32_t* buf, int64_t per_rank) {
     }
 #ifndef BLANCE_SIMT_EMU
     if (!c->rccl_comm) return fail(BLANCE_ERR_COMM, "no communicator");
+    if (comm_mark(c)) return BLANCE_ERR_DEVICE;
     int e = g_rccl.AllGather(buf + (size_t)c->comm.rank * per_rank, buf, (size_t)per_rank, kNcclInt32, c->rccl_comm, c->stream);
     if (e) return fail(BLANCE_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    if (comm_mark(c)) return BLANCE_ERR_DEVICE;
     return 0;
 #else
     return fail(BLANCE_ERR_COMM, "no communicator");
@@ -1573,7 +1607,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     if (stayed) {
         HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
         c->pass_kind.resize(n_pass + 1);
-        c->pass_kind[n_pass] = 0;
+        c->pass_kind[n_pass] = 3;                      // 3: k_stay_by_top verified the pass
         n_pass++;
         c->last_stays[m] = P;
         if (dump_pass(c, a.it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
@@ -1754,6 +1788,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     DevProblem d = dev_problem(c);
     c->last_stays.assign((size_t)(M > 0 ? M : 1), 0);
     c->queue_launches = c->queue_stops = 0;
+    c->comm_events_used = 0;
 
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 256, sm));
@@ -1931,6 +1966,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         memcpy(&spec, hs + 12, sizeof spec);
         memcpy(qs, hs + 18, sizeof qs);
         HIPTRY(hipEventSynchronize(c->ev1));
+        comm_sum_up(c);
         c->queue_moved = qs[0]; c->queue_exact = qs[1]; c->queue_rebuilds = qs[2]; c->queue_dense = qs[3];
         if (c->trace || getenv("BLANCE_QUEUE_STATS"))
             fprintf(stderr, "[blance] k_pass_queue: %lld launches, %lld stops, %lld moving steps (%lld with matrix reads, %lld scoring every node), %lld window rebuilds\n",
@@ -1941,16 +1977,18 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     }
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    double pass_ms = 0.0, flat_ms = 0.0, blank_ms = 0.0;
-    int n_kernel_pass = 0, n_flat = 0, n_blank = 0;
+    double pass_ms = 0.0, flat_ms = 0.0, blank_ms = 0.0, stay_ms = 0.0;
+    int n_kernel_pass = 0, n_flat = 0, n_blank = 0, n_stay = 0;
     for (int i = 0; i < n_pass; i++) {
         float pm = 0.f;
         HIPTRY(hipEventElapsedTime(&pm, c->pass_events[2 * i], c->pass_events[2 * i + 1]));
         if (c->pass_kind[i] != 1) { pass_ms += pm; n_kernel_pass++; } else { flat_ms += pm; n_flat++; }
         if (c->pass_kind[i] == 2) { blank_ms += pm; n_blank++; }
+        if (c->pass_kind[i] == 3) { stay_ms += pm; n_stay++; }
         if (c->trace)
             fprintf(stderr, "[blance] pass %d (%s): %.3f ms\n", i,
-                    c->pass_kind[i] == 1 ? "flat bulk driver" : c->pass_kind[i] == 2 ? "all-blank chain kernel" : "pass kernel", pm);
+                    c->pass_kind[i] == 1 ? "flat bulk driver" : c->pass_kind[i] == 2 ? "all-blank chain kernel" :
+                    c->pass_kind[i] == 3 ? "k_stay_by_top" : "pass kernel", pm);
     }
     c->pass_ms = pass_ms;
     c->pass_launches = n_kernel_pass;
@@ -1958,6 +1996,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     c->flat_passes = n_flat;
     c->blank_ms = blank_ms;
     c->blank_launches = n_blank;
+    c->stay_ms = stay_ms;
+    c->stay_launches = n_stay;
     c->iterations = iterations;
     c->converged = converged;
     c->device_ms = ms;
@@ -1982,6 +2022,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         res->flat_passes = n_flat;
         res->blank_pass_ms = blank_ms;
         res->blank_pass_launches = n_blank;
+        res->stay_pass_ms = stay_ms;
+        res->stay_pass_launches = n_stay;
     }
     return BLANCE_OK;
 }
@@ -2046,6 +2088,8 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     res->flat_passes = c->flat_passes;
     res->blank_pass_ms = c->blank_ms;
     res->blank_pass_launches = c->blank_launches;
+    res->stay_pass_ms = c->stay_ms;
+    res->stay_pass_launches = c->stay_launches;
     return BLANCE_OK;
 }
 

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     auto dense_part = [&]() {
         const int f = hcmd[1], kk = hcmd[2], o0 = hcmd[3], o1 = hcmd[4], h0 = hcmd[5], h1 = hcmd[6], hb = hcmd[7], rowf = hcmd[8];
         const u64 U = ((u64)(unsigned)hcmd[10] << 32) | (unsigned)hcmd[11];
-        const int NH = NW - 1, hw = wave - 1;        // the workers are waves 1 .. NW - 1
+        const int NH = NW, hw = wave;                // every wave of the workgroup takes a share, the walking wave too
         const int CJ = (G + NH - 1) / NH, ib = hw * CJ, ie = ib + CJ < G ? ib + CJ : G;
         u64 lb[KM];
         int ln[KM];
@@ -1257,12 +1257,13 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                     BLANCE_QWAIT_BUMPS();            // (rows bumped by this wave are read by the others)
                     lds_barrier();                   // (1) posted
                     PH(13);
-                    lds_barrier();                   // (2) the workers' k best each are in
+                    dense_part();                    // (this wave's share)
+                    lds_barrier();                   // (2) every wave's k best are in
                     PH(15);
                     {
                         u64 ek = ~0ull;
                         int en = INT_MAX;
-                        if (lane < (NW - 1) * k) {
+                        if (lane < NW * k) {
                             const int* r = hres + ((lane / k) * KM + (lane % k)) * kQResWords;
                             ek = ((u64)(unsigned)r[0] << 32) | (unsigned)r[1];
                             en = r[2];

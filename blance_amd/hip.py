@@ -18,7 +18,7 @@ EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", 
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
            "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get",
            "blance_comm_unique_id", "blance_comm_init_rccl", "blance_comm_set", "blance_comm_stats",
-           "blance_is_emulated", "blance_host_alloc", "blance_host_free"]
+           "blance_is_emulated", "blance_host_alloc", "blance_host_free", "blance_comm_time_ms"]
 
 _libs = {}
 
@@ -70,6 +70,8 @@ def load_library(path=None):
     lib.blance_comm_stats.restype = C.c_int
     lib.blance_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.blance_is_emulated.restype = C.c_int
+    lib.blance_comm_time_ms.restype = C.c_int
+    lib.blance_comm_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.blance_host_alloc.restype = C.c_void_p
     lib.blance_host_alloc.argtypes = [C.c_size_t]
     lib.blance_host_free.restype = None
@@ -202,6 +204,12 @@ class Planner:
         self._check(self.lib.blance_comm_stats(self._h, C.byref(calls), C.byref(words)))
         return int(calls.value), int(words.value)
 
+    def comm_time_ms(self):
+        """Device ms spent inside RCCL collectives by this context's plans so far."""
+        ms = C.c_double(0.0)
+        self._check(self.lib.blance_comm_time_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def is_emulated(self):
         return bool(self.lib.blance_is_emulated())
 
@@ -210,6 +218,12 @@ class Planner:
 
     def validate(self, fp):
         return self.lib.blance_validate(C.byref(fp.as_struct()))
+
+    def plan_into(self, fp, res):
+        """blance_plan with the caller's result buffers (a FlatResult made for this problem shape) written again."""
+        self._fp = fp
+        self._check(self.lib.blance_plan(self._h, C.byref(fp.as_struct()), C.byref(res.struct)))
+        return res
 
     def plan(self, fp):
         """blance_plan(): host buffers in, host buffers out."""
@@ -264,8 +278,9 @@ class Planner:
         self._check(self.lib.blance_plan_resident(self._h, C.byref(r)))
         return r
 
-    def download(self, arena=None):
-        """arena: a HostArena -- the result's arrays in page-locked memory (the device writes them by DMA)."""
-        res = abi.FlatResult(self._fp, arena)
+    def download(self, arena=None, into=None):
+        """arena: a HostArena -- the result's arrays in page-locked memory (the device writes them by DMA); into: a FlatResult
+        of an earlier download of the same problem shape, written again (no allocation)."""
+        res = into if into is not None else abi.FlatResult(self._fp, arena)
         self._check(self.lib.blance_download(self._h, C.byref(res.struct)))
         return res

@@ -78,8 +78,11 @@ def case_to_flat(c, max_iterations=10):
         max_iterations=max_iterations)
 
 
-def config_flat(cfg, P=None, N=None, max_iterations=10):
-    """The flat problem of config `cfg` without going through strings."""
+def config_flat(cfg, P=None, N=None, max_iterations=10, rotate=0):
+    """The flat problem of config `cfg` without going through strings.  rotate = s (config 3): nodesAll starts at the s-th
+    name -- node id i carries the name n[(i + s) mod N], so every per-node hierarchy table differs from the s = 0 instance;
+    for s a multiple of the zone size (128) zones and racks stay aligned blocks of ids and the plan, as ids, is the same
+    (bench.py: the replicas of an N-GPU run plan instances rotated by 512 rank)."""
     if cfg == 1:
         P, N = P or 64, N or 4
         prios, cons = [0], [1]
@@ -130,7 +133,7 @@ def config_flat(cfg, P=None, N=None, max_iterations=10):
         v_empty = d0 + n_dcs
         VX = v_empty + 1
         parent = np.full(VX, v_empty, dtype=np.int32)
-        nid = np.arange(N)
+        nid = (np.arange(N) + int(rotate)) % N      # the name (= leaf) index of node id i
         parent[:N] = r0 + nid // rack
         parent[r0:z0] = z0 + np.arange(n_racks) // rpz
         parent[z0:d0] = d0 + np.arange(n_zones) // zpd

@@ -185,12 +185,19 @@ func planNextMapHip(
 	pb.vertex_leaf_hi = i32(&pin, f.vertexLeafHi)
 	pb.node_leaf_pos = i32(&pin, f.nodeLeafPos)
 
-	if C.blance_validate(pb) != C.BLANCE_OK {
-		return nil, nil, false
-	}
+	// No blance_validate / blance_result_capacity in front of the call (ABI 5): blance_plan makes the same checks itself,
+	// the O(P) ones on the device, and returns the same status; the capacity is bounded here without another walk:
+	// sum of max(k, len) <= sum of len + P * sum of k.  The arrays above are ordinary Go slices (pageable): the library
+	// stages them through its own page-locked buffer with a few threads; a caller that wants the DMA to read them where
+	// they lie allocates them with C.blance_host_alloc (include/blance_hip.h) -- the ownership rule stays "caller owns".
 	M, P := f.nStates, f.nParts
 	PM := P * M
-	capNodes := int64(C.blance_result_capacity(pb))
+	capNodes := int64(len(f.assignNodes))
+	for m := 0; m < M; m++ {
+		if k := int64(f.stateConstraints[m]); k > 0 {
+			capNodes += int64(P) * k
+		}
+	}
 	outOff := make([]int32, PM+1)
 	outNodes := make([]int32, capNodes+1)
 	outKind := make([]uint8, PM+1)

@@ -186,6 +186,11 @@ typedef struct blance_result {
      * (k_pass_chain_planes / k_pass_chain_blank: the first hierarchy pass of a fresh plan) */
     double   blank_pass_ms;
     int64_t  blank_pass_launches;
+    /* out (ABI 5): of pass_kernel_ms / pass_kernel_launches, the part of chain passes that k_stay_by_top verified as stays
+     * (one thread per top priority node, incl. the grouping by top node in front of it) -- what is left after this and the
+     * all-blank part is k_pass_chain (hierarchy-rule states) or k_pass_queue / k_pass_tree / k_pass_seq (flat states) */
+    double   stay_pass_ms;
+    int64_t  stay_pass_launches;
 } blance_result;
 
 typedef struct blance_options {
@@ -319,6 +324,9 @@ int blance_comm_init_rccl(blance_ctx* ctx, int32_t n_ranks, int32_t rank, const 
 int blance_comm_set(blance_ctx* ctx, const blance_comm* comm /* NULL: back to a single rank */);
 /* collectives made / int32 words moved by this context's sharded plans so far */
 int blance_comm_stats(blance_ctx* ctx, int64_t* calls, int64_t* words);
+/* (ABI 5) device time, in ms, this context's plans have spent inside RCCL collectives so far: an event on either side of
+ * every ncclAllReduce / ncclAllGather on the planner's stream (0 for an embedder's own collectives, which run on the host) */
+int blance_comm_time_ms(blance_ctx* ctx, double* ms);
 
 /* 1 if this library is the GPU-less SIMT emulator build of the tests (its "device" memory is host
  * memory), 0 for the gfx950 product. */

@@ -17,3 +17,9 @@ PY
 tail -2 gpurun_out/r5/regime_b_$T.log
 BLANCE_QUEUE_STATS=1 timeout 600 python tools/config5_gpu.py > gpurun_out/r5/config5_$T.log 2>&1
 grep "k_pass_queue\|device\|matches" gpurun_out/r5/config5_$T.log
+timeout 300 python bench.py --steps 5 --warmup 2 --no-other-configs --no-extra --no-cpu-baseline --no-sharded --no-live-pmc > gpurun_out/r5/bench_short_$T.log 2>&1
+python - <<PY
+import json
+d=json.loads([l for l in open("gpurun_out/r5/bench_short_$T.log") if l.startswith("{")][-1])
+print("ms_per_step", d["ms_per_step"], json.dumps(d["transfers"])[:1500])
+PY
