@@ -196,10 +196,19 @@ struct blance_ctx {
     int periodic_cut = 0;           // test knob BLANCE_PERIODIC_CUT (k_period_clamp)
     DevBuf cnt_base, xbuf, gath;    // sharded pass: loads at pass start, [flags | load change], gathered output slices
     std::vector<int32_t> h_reg_off; // host copy of the chain offsets (slice sizes of the all-gather)
+    int chain_group_state = -1;     // the state whose chain pass last grouped the steps by region (chain_order, chain_oi, reg_off) ...
+    bool chain_group_static = false; // ... and whether it did so from the static order (sweeps >= 2)
+    bool tops_moved = true;         // this sweep's top-state pass was not (known to be) one run of stays
     bool trace = false;             // BLANCE_TRACE, read once at context creation
     int dump_sweep = -1;            // BLANCE_DUMP_SWEEP (developer aid), likewise
     DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
     HostStage stage;                // pageable arrays of the caller pass through this page-locked buffer
+    // small readbacks (flag words, counts) land in a page-locked block first: a D2H copy into pageable memory is staged by
+    // the runtime and costs several microseconds more, thirteen times per call
+    void* rb_buf = nullptr;
+    size_t rb_used = 0;
+    struct RbItem { void* dst; size_t off, bytes; };
+    std::vector<RbItem> rb_items;
     DevBuf vres, vseen;             // blance_upload: the device's part of the validation (k_validate_parts)
     DevBuf mv[11];                  // blance_calc_moves: inputs, per-partition slices, offsets, compacted outputs (kept between calls)
     int64_t comm_calls = 0, comm_bytes = 0;
@@ -229,7 +238,6 @@ struct blance_ctx {
     bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
     // nodeToNodeCounts (67 MB at config 3) is zeroed lazily: only a pass that reads or bumps the matrix in HBM pays for it
     // (region chains keep their rows in LDS, a pass that is one run of stays needs none of it)
-    bool ntn_clean = false;         // the matrix (and its bit maps) are known to be all zero
     bool pass_ntn_ready = false;    // this pass has been given its zeroed matrix already (plan.go:266)
     int64_t queue_launches = 0, queue_stops = 0, queue_moved = 0, queue_exact = 0, queue_rebuilds = 0, queue_dense = 0;
     struct RuleRegions {           // regions the rule cuts the leaves into (chains), if it does
@@ -285,6 +293,8 @@ struct blance_ctx {
         cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release(); ntn_bits.release();
         dl_off.release(); dl_nodes.release(); vres.release(); vseen.release();
         stage.release();
+        if (rb_buf) pin_free(rb_buf);
+        rb_buf = nullptr;
         for (DevBuf& b : mv) b.release();
         DevBuf* more[] = {&leaf_node, &regid, &chain_order, &bucket_counts, &reg_off, &cnt_save, &crec, &period, &cnt_p1, &n_ev, &chain_oi,
                           &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
@@ -508,6 +518,29 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     delete c;
 }
 
+constexpr size_t kRbBytes = 64 * 1024;
+// device -> host of a few words, complete after the next stream_sync()
+static hipError_t read_back(blance_ctx* c, void* dst, const void* dev, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (!c->rb_buf) c->rb_buf = pin_alloc(kRbBytes);
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if (!c->rb_buf || c->rb_used + need > kRbBytes) return hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    char* at = (char*)c->rb_buf + c->rb_used;
+    hipError_t e = hipMemcpyAsync(at, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return e;
+    c->rb_items.push_back(blance_ctx::RbItem{dst, c->rb_used, bytes});
+    c->rb_used += need;
+    return hipSuccess;
+}
+static hipError_t stream_sync(blance_ctx* c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        for (const blance_ctx::RbItem& it : c->rb_items) memcpy(it.dst, (const char*)c->rb_buf + it.off, it.bytes);
+    c->rb_items.clear();
+    c->rb_used = 0;
+    return e;
+}
+
 // ---- host <-> device copies.  An array in page-locked memory (blance_host_alloc, or registered by the caller) is copied by
 // DMA where it lies; a pageable one passes through the context's page-locked staging buffer -- small ones at once, big ones
 // (>= 1 MB) by a few threads at flush().  Nothing of the caller's is read after the stream synchronisation that ends the call.
@@ -538,7 +571,7 @@ int Mover::reserve(size_t bytes) {
     if (st.used + bytes <= st.cap) return 0;
     int e = to_device ? flush() : finish();
     if (e) return e;
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     if (bytes <= st.cap) { st.used = 0; return 0; }
     return stage_grow(c, bytes);
 }
@@ -580,7 +613,7 @@ int Mover::flush() {
 int Mover::finish() {
     if (to_device) return flush();
     if (host_copy.empty()) return 0;
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     copy_threaded(host_copy);
     host_copy.clear();
     return 0;
@@ -601,7 +634,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb);
 // error cuts the upload short: never return with copies in flight
 static int upload_locked(blance_ctx* c, const blance_problem* pb) {
     int st = upload_inner(c, pb);
-    if (st && c->stream) (void)hipStreamSynchronize(c->stream);
+    if (st && c->stream) (void)stream_sync(c);
     return st;
 }
 
@@ -611,7 +644,6 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     HIPTRY(hipSetDevice(c->device));
     c->uploaded = false;
     c->planned = false;
-    c->ntn_clean = false;
     c->h = *pb;
     const int N = pb->n_nodes, NX = pb->n_nodes_ext, M = pb->n_states, P = pb->n_parts;
     const int64_t PM = (int64_t)P * M;
@@ -678,10 +710,10 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
         BLANCE_LAUNCH(k_validate_parts, cdiv(PM > P ? PM : P, 256), 256, 0, c->stream, vp);
     }
     int32_t vr[16] = {0};
-    HIPTRY(hipMemcpyAsync(vr, c->vres.p, sizeof vr, hipMemcpyDeviceToHost, c->stream));
+    HIPTRY(read_back(c, vr, c->vres.p, sizeof vr));
     const int tail_a = validate_tail_a(pb);          // (the host's share, while the device works)
     const std::string tail_a_text = g_last_error;
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     if (vr[3]) {                                      // the first list the host's loop would have refused, and why
         const int check = (INT_MAX - vr[3]) & 3;
         if (check == 0) return fail(BLANCE_ERR_BAD_ARG, "CSR offsets not monotone");
@@ -696,8 +728,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     if (na > 0) BLANCE_LAUNCH(k_validate_ids, cdiv(na, 256), 256, 0, c->stream, (long long)na, NX, c->a_nodes.as<int32_t>(), kVErrAssignId, c->vres.as<int32_t>());
     if (np > 0) BLANCE_LAUNCH(k_validate_ids, cdiv(np, 256), 256, 0, c->stream, (long long)np, NX, c->p_nodes.as<int32_t>(), kVErrPrevId, c->vres.as<int32_t>());
     if (na > 0 || np > 0) {
-        HIPTRY(hipMemcpyAsync(vr, c->vres.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipStreamSynchronize(c->stream));
+        HIPTRY(read_back(c, vr, c->vres.p, sizeof(int32_t)));
+        HIPTRY(stream_sync(c));
     }
     if (vr[0] & kVErrAssignId) return fail(BLANCE_ERR_BAD_ARG, "assign node id out of range");
     if (vr[0] & kVErrPrevId) return fail(BLANCE_ERR_BAD_ARG, "prev node id out of range");
@@ -902,7 +934,7 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
         RESERVE(f_hist, sizeof(int32_t) * 256 * ((size_t)cdiv(2 * (int64_t)P + 4, kSortTile) + 1));
     }
     if ((st = up.flush())) return st;
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     // the caller's arrays are not retained: drop the host pointers
     blance_problem& h = c->h;
     h.state_priority = h.state_constraints = h.state_stickiness = nullptr;
@@ -912,18 +944,16 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
 }
 
 // plan.go:266: a state pass starts from an empty nodeToNodeCounts.  Called by whatever is about to read or bump the matrix
-// in HBM (NumPartitions > 0); the first such call of a pass zeroes it unless it is known to be zero already.
+// in HBM (NumPartitions > 0); the first such call of a pass zeroes it (a pass that never calls this -- region chains with their
+// rows in LDS, a pass that is one run of stays -- does not pay for the 67 MB).
 static int ntn_prepare(blance_ctx* c) {
     if (!c->pass_ntn_ready) {
-        if (!c->ntn_clean) {
-            const blance_problem& h = c->h;
-            HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(h.n_nodes_ext + 1) * (h.n_nodes > 0 ? h.n_nodes : 1), c->stream));
-            HIPTRY(hipMemsetAsync(c->ntn_bits.p, 0, sizeof(uint32_t) * queue_bits_words(h.n_nodes_ext), c->stream));
-        }
+        const blance_problem& h = c->h;
+        HIPTRY(hipMemsetAsync(c->ntn.p, 0, sizeof(int32_t) * (size_t)(h.n_nodes_ext + 1) * (h.n_nodes > 0 ? h.n_nodes : 1), c->stream));
+        HIPTRY(hipMemsetAsync(c->ntn_bits.p, 0, sizeof(uint32_t) * queue_bits_words(h.n_nodes_ext), c->stream));
         c->pass_ntn_ready = true;
         c->bits_stale = false;
     }
-    c->ntn_clean = false;                            // (the caller writes it)
     return 0;
 }
 #define NTNTRY() do { int e__ = ntn_prepare(c); if (e__) return e__; } while (0)
@@ -968,8 +998,8 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
         }
         if (!launch_pass_queue(c->stream, q)) { q.beg = pos; return dispatch_pass_tree_or_seq(c, q); }
         int32_t st[2] = {0, 0};
-        HIPTRY(hipMemcpyAsync(st, scal + 16, sizeof st, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipStreamSynchronize(c->stream));
+        HIPTRY(read_back(c, st, scal + 16, sizeof st));
+        HIPTRY(stream_sync(c));
         c->queue_launches++;
         if (c->trace) fprintf(stderr, "[blance] k_pass_queue state %d steps [%d, %d) k %d: stopped at %d (%d)\n", q.s, pos, q0.end, q.k, st[0], st[1]);
         if (st[0] < pos || st[0] > q0.end) return fail(BLANCE_ERR_DEVICE, "k_pass_queue returned a position outside its range");
@@ -1017,8 +1047,8 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches, int32_t** s
     unsigned long long varying = 0;
     HIPTRY(hipMemsetAsync(vbits, 0, sizeof varying, c->stream));
     BLANCE_LAUNCH(k_sort_varbits, cdiv(n, 256 * kVarbitsPer), 256, 0, c->stream, n, ka, vbits);
-    HIPTRY(hipMemcpyAsync(&varying, vbits, sizeof varying, hipMemcpyDeviceToHost, c->stream));
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(read_back(c, &varying, vbits, sizeof varying));
+    HIPTRY(stream_sync(c));
     *launches += 1;
     int done = 0;
     for (int shift = 0; shift < 64; shift += 8) {
@@ -1060,6 +1090,7 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
     cq.alive = q.alive; cq.node_weight = q.node_weight; cq.node_has_weight = q.node_has_weight;
     cq.cnt = q.cnt; cq.ntn = q.ntn; cq.crec = c->crec.as<int32_t>(); cq.out = q.out; cq.flags = scal + 4;
     int pos = beg;
+    c->chain_group_state = -1;                       // (reg_off is this chain's range from here on)
     while (pos < end) {
         int32_t range[2] = {pos, end};
         HIPTRY(hipMemcpyAsync(c->reg_off.p, range, sizeof range, hipMemcpyHostToDevice, sm));
@@ -1067,8 +1098,8 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
         cq.ntn_in_lds = lds_rows ? 1 : 0;
         if (!dispatch_chain(c, cq, q.NX)) return fail(BLANCE_ERR_UNSUPPORTED, "flat chain shape");
         int32_t fl[8] = {0};
-        HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(read_back(c, fl, scal + 4, sizeof fl));
+        HIPTRY(stream_sync(c));
         *launches += 1;
         lds_rows = false;                          // a stopped chain handed its rows to global memory
         if (fl[0]) return 1;                       // a step the compact record cannot hold: caller falls back
@@ -1127,12 +1158,13 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
         BLANCE_LAUNCH(k_flat_scan, scan_blocks, 256, 0, sm, fq, pos, P);
         BLANCE_LAUNCH(k_flat_scan_min, 1, 1024, 256, sm, fq.scan_waves, (const int32_t*)fq.scan_part, scal + 8);
         int32_t got[2] = {0, 0};
-        HIPTRY(hipMemcpyAsync(got, scal + 8, sizeof got, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(read_back(c, got, scal + 8, sizeof got));
+        HIPTRY(stream_sync(c));
         *launches += 1;
         int first_nonstay = got[0] > P ? P : got[0], first_nonfresh = got[1] > P ? P : got[1];
         if (first_nonstay - pos >= kMinStayRun || (first_nonstay == P && first_nonstay > pos)) {
             const bool whole = pos == 0 && first_nonstay == P;      // the pass is one run of stays: no one reads the matrix
+            if (whole && q.s == q.top_state && q.k == 1) c->tops_moved = false;      // (k > 1: a stay may still reorder the list, plan.go:126-138 reads its first node)
             if (q.NP > 0 && !whole) NTNTRY();
             BLANCE_LAUNCH_NOSYNC(k_flat_commit_stay, cdiv(first_nonstay - pos, 256), 256, 0, sm, fq, pos, first_nonstay, whole ? 0 : 1);
             *launches += 1;
@@ -1161,8 +1193,8 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
                 int32_t bad = INT_MAX;
                 HIPTRY(hipMemcpyAsync(scal + 10, &bad, sizeof bad, hipMemcpyHostToDevice, sm));
                 BLANCE_LAUNCH(k_fresh_excl, 1, 1024, 2048 + 64, sm, fq, pos, R, sorted_vals, other_vals, scal + 10);
-                HIPTRY(hipMemcpyAsync(&bad, scal + 10, sizeof bad, hipMemcpyDeviceToHost, sm));
-                HIPTRY(hipStreamSynchronize(sm));
+                HIPTRY(read_back(c, &bad, scal + 10, sizeof bad));
+                HIPTRY(stream_sync(c));
                 *launches += 1;
                 if (bad < R) R = bad;               // a pending node came up again: the run ends before that step
                 picks = other_vals;
@@ -1209,7 +1241,7 @@ static int dump_pass(blance_ctx* c, int sweep, int state, int P, int OW, const i
     std::vector<int32_t> out((size_t)P * OW), idx((size_t)P);
     HIPTRY(hipMemcpyAsync(out.data(), c->out.p, sizeof(int32_t) * out.size(), hipMemcpyDeviceToHost, c->stream));
     if (idx_dev) HIPTRY(hipMemcpyAsync(idx.data(), idx_dev, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     std::vector<int> at((size_t)P);
     for (int i = 0; i < P; i++) at[idx_dev ? idx[i] : i] = i;
     for (int oi = 0; oi < P; oi++) {
@@ -1378,7 +1410,7 @@ static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
     c->comm_calls++;
     c->comm_bytes += n * 4;
     if (c->comm.allreduce_sum_i32) {
-        HIPTRY(hipStreamSynchronize(c->stream));
+        HIPTRY(stream_sync(c));
         if (c->comm.allreduce_sum_i32(c->comm.user, buf, n)) return fail(BLANCE_ERR_COMM, "the caller's all-reduce failed");
         return 0;
     }
@@ -1400,7 +1432,7 @@ static int comm_allgather(blance_ctx* c, int32_t* buf, int64_t per_rank) {
     c->comm_calls++;
     c->comm_bytes += per_rank * 4 * c->comm.n_ranks;
     if (c->comm.allreduce_sum_i32) {
-        HIPTRY(hipStreamSynchronize(c->stream));
+        HIPTRY(stream_sync(c));
         if (!c->comm.allgather_i32) return fail(BLANCE_ERR_COMM, "no all-gather hook");
         if (c->comm.allgather_i32(c->comm.user, buf, per_rank)) return fail(BLANCE_ERR_COMM, "the caller's all-gather failed");
         return 0;
@@ -1440,6 +1472,8 @@ constexpr int kXHead = 16;
 struct ChainPassArgs {
     DevProblem d;
     int m, k, NP, OW, RW, higher_mask, r0, it;
+    const int32_t* order;          // the pass order: the stable partition of sweep 1, the static order itself afterwards
+    bool same_tops;                // no partition has changed its top priority node since this state's last chain pass
 };
 
 // this rank failed before collective A of a sharded chain pass: take part in it with the poison word set
@@ -1450,9 +1484,9 @@ static void comm_poison(blance_ctx* c) {
     if (hipMemsetAsync(c->xbuf.p, 0, sizeof(int32_t) * n, c->stream) != hipSuccess) return;
     const int32_t one = 1;
     if (hipMemcpyAsync(c->xbuf.as<int32_t>() + 8, &one, sizeof one, hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+    if (stream_sync(c) != hipSuccess) return;
     (void)comm_allreduce(c, c->xbuf.as<int32_t>(), (int64_t)n);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_sync(c);
 }
 
 // 0 = ok (*done tells whether the pass was made; if not, the counters are as before and the caller
@@ -1473,38 +1507,48 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     const bool sharded = G > 1 && B >= G;
     HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
     BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P + 1, 256), 256, 0, sm, d, m, h.top_state,
-                         c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
+                         a.order, rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
                          c->n_ev.as<int32_t>(), scal + 4);
     int nbits = 1;
     while ((1 << nbits) < B) nbits++;
-    BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
-                  (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, B, c->bucket_counts.as<int32_t>());
-    SCANTRY(B * nbc, c->bucket_counts.as<int32_t>());
-    BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nbc, P,
-                         c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
-    BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
-                  (const uint8_t*)nullptr, (const int32_t*)nullptr, c->order.as<int32_t>(), nbc, B, nbits,
-                  c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>());
+    // The steps grouped by the region of their top priority node (a stable counting sort of the pass order).  A sweep whose
+    // top-state pass was one run of stays has moved no top priority node, and from sweep 2 on the pass order is the static
+    // order: the grouping of this state's last chain pass -- chain_order, chain_oi, reg_off -- still stands (config 3's
+    // third sweep: six launches less).
+    const bool regroup = !(a.same_tops && c->chain_group_state == m && c->chain_group_static && a.order == c->part_order.as<int32_t>() &&
+                           c->h_reg_off.size() == (size_t)B + 1);
+    if (regroup) {
+        BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, B, c->bucket_counts.as<int32_t>());
+        SCANTRY(B * nbc, c->bucket_counts.as<int32_t>());
+        BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(B + 1, 64), 64, 0, sm, B, nbc, P,
+                             c->bucket_counts.as<int32_t>(), c->reg_off.as<int32_t>());
+        BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * B + 64, sm, P, c->regid.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, a.order, nbc, B, nbits,
+                      c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>());
+        c->chain_group_state = m;
+        c->chain_group_static = a.order == c->part_order.as<int32_t>();
+    } else if (c->trace) fprintf(stderr, "[blance] chain pass state %d: the grouping by region of the last sweep stands\n", m);
     // events: how many?  (also: is every step region-local at all, are there orphan nodes); a sharded
     // plan reads the chain offsets in the same round trip (the slice sizes of collective B)
     int32_t n_events = 0, cfl[8] = {0};
-    HIPTRY(hipMemcpyAsync(cfl, scal + 4, sizeof cfl, hipMemcpyDeviceToHost, sm));
-    if (sharded || c->periodic) {
+    HIPTRY(read_back(c, cfl, scal + 4, sizeof cfl));
+    if (regroup) {                                     // (always: the next sweep may reuse the grouping, the host's copy with it)
         c->h_reg_off.resize((size_t)B + 1);
-        HIPTRY(hipMemcpyAsync(c->h_reg_off.data(), c->reg_off.p, sizeof(int32_t) * ((size_t)B + 1), hipMemcpyDeviceToHost, sm));
+        HIPTRY(read_back(c, c->h_reg_off.data(), c->reg_off.p, sizeof(int32_t) * ((size_t)B + 1)));
     }
-    HIPTRY(hipStreamSynchronize(sm));
+    HIPTRY(stream_sync(c));
     if (!cfl[0] && cfl[7]) {                            // rare: nodes outside their partition's region
         SCANTRY(P + 1, c->n_ev.as<int32_t>());   // -> event slots
-        HIPTRY(hipMemcpyAsync(&n_events, c->n_ev.as<int32_t>() + P, sizeof n_events, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(read_back(c, &n_events, c->n_ev.as<int32_t>() + P, sizeof n_events));
+        HIPTRY(stream_sync(c));
     }
     if (c->trace)
         fprintf(stderr, "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
     HIPTRY(hipMemsetAsync(c->ev_off.p, 0, sizeof(int32_t) * ((size_t)B + 1), sm));
     if (!cfl[0] && n_events > 0) {
         const int nec = cdiv(n_events, kPartChunk);
-        BLANCE_LAUNCH_NOSYNC(k_chain_ev_fill, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+        BLANCE_LAUNCH_NOSYNC(k_chain_ev_fill, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, a.order,
                              rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), c->node_leaf_pos.as<int32_t>(),
                              c->regid.as<int32_t>(), c->n_ev.as<int32_t>(), c->ev_key.as<int32_t>(),
                              c->ev_oi.as<int32_t>(), c->ev_leaf.as<int32_t>(), c->ev_w.as<int32_t>());
@@ -1560,7 +1604,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     cq.ev_off = c->ev_off.as<int32_t>(); cq.ev_perm = c->ev_perm.as<int32_t>();
     cq.ev_oi = c->ev_oi.as<int32_t>(); cq.ev_leaf = c->ev_leaf.as<int32_t>(); cq.ev_w = c->ev_w.as<int32_t>();
     if (cfl[6])                                        // nodes of this state that lie in no region
-        BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, c->order.as<int32_t>(),
+        BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, a.order,
                              rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
     cq.cnt_out = cq.cnt;
     const bool gather_out = sharded && (c->comm.allgather_i32 || !c->comm.allreduce_sum_i32);
@@ -1597,8 +1641,8 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         HIPTRY(hipMemsetAsync(scal + 11, 0, 4, sm));
         if (launch_stay_by_top(sm, sq, rr.n_stay_wgs, rr.max_size)) {
             int32_t sf[8] = {0};                        // [0] a step is not region-local (k_gather_chain), [7] not all stays
-            HIPTRY(hipMemcpyAsync(sf, scal + 4, sizeof sf, hipMemcpyDeviceToHost, sm));
-            HIPTRY(hipStreamSynchronize(sm));
+            HIPTRY(read_back(c, sf, scal + 4, sizeof sf));
+            HIPTRY(stream_sync(c));
             launches += 5;
             stayed = !sf[0] && !sf[7];
             if (c->trace) fprintf(stderr, "[blance] chain pass state %d: stays verified per top priority node: %s\n", m, stayed ? "all of them" : "no");
@@ -1668,7 +1712,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                     if (c->trace) {
                         std::vector<int32_t> hp((size_t)kPWords * B);
                         HIPTRY(hipMemcpyAsync(hp.data(), pb, sizeof(int32_t) * hp.size(), hipMemcpyDeviceToHost, sm));
-                        HIPTRY(hipStreamSynchronize(sm));
+                        HIPTRY(stream_sync(c));
                         int64_t copied = 0; int n_ok = 0;
                         for (int r = 0; r < B; r++)
                             if (hp[(size_t)kPOk * B + r]) { n_ok++; copied += hp[(size_t)kPLimit * B + r] - 2 * hp[(size_t)kPT * B + r]; }
@@ -1680,8 +1724,8 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         }
         if (!walked && (c->no_planes || !launch_chain_planes(sm, cq, rr.max_size))) launch_chain_blank(sm, cq, rr.max_size);
         int32_t fl[2] = {0, 0};
-        HIPTRY(hipMemcpyAsync(fl, scal + 4, sizeof fl, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(read_back(c, fl, scal + 4, sizeof fl));
+        HIPTRY(stream_sync(c));
         launches++;
         if (c->trace) fprintf(stderr, "[blance] chain pass state %d: all-blank kernel (%s) %s\n", m, c->no_planes ? "lanes" : "planes",
                               !fl[0] && !fl[1] ? "did the pass" : "escaped");
@@ -1692,7 +1736,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                                   hipMemcpyDeviceToDevice, sm));
             if (cfl[6] && !sharded)
                 BLANCE_LAUNCH_NOSYNC(k_chain_orphans, cdiv(P, 256), 256, 0, sm, d, m, h.top_state,
-                                     c->order.as<int32_t>(), rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
+                                     a.order, rr.node_region.as<int32_t>(), c->cnt.as<int32_t>());
             HIPTRY(hipMemsetAsync(scal + 4, 0, 16, sm));
         }
     }
@@ -1715,12 +1759,12 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                              c->cnt_base.as<int32_t>(), xb + kXHead);
         *a_done = true;
         COMMTRY(comm_allreduce(c, xb, (int64_t)(kXHead + cnt_words)));
-        HIPTRY(hipMemcpyAsync(fl, xb, sizeof fl, hipMemcpyDeviceToHost, sm));
+        HIPTRY(read_back(c, fl, xb, sizeof fl));
         launches++;
     } else if (!lean) {                              // (the all-blank kernel's flags were read above: all clear)
-        HIPTRY(hipMemcpyAsync(fl, scal + 4, 32, hipMemcpyDeviceToHost, sm));
+        HIPTRY(read_back(c, fl, scal + 4, 32));
     }
-    if (sharded || !lean) HIPTRY(hipStreamSynchronize(sm));
+    if (sharded || !lean) HIPTRY(stream_sync(c));
     if (fl[8]) return fail(BLANCE_ERR_COMM, "another rank of the sharded plan failed");
     if (c->trace)
         fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
@@ -1789,6 +1833,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     c->last_stays.assign((size_t)(M > 0 ? M : 1), 0);
     c->queue_launches = c->queue_stops = 0;
     c->comm_events_used = 0;
+    c->chain_group_state = -1;
 
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 256, sm));
@@ -1805,6 +1850,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         const int add_nil = first ? h.nodes_to_add_nil : 0;
         const int any_removed = first ? c->any_removed : 0;
         const int NP = first ? h.n_prev : c->np_later;
+        c->tops_moved = true;                                       // until this sweep's top-state pass turns out to be one run of stays
         HIPTRY(hipMemsetAsync(scal, 0, 8, sm));                     // warn_count, not_match
         if (PM > 0) {
             if (first)
@@ -1843,8 +1889,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 // sweeps >= 2 run with nodesToRemove = nodesToAdd = [] (non-nil, plan.go:53-55): no partition's
                 // nodes are in either, so every category is "1" (plan.go:542-561) and the pass order is the
                 // static order itself
-                HIPTRY(hipMemcpyAsync(c->order.p, c->part_order.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToDevice, sm));
             }
+            const int32_t* order = first ? c->order.as<int32_t>() : c->part_order.as<int32_t>();
             c->pass_ntn_ready = false;                              // nodeToNodeCounts := fresh (plan.go:266), zeroed when first needed
             const int OW = 1 + k;
             int higher_mask = 0;
@@ -1861,7 +1907,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             bool done = false;
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
                 c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
-                ChainPassArgs ca{d, m, k, NP, OW, RW, higher_mask, r0, it};
+                ChainPassArgs ca{d, m, k, NP, OW, RW, higher_mask, r0, it, order, !first && !c->tops_moved && m != h.top_state};
                 bool a_done = false;
                 const int e = run_chain_pass(c, ca, &launches, &batched, &n_pass, &done, &a_done);
                 if (e) {
@@ -1872,7 +1918,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 }
             }
             if (!done) {
-            BLANCE_LAUNCH(k_gather, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (RW | 1) + 64, sm, d, m, h.top_state, RW, c->order.as<int32_t>(),
+            BLANCE_LAUNCH(k_gather, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (RW | 1) + 64, sm, d, m, h.top_state, RW, order,
                                  c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
             PassParams q;
             memset(&q, 0, sizeof q);
@@ -1907,14 +1953,14 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             if (flat_chain) {
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
                 BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, higher_mask,
-                                     c->order.as<int32_t>(), (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
+                                     order, (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
                                      c->fl_one.as<int32_t>(), 1,
                                      c->crec.as<int32_t>(), scal + 4, (int32_t*)nullptr);
                 int32_t bad = 0;
-                HIPTRY(hipMemcpyAsync(&bad, scal + 4, sizeof bad, hipMemcpyDeviceToHost, sm));
-                HIPTRY(hipStreamSynchronize(sm));
+                HIPTRY(read_back(c, &bad, scal + 4, sizeof bad));
+                HIPTRY(stream_sync(c));
                 launches++;
                 if (bad) flat_chain = false;       // some step does not fit the compact record
             }
@@ -1940,7 +1986,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
             n_pass++;
             if (dump_pass(c, it, m, P, q.OW, nullptr)) return BLANCE_ERR_DEVICE;
-            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, c->order.as<int32_t>(), c->out.as<int32_t>());
+            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, order, c->out.as<int32_t>());
             }
             launches += 7;
             steps += P;
@@ -1953,8 +1999,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         }
         // one readback per sweep: the convergence word with the warnings count, and -- complete with the last sweep --
         // the statistics words behind them (steps k_pass_seq committed as verified stays, the queue kernel's counters)
-        HIPTRY(hipMemcpyAsync(hs, scal, sizeof hs, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(read_back(c, hs, scal, sizeof hs));
+        HIPTRY(stream_sync(c));
         HIPTRY(hipGetLastError());
         if (hs[2]) return fail(BLANCE_ERR_UNSUPPORTED, "hierarchy fold overflowed the device's interval budget");
         c->n_warnings = hs[0];
@@ -2058,8 +2104,8 @@ static int download_locked(blance_ctx* c, blance_result* res) {
         BLANCE_LAUNCH_NOSYNC(k_result_len, cdiv((int64_t)PM + 1, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>());
         SCANTRY((int)PM + 1, c->dl_off.as<int32_t>());
         int32_t total = 0;
-        HIPTRY(hipMemcpyAsync(&total, c->dl_off.as<int32_t>() + PM, sizeof total, hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipStreamSynchronize(c->stream));
+        HIPTRY(read_back(c, &total, c->dl_off.as<int32_t>() + PM, sizeof total));
+        HIPTRY(stream_sync(c));
         if (total > res->out_capacity) return fail(BLANCE_ERR_CAPACITY, "out_capacity too small");
         RESERVE(dl_nodes, sizeof(int32_t) * ((size_t)total + 1));
         BLANCE_LAUNCH_NOSYNC(k_result_gather, cdiv((int64_t)PM, 256), 256, 0, c->stream, d, c->dl_off.as<int32_t>(),
@@ -2073,7 +2119,7 @@ static int download_locked(blance_ctx* c, blance_result* res) {
         if ((e = down.copy(res->warn_state, c->warn_state.p, sizeof(int32_t) * (size_t)c->n_warnings))) return e;
     }
     if ((e = down.finish())) return e;
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     res->n_warnings = c->n_warnings;
     res->iterations = c->iterations;
     res->converged = c->converged;
@@ -2120,14 +2166,14 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
     int e;
     if ((e = up(boff, pb->beg_off, PS + 1)) || (e = up(bnod, pb->beg_nodes, (size_t)nb)) ||
         (e = up(eoff, pb->end_off, PS + 1)) || (e = up(enod, pb->end_nodes, (size_t)ne))) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)stream_sync(c);
         return e;
     }
     if (onode.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || ostate.reserve(sizeof(int32_t) * ((size_t)cap + 1)) ||
         okind.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || nmov.reserve(sizeof(int32_t) * ((size_t)P + 2)) ||
         cnode.reserve(sizeof(int32_t) * ((size_t)cap + 1)) || cstate.reserve(sizeof(int32_t) * ((size_t)cap + 1)) ||
         ckind.reserve(sizeof(int32_t) * ((size_t)cap + 1))) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)stream_sync(c);
         return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
     }
     MovesParams q;
@@ -2149,7 +2195,7 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
     HIPTRY(hipEventRecord(c->ev1, c->stream));
     if (P > 0) {
         HIPTRY(hipMemcpyAsync(res->op_off, nmov.p, sizeof(int32_t) * ((size_t)P + 1), hipMemcpyDeviceToHost, c->stream));
-        HIPTRY(hipStreamSynchronize(c->stream));
+        HIPTRY(stream_sync(c));
         const int64_t total = res->op_off[P];
         if (total > 0) {
             HIPTRY(hipMemcpyAsync(res->op_node, cnode.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, c->stream));
@@ -2157,7 +2203,7 @@ extern "C" int blance_calc_moves(blance_ctx* c, const blance_moves_problem* pb, 
             HIPTRY(hipMemcpyAsync(res->op_kind, ckind.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, c->stream));
         }
     }
-    HIPTRY(hipStreamSynchronize(c->stream));
+    HIPTRY(stream_sync(c));
     float ms = 0.f;
     HIPTRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     res->device_ms = ms;
@@ -2217,7 +2263,7 @@ extern "C" int blance_plan_stats_get(blance_ctx* c, blance_plan_stats* st) {
         BLANCE_LAUNCH(k_stats_reduce, M, 256, sizeof(long long) * 5 * 256 + 64, sm, N, NX, c->alive.as<uint8_t>(), load.as<int32_t>(), out.as<long long>());
         HIPTRY(hipMemcpyAsync(host.data(), out.p, sizeof(long long) * (size_t)M * 5, hipMemcpyDeviceToHost, sm));
         HIPTRY(hipMemcpyAsync(hun.data(), unmet.p, sizeof(long long) * 2 * (size_t)M, hipMemcpyDeviceToHost, sm));
-        HIPTRY(hipStreamSynchronize(sm));
+        HIPTRY(stream_sync(c));
     }
     if (c->iterations > 0) n_next = c->n_alive;
     st->n_nodes_next = n_next;

@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
+#include <system_error>
 #include <atomic>
 #include <functional>
 #include <mutex>
@@ -180,6 +182,33 @@ struct Scratch {
     std::vector<PartitionPtr> parts, stored;
 };
 
+// Worker threads that cannot take the process down: a worker's exception (std::bad_alloc, say) is carried to the calling
+// thread and rethrown there after every thread has been joined; if the system gives no more threads the caller does the
+// rest of the work itself.  fn(i) for i in [0, n): the caller runs i = 0.
+struct Joiner {
+    std::vector<std::thread>& th;
+    ~Joiner() { for (auto& x : th) if (x.joinable()) x.join(); }
+};
+template <class Fn>
+void run_workers(int n, Fn fn) {
+    std::vector<std::thread> th;
+    std::exception_ptr first;
+    std::mutex mu;
+    auto guarded = [&](int i) {
+        try { fn(i); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    };
+    int started = 1;
+    {
+        Joiner join{th};
+        try {
+            for (int i = 1; i < n; i++) { th.emplace_back(guarded, i); started++; }
+        } catch (const std::system_error&) {}        // no more threads
+        guarded(0);
+        for (int i = started; i < n; i++) guarded(i);
+    }
+    if (first) std::rethrow_exception(first);
+}
+
 template <class T>
 const T* ptr(const std::vector<T>& v) {
     static T dummy[1] = {};
@@ -195,7 +224,7 @@ void collect_in_order(const Map& m, std::vector<const typename Map::value_type*>
     using V = typename Map::value_type;
     out.clear();
     out.reserve(m.size());
-#if defined(__GLIBCXX__)
+#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG)
     using Base = std::_Rb_tree_node_base;
     using Node = std::_Rb_tree_node<V>;
     if (n_threads > 1 && m.size() >= min_size) {
@@ -241,10 +270,7 @@ void collect_in_order(const Map& m, std::vector<const typename Map::value_type*>
                 }
             }
         };
-        std::vector<std::thread> th;
-        for (int i = 1; i < n_threads; i++) th.emplace_back(work);
-        work();
-        for (auto& x : th) x.join();
+        run_workers(n_threads, [&](int) { work(); });
         for (auto& t : tasks) {
             if (t.subtree) out.insert(out.end(), t.got.begin(), t.got.end());
             else out.push_back(static_cast<const Node*>(t.n)->_M_valptr());
@@ -521,10 +547,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
     };
     bool again = false;
     if (n_ranges > 1) {
-        std::vector<std::thread> th;
-        for (int r = 1; r < n_ranges; r++) th.emplace_back(run_range, r, false);
-        run_range(0, false);
-        for (auto& x : th) x.join();
+        run_workers(n_ranges, [&](int r) { run_range(r, false); });
         for (auto& R : ranges) if (R.unknown_node) again = true;
     }
     if (n_ranges == 1 || again) {
@@ -679,12 +702,7 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
             // slices in order, so the sort stays stable
             const int T = (P >= 65536 || threads_forced) ? std::max(1, std::min(n_threads, P)) : 1;
             std::vector<std::vector<size_t>> cnt((size_t)T, std::vector<size_t>(2048));
-            auto parallel = [&](const std::function<void(int)>& fn) {
-                std::vector<std::thread> th;
-                for (int t = 1; t < T; t++) th.emplace_back(fn, t);
-                fn(0);
-                for (auto& x : th) x.join();
-            };
+            auto parallel = [&](const std::function<void(int)>& fn) { run_workers(T, fn); };
             auto radix = [&](long long mx) {
                 for (int shift = 0; shift < 63 && (mx >> shift) != 0; shift += 11) {
                     parallel([&](int t) {
@@ -933,12 +951,7 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
             failed.store(true);
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int i = 1; i < n_threads; i++) th.emplace_back(build_blocks);
-        build_blocks();
-        for (auto& x : th) x.join();
-    }
+    run_workers(n_threads, [&](int) { build_blocks(); });
     if (failed.load()) { out.handled = false; out.why = "out of memory while building the result"; parts.clear(); stored.clear(); return out; }
     out.unintern_parts_ms = ms_since(t_un);
     out.threads = n_threads;
@@ -985,21 +998,22 @@ PlanOutcome PlanNextMapEx(Library& lib, PartitionMap* prevMap, PartitionMap& par
         auto store_prev = [&]() { store(*prevMap, f.prev_slot); prev_ms = ms_since(t_st); };
         auto store_assign = [&]() { store(partitionsToAssign, f.assign_slot); assign_ms = ms_since(t_st); };
         const bool two = need_store && &partitionsToAssign != prevMap;
-        std::vector<std::thread> th;
-        if (need_store && n_threads > 1) {
-            th.emplace_back(store_prev);
-            if (two) th.emplace_back(store_assign);
-        }
-        {   // the result map, filled in name order -- the order the partitions were taken from partitionsToAssign --
+        auto result_map = [&]() {   // filled in name order -- the order the partitions were taken from partitionsToAssign --
             ArenaScope scope;                              // so every insertion lands at the end
             for (int p = 0; p < P; p++) out.nextMap.emplace_hint(out.nextMap.end(), f.part_names[(size_t)p], parts[(size_t)p]);
+            out.unintern_map_ms = ms_since(t_st);
+        };
+        if (need_store && n_threads > 1) {
+            // the result map on this thread, the stores of plan.go:49-52 beside it (run_workers: an exception of a worker
+            // is rethrown here after the join, thread shortage means this thread does the stores as well)
+            run_workers(two ? 3 : 2, [&](int i) { if (i == 0) result_map(); else if (i == 1) store_prev(); else store_assign(); });
+        } else {
+            result_map();
+            if (need_store) {
+                store_prev();
+                if (two) store_assign();
+            }
         }
-        out.unintern_map_ms = ms_since(t_st);
-        if (need_store && n_threads <= 1) {
-            store_prev();
-            if (two) store_assign();
-        }
-        for (auto& x : th) x.join();
         if (getenv("BLANCE_HOST_TRACE")) fprintf(stderr, "[host] store prev %.1f ms, assign %.1f ms, result map %.1f ms (side by side)\n", prev_ms, assign_ms, out.unintern_map_ms);
         out.store_ms = std::max(prev_ms, assign_ms);        // (side by side with the result map when threads are used)
     }
