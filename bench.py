@@ -155,7 +155,7 @@ def live_pmc(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(work, counter), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "1", "--warmup", "0",
-                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc", "--no-other-configs"]
+                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc", "--no-other-configs", "--no-transfers"]
             if args.parts:
                 cmd += ["--parts", str(args.parts)]
             if args.nodes:
@@ -312,6 +312,8 @@ def main():
     ap.add_argument("--cpu-sample", action="store_true", help="cpu_baseline on a quarter of the partitions, extrapolated (14 s) -- the default "
                     "times the oracle on ALL partitions of config 3 (about a minute on the GPU box's EPYC, two here)")
     ap.add_argument("--cpu-full", action="store_true", help="(the default since round 5; kept so that old command lines still parse)")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the transfers block (the problem uploaded and the result downloaded again, "
+                    "pageable and page-locked): profiles of the plan itself use this")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (BASELINE configs 2 and 5 timed with digests, about 40 s)")
     args = ap.parse_args()
 
@@ -406,7 +408,7 @@ def main():
     # the same problem uploaded again and the result downloaded again into buffers that exist -- pageable arrays (staged
     # through the context's page-locked buffer by a few threads) and arrays from blance_host_alloc (DMA where they lie)
     xfer = None
-    if rank == 0 and not rehearsal:
+    if rank == 0 and not rehearsal and not args.no_transfers:
         try:
             def again(f, arena):
                 r_ = None
@@ -461,10 +463,10 @@ def main():
             hbm, hbm_src = live_pmc(args)
         if hbm is None:
             why = hbm_src
-            hbm, hbm_src = profile_json("r4_pmc_hbm_config%d.json" % args.config)
+            hbm, hbm_src = profile_json("r5_pmc_hbm_config%d.json" % args.config)
             hbm_src = "%s -- a committed profile of the same kernel sources, NOT measured in this run (%s)" % (hbm_src, why) if hbm else \
                       "none: %s; %s" % (why, hbm_src)
-        sq, sq_src = profile_json("r4_pmc_sq_config%d.json" % args.config)
+        sq, sq_src = profile_json("r5_pmc_sq_config%d.json" % args.config)
         survey_state = synth.algorithmic_bytes_per_state(fp)          # the reference's dense scan, per pass of a state
 
         def kernel_line(label, prefix, words, ms, launches, chains, dense_bytes):

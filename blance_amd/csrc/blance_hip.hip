@@ -707,7 +707,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
         vp.part_order = c->part_order.as<int32_t>(); vp.part_weight = c->part_weight.as<int32_t>();
         vp.part_has_weight = c->part_has_weight.as<uint8_t>(); vp.part_in_prev = c->part_in_prev.as<uint8_t>();
         vp.seen = c->vseen.as<uint32_t>(); vp.res = c->vres.as<int32_t>();
-        BLANCE_LAUNCH(k_validate_parts, cdiv(PM > P ? PM : P, 256), 256, 0, c->stream, vp);
+        const int vblocks = cdiv(PM > P ? PM : P, 256);
+        BLANCE_LAUNCH(k_validate_parts, vblocks < 1024 ? vblocks : 1024, 256, 4 * 8 * sizeof(unsigned long long), c->stream, vp);
     }
     int32_t vr[16] = {0};
     HIPTRY(read_back(c, vr, c->vres.p, sizeof vr));

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             for (int w2 = 0; w2 < NW - 1; w2++) cw += cntw[w2];
             cw = uni(cw);
             const int tn = uni(thT[2]);
-            if (cw >= 40 || tn == INT_MAX) {         // (a short window is exact all the same, it only lasts a few steps)
+            if (cw >= 40 || tn == INT_MAX) {         // (a short window is exact all the same, it only lasts a few steps; measured: accepting 16 costs regime (b) 3 %)
                 const int wc = cw < 64 ? cw : 64;
                 wk = lane < wc ? winK[lane] : ~0ull;
                 wn = lane < wc ? winN[lane] : INT_MAX;

@@ -1,4 +1,4 @@
-"""The bench line contract, checked on the line committed from the last device run (profiles/r4_bench_default.json):
+"""The bench line contract, checked on the line committed from the last device run (profiles/r5_bench_default.json):
 the keys the driver parses, BASELINE.json's metric and headline workload, a roofline object that follows from its own
 inputs, a CPU baseline with its sample stated -- and the bookkeeping that ties the quoted counters to kernel sources."""
 import json
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r4_bench_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r5_bench_default.json")) as f:
         return json.load(f)
 
 
@@ -58,7 +58,7 @@ def test_quoted_counters_are_tied_to_kernel_sources():
     import bench
     import profile_summary
     now = profile_summary.source_hash()
-    for name in ("r4_pmc_hbm_config3.json", "r4_pmc_sq_config3.json", "r4_pmc_hbm_config5.json"):
+    for name in ("r5_pmc_hbm_config3.json", "r5_pmc_sq_config3.json", "r5_pmc_hbm_config5.json"):
         data, src = bench.profile_json(name)
         with open(os.path.join(ROOT, "profiles", name)) as f:
             profiled = json.load(f)["source_hash"]
@@ -66,7 +66,7 @@ def test_quoted_counters_are_tied_to_kernel_sources():
             assert data is not None and profiled in src
         else:
             assert data is None and "other kernel sources" in src
-    data, src = bench.profile_json("r4_no_such_profile.json")
+    data, src = bench.profile_json("r5_no_such_profile.json")
     assert data is None
 
 
@@ -79,6 +79,24 @@ def test_committed_line_measured_its_traffic_in_the_same_run():
     assert abs(r["survey_8d_frac"] - r["survey_8d_GBps"] / r["peak"]) < 1e-9
     gr = _line()["general_regime"]
     assert len(gr) == 2 and all(w["matches_oracle_digest"] is True and w["headline"] is False for w in gr)
+
+
+def test_committed_line_carries_every_baseline_config_and_the_boundary():
+    """Round 5: the default line times BASELINE configs 2 and 5 as well (digests checked), names ONE kernel in `roofline`,
+    runs the CPU oracle on all of config 3, and reports the transfers in steady state both ways."""
+    d = _line()
+    oc = d["other_configs"]
+    assert [w["config"] for w in oc] == [2, 5, 5]
+    assert all("error" not in w and w["matches_oracle_digest"] is True for w in oc), oc
+    assert all(abs(w["roofline"]["frac"] - w["roofline"]["achieved"] / w["roofline"]["peak"]) < 1e-9 for w in oc)
+    assert d["roofline"]["kernel"].startswith("k_pass_chain<2,2,false>")
+    assert not any("/" in k["kernel"].split("(")[0] for k in d["roofline_per_kernel"] if k["kernel"].startswith("k_"))
+    assert d["cpu_baseline"]["extrapolated"] is False and "NOT extrapolated" in d["cpu_baseline"]["sample"]
+    t = d["transfers"]
+    assert t["same_digest_both_ways"] is True
+    assert t["page_locked"]["upload_s"] + t["page_locked"]["download_s"] < 4e-3          # VERDICT r4: <= 4 ms at config 3
+    assert t["value_incl_transfers"] >= 300e6
+    assert t["value_incl_transfers"] < d["value"]                                      # never the headline
 
 
 def test_live_line_of_a_rehearsal_has_the_same_fields():

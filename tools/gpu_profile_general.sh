@@ -14,4 +14,12 @@ for w in a b; do
   db=$(find "$work" -name "*_results.db" | head -1)
   python tools/profile_summary.py trace "$db" 1 "$out/kernel_trace_stats_general_$w.txt" "rocprofv3 --kernel-trace --stats -- python $cmd: $what" > /dev/null
   tail -2 "$out/kt_$w.log"; head -16 "$out/kernel_trace_stats_general_$w.txt"
+  # HBM traffic of the same call: FETCH_SIZE and WRITE_SIZE in separate passes, nothing but --kernel-trace beside --pmc
+  dbs=""
+  for counter in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && BLANCE_DEV_PRODUCT=1 timeout 600 rocprofv3 --kernel-trace --pmc $counter -d "$work/$counter" -o p -- python "$GRAFT_REPO_ROOT/$cmd" > "$out/pmc_${counter}_$w.log" 2>&1)
+    dbs="$dbs $(find "$work/$counter" -name "*_results.db" | head -1)"
+  done
+  python tools/profile_summary.py pmc "$out/pmc_hbm_general_$w.txt" "$out/pmc_hbm_general_$w.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python $cmd: $what; unit KB as reported" $dbs > /dev/null
+  head -8 "$out/pmc_hbm_general_$w.txt"
 done

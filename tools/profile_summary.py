@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["blance_amd/csrc/k_pass_chain.h", "blance_amd/csrc/k_pass_tree.h", "blance_amd/csrc/k_pass_seq.h",
                   "blance_amd/csrc/k_flat.h", "blance_amd/csrc/k_sweep.h", "blance_amd/csrc/dev_common.h",
                   "blance_amd/csrc/blance_hip.hip", "blance_amd/csrc/k_stay.h", "blance_amd/csrc/blance_kernels.h",
-                  "blance_amd/csrc/k_period.h", "blance_amd/csrc/k_pass_queue.h", "blance_amd/csrc/dev_prelude.h"]
+                  "blance_amd/csrc/k_period.h", "blance_amd/csrc/k_pass_queue.h", "blance_amd/csrc/dev_prelude.h",
+                  "blance_amd/csrc/k_queue_walk.h"]
 
 
 def source_hash():
