@@ -32,3 +32,5 @@ if [ -f devbuild/libblance_prof.so ]; then
   timeout 300 python tools/dev_general_regime.py > "$out/phase_general_b.log" 2>&1
   grep -c "queue\]" "$out/phase_general_b.log"
 fi
+timeout 1500 python -m pytest tests -q -m gpu > "$out/test_gpu_full.log" 2>&1; grep -E "passed|failed" "$out/test_gpu_full.log" | tail -2
+bash tools/gpu_stress5.sh 150 71000 100 73000 | tail -8
