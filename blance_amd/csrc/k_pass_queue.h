@@ -18,11 +18,10 @@ namespace blance {
 //    its new key is below THETA, inserted at its place (lanes at and above move up one); a 65th entry is
 //    dropped and becomes THETA.  The smallest candidate is lane 0, no reduction over the wave -- k_pass_tree
 //    paid three to four wave minima (two DPP chains each) and a group rescan per moving step.  A window that has
-//    run dry, or whose entries cannot settle a step, is REBUILT from the keys in LDS: first in its striped form
-//    (every lane's smallest key, cut at the smallest of the lanes' second-smallest keys, sorted by a bitonic
-//    network: exact whenever it applies, a sixth of the cost), else by selecting the 65 smallest one by one.
-//    Measured on BASELINE config 5: one rebuild per ~500 moving steps; with many nodes of one load (a
-//    rebalance after nodes left, Zipf weights) one per 64 to 120.
+//    run dry, or whose entries cannot settle a step, is REBUILT from the keys in LDS -- since round 5 by the helper
+//    waves (topl_part below: three waves select the 32 smallest of a third of the nodes each, the lists are merged
+//    below the smallest of their last entries).  Measured on BASELINE config 5: one rebuild per ~500 moving steps;
+//    with many nodes of one load (a rebalance after nodes left, Zipf weights) one per 64 to 120.
 //  * ROW BIT MAPS: "is nodeToNodeCounts[row][n] zero" for the 64 rows of a batch sits in LDS (ntn_bits:
 //    one bit per matrix entry, maintained next to the matrix), so a candidate whose bit is clear has its
 //    exact score = its window key without touching the matrix -- k_pass_tree waited ~1 us for an entry
@@ -141,7 +140,8 @@ namespace blance {
 // command in LDS, joins the barrier, every wave scans its share of the nodes out of the LDS tables (keys, row bits,
 // counters -- all of them already there), leaves its k best (key, node) in LDS, second barrier, wave 0 merges.
 constexpr int kQueueWaves = 4;
-constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdStripe = 2, kQCmdExact = 3;
+constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdTopL = 2, kQCmdExact = 3;
+constexpr int kQTopL = 48;                          // entries each worker selects for the window's rebuild
 constexpr int kQScratch = 5632;                    // bytes the cooperative rebuild needs (aliases rowTag, which only a batch's validation uses)
 constexpr int kQCmdWords = 32, kQResWords = 4;      // a command block; one (key hi, key lo, node, -) result per wave and pick
 
@@ -173,15 +173,14 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     unsigned char* shL = rowTag + RT;                // [NXp] e when the node's score is divided by 2^e (no weight, weight 0: e = 0)
     unsigned short* ntL = (unsigned short*)(shL + NXp);      // [NXp] folded mode: row "" of nodeToNodeCounts
     // the cooperative rebuild's scratch, over rowTag (no rebuild runs between a batch's writes and reads of rowTag)
-    u64* runK = (u64*)rowTag;                        // [2 (kQueueWaves - 1) * 64] the sorted runs: keys ...
-    int* runN = (int*)(runK + 2 * (kQueueWaves - 1) * 64);     // ... and nodes
-    u64* winK = (u64*)(runN + 2 * (kQueueWaves - 1) * 64);     // [64] the new window
+    u64* runK = (u64*)rowTag;                        // [(kQueueWaves - 1) * 64] every worker's sorted list: keys ...
+    int* runN = (int*)(runK + (kQueueWaves - 1) * 64);         // ... and nodes
+    u64* winK = (u64*)(runN + (kQueueWaves - 1) * 64);         // [64] the new window
     int* winN = (int*)(winK + 64);
-    int* thw = winN + 64;                            // [kQueueWaves * 4] every wave's smallest third minimum (hi, lo, node)
-    int* th65 = thw + kQueueWaves * 4;               // [4] the 65th smallest candidate (hi, lo, node)
-    int* cntw = th65 + 4;                            // [kQueueWaves] candidates below the bound, per wave
-    int* thT = cntw + kQueueWaves;                   // [4] the bound T' (hi, lo, node)
-    static_assert(2 * (kQueueWaves - 1) * 64 * 12 + 64 * 12 + kQueueWaves * 16 + 16 + kQueueWaves * 4 + 16 <= kQScratch, "scratch");
+    int* th65 = winN + 64;                           // [4] the 65th smallest entry (hi, lo, node)
+    int* cntw = th65 + 4;                            // [2 * kQueueWaves] per worker: entries of its list; entries below the bound
+    int* thT = cntw + 2 * kQueueWaves;               // [4] the bound T* (hi, lo, node)
+    static_assert((kQueueWaves - 1) * 64 * 12 + 64 * 12 + 16 + 8 * kQueueWaves + 16 <= kQScratch, "scratch");
     int* hcmd = (int*)(ntL + NXp);                   // [kQCmdWords] wave 0's command to the helper waves
     int* hres = hcmd + kQCmdWords;                   // [kQueueWaves * KM * kQResWords] their answers
 
@@ -338,94 +337,103 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             }
         }
     };
-    // ---- the cooperative rebuild (the helper waves between the barriers of a kQCmdStripe command).  Cell (wave, lane) owns
-    // the nodes 64 i + lane of the wave's columns; with m1 <= m2 <= m3 its three smallest (key, node): T' = the smallest m3 of
-    // all cells, candidates = the m1 and m2 below T' -- the window is the 64 smallest of them, the 65th then is THETA, else
-    // T' is.  Every node outside is a candidate >= THETA or lies behind its cell's third: >= m3 >= T' >= THETA -- the
-    // invariant, exactly.  (With the minima alone two of the smallest nodes in one cell cut the window there: ~20 entries
-    // out of 192 cells on scattered keys, and three times the rebuilds; with two per cell it takes three in one cell.)
-    // Each wave sorts its minima and its second minima (bitonic networks over the lanes): 2 (NW - 1) sorted runs; an
-    // element's rank among all candidates is its place in its own run plus, by binary search, the elements of the other
-    // runs in front of it.
-    auto stripe_part = [&]() {
+    // ---- the cooperative rebuild (the helper waves between the barriers of a kQCmdTopL command).  Worker w owns a third of the
+    // columns and selects the kQTopL smallest (key, node) of ITS nodes one by one -- the successive minima of round 4's exact
+    // selection, but 32 of them on each of three waves side by side instead of 65 on one.  With t_w the last of worker w's list
+    // (a worker that ran out of nodes has none), T* = the smallest t_w: a node of worker w that is not in w's list is >= t_w >= T*,
+    // so EVERY node below T* is in one of the lists.  The window = the (at most 64) smallest list entries below T*, THETA = the
+    // 65th of them, else T* -- the invariant, exactly, and never fewer than kQTopL - 1 entries while there are that many nodes
+    // (in practice nearly always all 64: three lists of 32 reach about the 85th smallest node).  The lists are sorted by
+    // construction; an entry's rank among all of them is its place in its own list plus, by binary search, the entries of the
+    // other two in front of it.  (Round 5's first cooperative form -- every lane's three smallest nodes, the window cut at the
+    // first (wave, lane) cell that holds three of the 65 smallest -- came out with fewer than 40 entries more than half of the
+    // time on scattered keys and then fell back to the 73 K-cycle selection on one wave; this form has no fallback.)
+    auto topl_part = [&]() {
         const int NH = NW - 1, hw = wave - 1;
-        const int CJ = (G + NH - 1) / NH, ib = hw * CJ, ie = ib + CJ < G ? ib + CJ : G;
-        u64 b0 = ~0ull, b1 = ~0ull, b2 = ~0ull;     // the cell's three smallest keys (nodes ascend: strict compares keep the lower node in front)
-        int n0 = INT_MAX, n1 = INT_MAX, n2 = INT_MAX;
-        for (int i0 = ib; i0 < ie; i0 += 8) {        // (8 independent LDS reads at a time; no branch)
-            u64 kv[8];
+        // worker hw owns the columns hw, hw + NH, hw + 2 NH, ...: blocks of 64 consecutive node ids go round the workers, so the
+        // workers' lists reach about equally deep into the order whatever the ids of the lowest nodes (contiguous thirds of the id
+        // range did not: with the lowest nodes in one third T* was that worker's 32nd entry and the window came out half full)
+        const int CJ = (G - hw + NH - 1) / NH;      // columns of this worker (local index j: column hw + j NH)
+        constexpr int RC = 4;
+        u64 taken = 0;                               // bit j: node 64 (hw + j NH) + lane is in the list already
+        u64 ca[RC];                                  // the lane's four smallest untaken keys, ascending ...
+        int cm[RC];                                  // ... and their nodes: a column is scanned again only when all four are gone
+        bool exhausted = false;
+        auto scan4 = [&]() {
 #pragma unroll
-            for (int u = 0; u < 8; u++) kv[u] = i0 + u < ie ? gB[(i0 + u) * 64 + lane] : ~0ull;
+            for (int j = 0; j < RC; j++) { ca[j] = ~0ull; cm[j] = INT_MAX; }
+            for (int j0 = 0; j0 < CJ; j0 += 8) {     // (8 independent LDS reads at a time)
+                u64 kv[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const u64 key = kv[u];
-                const int n = (i0 + u) * 64 + lane;
-                const bool lt0 = key < b0, lt1 = key < b1, lt2 = key < b2;
-                b2 = lt1 ? b1 : (lt2 ? key : b2);
-                n2 = lt1 ? n1 : (lt2 ? n : n2);
-                b1 = lt0 ? b0 : (lt1 ? key : b1);
-                n1 = lt0 ? n0 : (lt1 ? n : n1);
-                b0 = lt0 ? key : b0;
-                n0 = lt0 ? n : n0;
-            }
-        }
-        if (b0 == ~0ull) n0 = INT_MAX;               // (no candidate)
-        if (b1 == ~0ull) n1 = INT_MAX;
-        if (b2 == ~0ull) n2 = INT_MAX;
-        // the wave's minima and its second minima, each sorted across the lanes: runs 2 hw and 2 hw + 1
-        u64 sk[2] = {b0, b1};
-        int sn[2] = {n0, n1};
+                for (int u = 0; u < 8; u++) kv[u] = j0 + u < CJ ? gB[(hw + (j0 + u) * NH) * 64 + lane] : ~0ull;
 #pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-                for (int j = k2 >> 1; j > 0; j >>= 1) {
-                    const u64 pk = ((u64)(unsigned)__shfl_xor((int)(unsigned)(sk[c2] >> 32), j, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)sk[c2], j, 64);
-                    const int pn = __shfl_xor(sn[c2], j, 64);
-                    const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
-                    const bool take = keep_min ? qless(pk, pn, sk[c2], sn[c2]) : qless(sk[c2], sn[c2], pk, pn);
-                    sk[c2] = take ? pk : sk[c2];
-                    sn[c2] = take ? pn : sn[c2];
+                for (int u = 0; u < 8; u++) {
+                    u64 v = kv[u];
+                    int n = (hw + (j0 + u) * NH) * 64 + lane;
+                    if (j0 + u >= CJ || ((taken >> (j0 + u)) & 1) || v == ~0ull) continue;
+                    bool placed = false;             // ascending columns: ties keep the lower node in front; what follows moves down
+#pragma unroll
+                    for (int j = 0; j < RC; j++) {
+                        if (placed || v < ca[j]) { const u64 tv = ca[j]; const int tn = cm[j]; ca[j] = v; cm[j] = n; v = tv; n = tn; placed = true; }
+                    }
                 }
             }
-            runK[(2 * hw + c2) * 64 + lane] = sk[c2];
-            runN[(2 * hw + c2) * 64 + lane] = sn[c2];
+            if (cm[0] == INT_MAX) exhausted = true;
+        };
+        scan4();
+        int found = 0;
+        u64 myK = ~0ull;                             // lane e keeps the e-th of the list
+        int myN = INT_MAX;
+        for (int e = 0; e < kQTopL; e++) {
+            const QMin m = wave_min_key_node(ca[0], cm[0]);
+            if (m.node == INT_MAX) break;            // the worker's nodes are used up
+            if (lane == e) { myK = ((u64)m.hi << 32) | m.lo; myN = m.node; }
+            found = e + 1;
+            if (cm[0] == m.node) {
+                taken |= 1ull << (((m.node >> 6) - hw) / NH);
+#pragma unroll
+                for (int j = 0; j + 1 < RC; j++) { ca[j] = ca[j + 1]; cm[j] = cm[j + 1]; }
+                ca[RC - 1] = ~0ull; cm[RC - 1] = INT_MAX;
+            }
+            const bool dry = cm[0] == INT_MAX && !exhausted;
+            if (__ballot(dry)) { if (dry) scan4(); }
         }
-        const QMin t = wave_min_key_node(b2, n2);
-        if (lane == 0) { thw[hw * 4] = (int)t.hi; thw[hw * 4 + 1] = (int)t.lo; thw[hw * 4 + 2] = t.node; }
+        found = uni(found);
+        runK[hw * 64 + lane] = myK;                  // (lanes >= found: (~0, INT_MAX), behind everything)
+        runN[hw * 64 + lane] = myN;
+        if (lane == 0) cntw[hw] = found;
         lds_barrier();                               // (the walking wave passes this one too)
-        u64 tk = ~0ull;
+        u64 tk = ~0ull;                              // T*: the smallest last entry of the full lists
         int tn = INT_MAX;
         for (int w2 = 0; w2 < NH; w2++) {
-            const int xn = thw[w2 * 4 + 2];
-            const u64 xk = ((u64)(unsigned)thw[w2 * 4] << 32) | (unsigned)thw[w2 * 4 + 1];
-            if (xn != INT_MAX && qless(xk, xn, tk, tn)) { tk = xk; tn = xn; }
+            if (cntw[w2] < kQTopL) continue;         // (that worker's list holds all of its nodes: no bound from it)
+            const u64 xk = runK[w2 * 64 + kQTopL - 1];
+            const int xn = runN[w2 * 64 + kQTopL - 1];
+            if (qless(xk, xn, tk, tn)) { tk = xk; tn = xn; }
         }
-        int cw = 0;
+        int rank = lane;
+        for (int w2 = 0; w2 < NH; w2++) {
+            if (w2 == hw) continue;
+            const u64* rk = runK + w2 * 64;
+            const int* rn = runN + w2 * 64;
+            int pos = 0;                             // entries of list w2 in front of this one: lower bound over 64 sorted slots
 #pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            int rank = lane;
-            for (int r2 = 0; r2 < 2 * NH; r2++) {
-                if (r2 == 2 * hw + c2) continue;
-                const u64* rk = runK + r2 * 64;
-                const int* rn = runN + r2 * 64;
-                int pos = 0;                         // elements of run r2 in front of this one: lower bound over 64 sorted entries
-#pragma unroll
-                for (int st = 32; st >= 1; st >>= 1) pos += qless(rk[pos + st - 1], rn[pos + st - 1], sk[c2], sn[c2]) ? st : 0;
-                pos += qless(rk[pos], rn[pos], sk[c2], sn[c2]) ? 1 : 0;
-                rank += pos;
-            }
-            const bool in = sn[c2] != INT_MAX && (tn == INT_MAX || qless(sk[c2], sn[c2], tk, tn));
-            cw += __popcll(__ballot(in));
-            if (in && rank < 64) { winK[rank] = sk[c2]; winN[rank] = sn[c2]; }
-            if (in && rank == 64) { th65[0] = (int)(unsigned)(sk[c2] >> 32); th65[1] = (int)(unsigned)sk[c2]; th65[2] = sn[c2]; }
+            for (int st = 32; st >= 1; st >>= 1) pos += qless(rk[pos + st - 1], rn[pos + st - 1], myK, myN) ? st : 0;
+            pos += qless(rk[pos], rn[pos], myK, myN) ? 1 : 0;
+            rank += pos;
         }
-        if (lane == 0) cntw[hw] = cw;
-        if (hw == 0 && lane == 0) { thT[0] = (int)(unsigned)(tk >> 32); thT[1] = (int)(unsigned)tk; thT[2] = tn; }     // the bound T'
+        const bool in = myN != INT_MAX && (tn == INT_MAX || qless(myK, myN, tk, tn));
+        const int cw = __popcll(__ballot(in));
+        if (in && rank < 64) { winK[rank] = myK; winN[rank] = myN; }
+        if (in && rank == 64) { th65[0] = (int)(unsigned)(myK >> 32); th65[1] = (int)(unsigned)myK; th65[2] = myN; }
+        BLANCE_WAVE_SYNC();
+        if (lane == 0) cntw[kQueueWaves + hw] = cw;  // (cntw[0 .. NH) are still read by the other workers: the counts go behind them)
+        if (hw == 0 && lane == 0) { thT[0] = (int)(unsigned)(tk >> 32); thT[1] = (int)(unsigned)tk; thT[2] = tn; }     // the bound T*
     };
-    // ---- the exact selection (worker 0 alone, when the striped form came out short): 64 + 1 successive minima of the keys
+    // ---- the exact selection (worker 0 alone; a test knob since topl_part: an independent form of the same rebuild): 64 + 1 successive minima of the keys
     // in LDS; lane l owns nodes l, 64 + l, ... (bit i of `taken`: node 64 i + l) and keeps its four smallest untaken keys, so
     // that a column is scanned again only when all four are gone (64 minima over 64 columns: a column with five is rare).
-    // Results as stripe_part leaves them: winK / winN, cntw[0] = entries, th65 = THETA ((~0, INT_MAX): fewer than 65 candidates).
+    // Results: winK / winN, cntw[0] = entries, th65 = THETA ((~0, INT_MAX): fewer than 65 candidates).
     auto exact_part = [&]() {
         constexpr int RC = 4;
         u64 taken = 0;
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             const int op = uni(hcmd[0]);
             if (op == kQCmdExit) break;
             if (op == kQCmdDense) dense_part();
-            if (op == kQCmdStripe) stripe_part();
+            if (op == kQCmdTopL) topl_part();
             if (op == kQCmdExact && wave == 1) exact_part();
             lds_barrier();                           // (2) the answers are in
         }
@@ -536,39 +544,31 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
 #ifdef BLANCE_PHASE_PROF
     long long rb_cycles = 0, rb_scans = 0, rb_scan_cycles = 0;
 #endif
-    int stripe_skip = 0;                             // rebuilds for which the striped form is not tried (it just came out short)
     int rb_wcnt = 0;                                 // entries the last rebuild left: a window that has not drained since is not rebuilt again
-    long long n_striped = 0;
-    // The window is rebuilt by the helper waves (stripe_part; if that comes out short, exact_part): this wave posts the
-    // command, passes the barriers, and loads the new window out of LDS.
+    long long n_coop = 0;
+    // The window is rebuilt by the helper waves (topl_part): this wave posts the command, passes the barriers, and loads the
+    // new window out of LDS.
     auto rebuild = [&]() {
 #ifdef BLANCE_PHASE_PROF
         const long long rb_t0 = clock64();
 #endif
-        bool got = false;
-        if (q.spec & 64) {}                          // (test knob: every rebuild by the exact selection)
-        else if (stripe_skip > 0) stripe_skip--;
-        else {
-            if (lane == 0) hcmd[0] = kQCmdStripe;
+        if (!(q.spec & 64)) {
+            if (lane == 0) hcmd[0] = kQCmdTopL;
             lds_barrier();                           // (1) posted
-            lds_barrier();                           //     (the workers' own: minima sorted, bounds known)
+            lds_barrier();                           //     (the workers' own: their lists are in LDS)
             lds_barrier();                           // (2) done
             int cw = 0;
-            for (int w2 = 0; w2 < NW - 1; w2++) cw += cntw[w2];
+            for (int w2 = 0; w2 < NW - 1; w2++) cw += cntw[kQueueWaves + w2];
             cw = uni(cw);
             const int tn = uni(thT[2]);
-            if (cw >= 40 || tn == INT_MAX) {         // (a short window is exact all the same, it only lasts a few steps; measured: accepting 16 costs regime (b) 3 %)
-                const int wc = cw < 64 ? cw : 64;
-                wk = lane < wc ? winK[lane] : ~0ull;
-                wn = lane < wc ? winN[lane] : INT_MAX;
-                wcnt = uni(wc);
-                if (cw > 64) { thK = uni64(((u64)(unsigned)th65[0] << 32) | (unsigned)th65[1]); thN = uni(th65[2]); }
-                else { thK = uni64(((u64)(unsigned)thT[0] << 32) | (unsigned)thT[1]); thN = tn; }
-                n_striped++;
-                got = true;
-            } else stripe_skip = 16;
-        }
-        if (!got) {
+            const int wc = cw < 64 ? cw : 64;
+            wk = lane < wc ? winK[lane] : ~0ull;
+            wn = lane < wc ? winN[lane] : INT_MAX;
+            wcnt = uni(wc);
+            if (cw > 64) { thK = uni64(((u64)(unsigned)th65[0] << 32) | (unsigned)th65[1]); thN = uni(th65[2]); }
+            else { thK = uni64(((u64)(unsigned)thT[0] << 32) | (unsigned)thT[1]); thN = tn; }
+            n_coop++;
+        } else {                                     // (test knob: the exact selection of 65 minima on one helper wave)
             if (lane == 0) hcmd[0] = kQCmdExact;
             lds_barrier();
             lds_barrier();
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     }
 #ifdef BLANCE_PHASE_PROF
     if (lane == 0) {
-        printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld (striped %lld)\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild, n_striped);
+        printf("[queue] k %d steps [%d, %d) stop %d why %d: stays %lld moved %lld exact %lld dense %lld rebuilds %lld (by three waves %lld)\n", k, q.beg, q.end, stop_pos, stop_why, n_bulk, n_moved, n_exact, n_dense, n_rebuild, n_coop);
         for (int i_ = 0; i_ < 17; i_++) printf("[queue phase %d] %.0f kcycles\n", i_, (double)ph_acc[i_] / 1e3);
         printf("[queue rebuilds] %.0f kcycles, %lld column scans of lane 0 (first scans: %.0f kcycles)\n", (double)rb_cycles / 1e3, rb_scans, (double)rb_scan_cycles / 1e3);
     }
