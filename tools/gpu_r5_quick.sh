@@ -15,6 +15,7 @@ r = pl.plan(fp)
 print("regime (b): sweeps %d device %.1f ms digest ok %s" % (r.iterations, r.struct.device_ms, r.digest() == want), flush=True)
 PY
 tail -2 gpurun_out/r5/regime_b_$T.log
+timeout 300 python tools/dev_rebalance_regime.py 2> /dev/null | tail -3
 BLANCE_QUEUE_STATS=1 timeout 600 python tools/config5_gpu.py > gpurun_out/r5/config5_$T.log 2>&1
 grep "k_pass_queue\|device\|matches" gpurun_out/r5/config5_$T.log
 timeout 300 python bench.py --steps 5 --warmup 2 --no-other-configs --no-extra --no-cpu-baseline --no-sharded --no-live-pmc > gpurun_out/r5/bench_short_$T.log 2>&1
