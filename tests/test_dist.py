@@ -64,6 +64,7 @@ def test_sharded_plan_world_size_2(tmp_path):
         assert got[0].struct.steps_batched > 0
         assert len(calls) >= 2 * (3 + 3 + 3 + 2), calls                 # every hierarchical case did shard
         assert sharded.comm_stats()[0] == len(calls)
+        assert sharded.comm_time_ms() == 0.0                            # (an embedder's collectives run on the host: no RCCL time)
         # the rebalance from the sharded plan (events, nodes outside their region) as well
         plan1, _ = problem.decode_result(cases[-1], got[-1])
         fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)

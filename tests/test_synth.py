@@ -58,3 +58,18 @@ def test_named_weighted_flat_equals_interned(P, N):
     assert a.scalars == b.scalars
     for k in abi.I32_FIELDS + abi.U8_FIELDS:
         assert np.array_equal(a.arrays[k], b.arrays[k]), k
+
+
+def test_rotated_instances_of_config3_plan_to_the_same_ids():
+    """bench.py --gpus N: rank r plans config 3 with nodesAll starting 512 r names further on.  For a rotation by whole zones
+    (128 names) every per-node hierarchy table differs from the unrotated instance's, zones and racks stay aligned blocks of
+    ids, and the plan -- as ids -- is the same, so every rank's digest can be held against the oracle's; a rotation that is
+    not a multiple of the zone size gives another plan."""
+    from oracle import loader
+    base = synth.config_flat(3, P=8192, N=512)
+    rot = synth.config_flat(3, P=8192, N=512, rotate=256)
+    assert (base.arrays["node_leaf_pos"] != rot.arrays["node_leaf_pos"]).any()
+    assert (base.arrays["vertex_parent"] != rot.arrays["vertex_parent"]).any()
+    want = loader.plan(base).digest()
+    assert loader.plan(rot).digest() == want
+    assert loader.plan(synth.config_flat(3, P=8192, N=512, rotate=48)).digest() != want
