@@ -426,11 +426,7 @@ def main():
                 return min(ups[1:]), min(downs[1:]), r_.digest()
             up_pg, down_pg, d_pg = again(fp, None)
             arena = hip.HostArena()
-            import copy
-            fpp = copy.copy(fp)
-            fpp.arrays = dict(fp.arrays)
-            fpp._struct = None
-            fpp.pin(arena)
+            fpp = fp.pin(arena)
             up_pin, down_pin, d_pin = again(fpp, arena)
             nb = sum(a.nbytes for a in fp.arrays.values())
             ob = res.out_off.nbytes + res.out_nodes.nbytes + res.out_kind.nbytes

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -62,6 +62,7 @@ class Result(C.Structure):
         ("flat_pass_ms", C.c_double), ("flat_passes", C.c_int64),
         ("blank_pass_ms", C.c_double), ("blank_pass_launches", C.c_int64),
         ("stay_pass_ms", C.c_double), ("stay_pass_launches", C.c_int64),
+        ("host_syncs", C.c_int64),
     ]
 
 
@@ -147,15 +148,15 @@ class FlatProblem:
         return self._struct
 
     def pin(self, arena):
-        """Move every array into page-locked memory of `arena` (hip.HostArena): blance_upload then copies by DMA from where
-        they lie instead of staging them."""
-        for n in list(self.arrays):
-            a = self.arrays[n]
-            if a.size:
-                self.arrays[n] = arena.copy_of(a)
-        self._struct = None
-        self._arena = arena
-        return self
+        """A copy of this problem with every array in page-locked memory of `arena` (hip.HostArena): blance_upload then copies
+        by DMA from where they lie instead of staging them.  This problem itself is left as it is."""
+        import copy
+        q = copy.copy(self)
+        q.scalars = dict(self.scalars)
+        q.arrays = {n: (arena.copy_of(a) if a.size else a) for n, a in self.arrays.items()}
+        q._struct = None
+        q._keep = []
+        return q
 
     def result_capacity(self):
         P, M = self.scalars["n_parts"], self.scalars["n_states"]

@@ -8,6 +8,7 @@
 #include "dev_prelude.h"
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
@@ -109,6 +110,15 @@ void pin_free(void* p) {
     }
     (void)hipHostFree(p);
 }
+void pin_trim() {
+    std::vector<PinBlock> drop;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        drop.swap(g_pin_free);
+        g_pin_cached = 0;
+    }
+    for (const PinBlock& b : drop) (void)hipHostFree(b.p);
+}
 // does [p, p + bytes) lie in page-locked memory the device can copy from / to directly?
 bool host_ptr_pinned(const void* p, size_t bytes) {
     const uintptr_t a = (uintptr_t)p;
@@ -122,9 +132,13 @@ bool host_ptr_pinned(const void* p, size_t bytes) {
     }
 #ifndef BLANCE_SIMT_EMU
     if (bytes >= ((size_t)1 << 20)) {                // (memory the caller registered itself: worth a query for big arrays only)
-        hipPointerAttribute_t at;
+        // both ends: an array that only starts inside a registered range is not DMA'd as if all of it were page-locked
+        hipPointerAttribute_t at, at_end;
         if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-        return at.type == hipMemoryTypeHost;
+        if (at.type != hipMemoryTypeHost) return false;
+        if (hipPointerGetAttributes(&at_end, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at_end.type == hipMemoryTypeHost && at_end.hostPointer != nullptr && at.hostPointer != nullptr &&
+               (const char*)at_end.hostPointer - (const char*)at.hostPointer == (ptrdiff_t)(bytes - 1);
     }
 #endif
     return false;
@@ -166,6 +180,8 @@ void copy_threaded(const std::vector<CopySeg>& segs) {
 
 extern "C" void* blance_host_alloc(size_t bytes) { return pin_alloc(bytes); }
 extern "C" void blance_host_free(void* p) { pin_free(p); }
+extern "C" void blance_host_trim(void) { pin_trim(); }
+static std::atomic<int> g_live_contexts{0};
 
 struct HostStage {                                   // a page-locked staging buffer of the context
     void* p = nullptr;
@@ -199,6 +215,7 @@ struct blance_ctx {
     int chain_group_state = -1;     // the state whose chain pass last grouped the steps by region (chain_order, chain_oi, reg_off) ...
     bool chain_group_static = false; // ... and whether it did so from the static order (sweeps >= 2)
     bool tops_moved = true;         // this sweep's top-state pass was not (known to be) one run of stays
+    bool top_prio_strict = false;   // every other state with constraints > 0 has a priority strictly behind the top state's
     bool trace = false;             // BLANCE_TRACE, read once at context creation
     int dump_sweep = -1;            // BLANCE_DUMP_SWEEP (developer aid), likewise
     DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
@@ -215,6 +232,7 @@ struct blance_ctx {
     std::vector<hipEvent_t> comm_events;     // begin / end pairs around the collectives of the current plan (RCCL path)
     size_t comm_events_used = 0;
     double comm_ms = 0.0;                    // device time between those pairs, all plans so far
+    int64_t n_syncs = 0, plan_syncs = 0;     // stream_sync() calls so far / inside the last plan
 
     // host copy of the small parts of the problem
     blance_problem h{};
@@ -234,6 +252,8 @@ struct blance_ctx {
     bool queue_no_asm = false;      // test knob (& 4096): k_pass_queue's lean walk as compiled C++ only
     bool queue_force_dense = false; // test knob (& 2048): every general step of k_pass_queue scores every node
     bool queue_exact_rebuild = false; // test knob (& 8192): k_pass_queue's window always rebuilt by the exact selection
+    bool shard_one_rank = false;    // test knob (& 16384): a communicator of ONE rank takes the sharded branch of a chain pass, so that
+                                    // both collectives really execute (ncclAllReduce / ncclAllGather on a one-GPU box)
     DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
     bool bits_stale = false;        // another kernel bumped the matrix in this pass: k_ntn_bits before k_pass_queue goes on
     // nodeToNodeCounts (67 MB at config 3) is zeroed lazily: only a pass that reads or bumps the matrix in HBM pays for it
@@ -488,6 +508,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->queue_force_dense = opt && (opt->reserved[2] & 2048);
     c->queue_no_asm = opt && (opt->reserved[2] & 4096);
     c->queue_exact_rebuild = opt && (opt->reserved[2] & 8192);
+    c->shard_one_rank = opt && (opt->reserved[2] & 16384);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->periodic = !(opt && (opt->reserved[2] & 256));
@@ -501,6 +522,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
         return fail(BLANCE_ERR_DEVICE, "stream/event creation failed");
     }
     *out = c;
+    g_live_contexts++;
     return BLANCE_OK;
 }
 
@@ -516,6 +538,7 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    if (--g_live_contexts == 0) pin_trim();          // the process's last context: the cache of page-locked blocks goes too
 }
 
 constexpr size_t kRbBytes = 64 * 1024;
@@ -533,12 +556,27 @@ static hipError_t read_back(blance_ctx* c, void* dst, const void* dev, size_t by
     return hipSuccess;
 }
 static hipError_t stream_sync(blance_ctx* c) {
+    c->n_syncs++;
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess)
         for (const blance_ctx::RbItem& it : c->rb_items) memcpy(it.dst, (const char*)c->rb_buf + it.off, it.bytes);
     c->rb_items.clear();
     c->rb_used = 0;
     return e;
+}
+
+// An entry point's error exit: nothing is in flight any more (no DMA into the caller's arrays after the call returns) and
+// no read-back is left queued -- its destination is a local of a frame that is gone by now, so it is dropped, not copied.
+static void rb_discard(blance_ctx* c) {
+    c->rb_items.clear();
+    c->rb_used = 0;
+}
+static int settle(blance_ctx* c, int st) {
+    if (st) {
+        if (c->stream && hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();
+        rb_discard(c);
+    }
+    return st;
 }
 
 // ---- host <-> device copies.  An array in page-locked memory (blance_host_alloc, or registered by the caller) is copied by
@@ -633,9 +671,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb);
 // copies may still be reading the caller's arrays (and the staging buffer) when an
 // error cuts the upload short: never return with copies in flight
 static int upload_locked(blance_ctx* c, const blance_problem* pb) {
-    int st = upload_inner(c, pb);
-    if (st && c->stream) (void)stream_sync(c);
-    return st;
+    rb_discard(c);                                   // (left behind by a call that ended in an exception)
+    return settle(c, upload_inner(c, pb));
 }
 
 static int upload_inner(blance_ctx* c, const blance_problem* pb) {
@@ -650,6 +687,9 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     c->state_priority.assign(pb->state_priority, pb->state_priority + M);
     c->state_constraints.assign(pb->state_constraints, pb->state_constraints + M);
     c->rule_off.assign(pb->rule_off, pb->rule_off + M + 1);
+    c->top_prio_strict = M > 0;
+    for (int m = 0; m < M; m++)
+        if (m != pb->top_state && pb->state_priority[m] <= pb->state_priority[pb->top_state]) c->top_prio_strict = false;
     std::vector<uint8_t> alive((size_t)NX + 1, 0);
     c->n_alive = 0;
     c->any_removed = 0;
@@ -1407,7 +1447,7 @@ static void comm_sum_up(blance_ctx* c) {            // (after the stream has bee
 
 // in-place int32 sum over the ranks, ordered with the kernels of the planner's stream
 static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
-    if (c->comm.n_ranks <= 1 || n <= 0) return 0;
+    if ((c->comm.n_ranks <= 1 && !c->shard_one_rank) || n <= 0) return 0;
     c->comm_calls++;
     c->comm_bytes += n * 4;
     if (c->comm.allreduce_sum_i32) {
@@ -1429,7 +1469,7 @@ static int comm_allreduce(blance_ctx* c, int32_t* buf, int64_t n) {
 
 // in-place all-gather of n_ranks blocks of `per_rank` int32 values (this rank's block filled in)
 static int comm_allgather(blance_ctx* c, int32_t* buf, int64_t per_rank) {
-    if (c->comm.n_ranks <= 1 || per_rank <= 0) return 0;
+    if ((c->comm.n_ranks <= 1 && !c->shard_one_rank) || per_rank <= 0) return 0;
     c->comm_calls++;
     c->comm_bytes += per_rank * 4 * c->comm.n_ranks;
     if (c->comm.allreduce_sum_i32) {
@@ -1505,7 +1545,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     blance_ctx::RuleRegions& rr = c->rule_regions[a.r0];
     const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
     const int G = c->comm.n_ranks, rank = c->comm.rank;
-    const bool sharded = G > 1 && B >= G;
+    const bool sharded = (G > 1 || c->shard_one_rank) && B >= G;
     HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
     BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P + 1, 256), 256, 0, sm, d, m, h.top_state,
                          a.order, rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
@@ -1835,6 +1875,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     c->queue_launches = c->queue_stops = 0;
     c->comm_events_used = 0;
     c->chain_group_state = -1;
+    const int64_t syncs0 = c->n_syncs;
 
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 256, sm));
@@ -1908,11 +1949,14 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             bool done = false;
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
                 c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
-                ChainPassArgs ca{d, m, k, NP, OW, RW, higher_mask, r0, it, order, !first && !c->tops_moved && m != h.top_state};
+                // (same_tops: the top state's pass was one run of stays AND no other state can take a partition's top priority
+                // node away in between -- plan.go:146-154 keeps only nodes of STRICTLY higher priority states out of a pass)
+                ChainPassArgs ca{d, m, k, NP, OW, RW, higher_mask, r0, it, order,
+                                 !first && !c->tops_moved && m != h.top_state && c->top_prio_strict};
                 bool a_done = false;
                 const int e = run_chain_pass(c, ca, &launches, &batched, &n_pass, &done, &a_done);
                 if (e) {
-                    const bool sharded = c->comm.n_ranks > 1 && c->rule_regions[r0].n_regions >= c->comm.n_ranks;
+                    const bool sharded = (c->comm.n_ranks > 1 || c->shard_one_rank) && c->rule_regions[r0].n_regions >= c->comm.n_ranks;
                     if (sharded && !a_done) comm_poison(c);       // the other ranks are (or will be) in collective A
                     if (sharded) comm_abort(c);
                     return e;
@@ -2048,6 +2092,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     c->iterations = iterations;
     c->converged = converged;
     c->device_ms = ms;
+    c->plan_syncs = c->n_syncs - syncs0;
     c->steps_total = steps;
     c->steps_batched = batched;
     c->kernel_launches = launches;
@@ -2071,6 +2116,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         res->blank_pass_launches = n_blank;
         res->stay_pass_ms = stay_ms;
         res->stay_pass_launches = n_stay;
+        res->host_syncs = c->plan_syncs;
     }
     return BLANCE_OK;
 }
@@ -2137,6 +2183,7 @@ static int download_locked(blance_ctx* c, blance_result* res) {
     res->blank_pass_launches = c->blank_launches;
     res->stay_pass_ms = c->stay_ms;
     res->stay_pass_launches = c->stay_launches;
+    res->host_syncs = c->plan_syncs;
     return BLANCE_OK;
 }
 
@@ -2224,7 +2271,8 @@ extern "C" int blance_plan_resident(blance_ctx* c, blance_result* res) {
     return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
-    return plan_locked(c, res);
+    rb_discard(c);
+    return settle(c, plan_locked(c, res));
     });
 }
 
@@ -2286,7 +2334,8 @@ extern "C" int blance_download(blance_ctx* c, blance_result* res) {
     return guarded([&]() -> int {
     if (!c) return fail(BLANCE_ERR_BAD_ARG, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
-    return download_locked(c, res);
+    rb_discard(c);
+    return settle(c, download_locked(c, res));
     });
 }
 
@@ -2301,8 +2350,8 @@ extern "C" int blance_plan(blance_ctx* c, const blance_problem* pb, blance_resul
     HIPTRY(hipEventCreate(&t1));
     HIPTRY(hipEventRecord(t0, c->stream));
     int st = upload_locked(c, pb);
-    if (!st) st = plan_locked(c, res);
-    if (!st) st = download_locked(c, res);
+    if (!st) st = settle(c, plan_locked(c, res));
+    if (!st) st = settle(c, download_locked(c, res));
     if (!st) {
         (void)hipEventRecord(t1, c->stream);
         (void)hipEventSynchronize(t1);

@@ -782,6 +782,16 @@ void build(Flat& f, const PartitionMap* prevMapIn, const PartitionMap& assign, c
 bool Library::open(const std::string& path, std::string* err) {
     handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!handle) { if (err) *err = dlerror(); return false; }
+    // the structs of include/blance_hip.h are written by the library: one built against another ABI would write past (or
+    // short of) this program's blance_result
+    int (*abi_version)(void) = (int (*)(void))dlsym(handle, "blance_abi_version");
+    if (!abi_version || abi_version() != BLANCE_ABI_VERSION) {
+        if (err) *err = "library ABI " + (abi_version ? std::to_string(abi_version()) : std::string("unknown")) +
+                        ", this program was built for ABI " + std::to_string(BLANCE_ABI_VERSION);
+        dlclose(handle);
+        handle = nullptr;
+        return false;
+    }
     Abi a;
     a.validate = (int (*)(const blance_problem*))dlsym(handle, "blance_validate");
     a.result_capacity = (int64_t (*)(const blance_problem*))dlsym(handle, "blance_result_capacity");

@@ -18,7 +18,7 @@ EXPORTS = ["blance_abi_version", "blance_last_error", "blance_result_capacity", 
            "blance_ctx_create", "blance_ctx_destroy", "blance_plan", "blance_upload",
            "blance_plan_resident", "blance_download", "blance_calc_moves", "blance_plan_stats_get",
            "blance_comm_unique_id", "blance_comm_init_rccl", "blance_comm_set", "blance_comm_stats",
-           "blance_is_emulated", "blance_host_alloc", "blance_host_free", "blance_comm_time_ms"]
+           "blance_is_emulated", "blance_host_alloc", "blance_host_free", "blance_comm_time_ms", "blance_host_trim"]
 
 _libs = {}
 
@@ -76,29 +76,50 @@ def load_library(path=None):
     lib.blance_host_alloc.argtypes = [C.c_size_t]
     lib.blance_host_free.restype = None
     lib.blance_host_free.argtypes = [C.c_void_p]
+    lib.blance_host_trim.restype = None
+    lib.blance_host_trim.argtypes = []
     if lib.blance_abi_version() != abi.ABI_VERSION:
         raise ImportError("ABI version mismatch")
     _libs[path] = lib
     return lib
 
 
+class _PinnedBlock:
+    """One block of blance_host_alloc; goes back to the library when the last numpy view of it is collected."""
+
+    def __init__(self, lib, nbytes):
+        self.lib = lib
+        self.p = lib.blance_host_alloc(nbytes)
+        if not self.p:
+            raise MemoryError("blance_host_alloc(%d) failed" % nbytes)
+
+    def __del__(self):
+        try:
+            if self.p:
+                self.lib.blance_host_free(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+
 class HostArena:
     """Page-locked host arrays from blance_host_alloc (include/blance_hip.h, ABI 5): numpy views the device copies from / to
-    by DMA where they lie.  The blocks go back to the library when the arena is closed or collected."""
+    by DMA where they lie.  Every array keeps its block alive (the ctypes buffer it is a view of owns the block), so an array
+    that outlives the arena -- a result kept after the arena is closed -- never aliases a block that was handed out again;
+    a block goes back to the library when its last view is collected."""
 
     def __init__(self, lib_path=None):
         self.lib = load_library(lib_path)
-        self._blocks = []
+        self.n_blocks = 0
 
     def empty(self, n, dtype):
         import numpy as np
         dt = np.dtype(dtype)
         nbytes = max(int(n), 1) * dt.itemsize
-        p = self.lib.blance_host_alloc(nbytes)
-        if not p:
-            raise MemoryError("blance_host_alloc(%d) failed" % nbytes)
-        self._blocks.append(p)
-        buf = (C.c_char * nbytes).from_address(p)
+        block = _PinnedBlock(self.lib, nbytes)
+        buf = (C.c_char * nbytes).from_address(block.p)
+        buf._block = block                                  # the view's base owns the block
+        self.n_blocks += 1
         return np.frombuffer(buf, dtype=dt, count=int(n))
 
     def copy_of(self, arr):
@@ -107,22 +128,15 @@ class HostArena:
         return a
 
     def close(self):
-        for p in self._blocks:
-            self.lib.blance_host_free(p)
-        self._blocks = []
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """Kept for callers of the earlier interface: the blocks are owned by the arrays, nothing to release here."""
 
 
 class Planner:
     """One blance_ctx: a planner bound to one gfx950 device."""
 
     def __init__(self, device_id=0, engine=abi.ENGINE_AUTO, lib_path=None, force_threads=0,
-                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True, stay_top="auto", periodic=True, queue=True):
+                 chain_min_parts=0, seq_speculation=True, tree="auto", planes=True, stay_top="auto", periodic=True, queue=True,
+                 shard_one_rank=False):
         self.lib = load_library(lib_path)
         opt = abi.Options()
         opt.engine = engine
@@ -142,9 +156,11 @@ class Planner:
         # 2048 = ... and every general step of it scoring every node; 4096 = its lean walk as compiled C++ only (the device
         # build walks the plain k = 2 steps in hand-written assembly, k_queue_walk.h); 8192 = its window always rebuilt by the
         # exact selection (one helper wave), never by the helper waves' striped form
+        # 16384 = a communicator of ONE rank takes the sharded branch of every chain pass (both collectives execute:
+        # how ncclAllReduce / ncclAllGather run on a one-GPU box)
         qbits = {True: 0, "on": 0, False: 512, "off": 512, "general": 1024, "dense": 1024 | 2048, "lean-cpp": 4096,
                  "exact-rebuild": 8192}[queue]
-        opt.reserved[2] = qbits | (0 if periodic else 256) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
+        opt.reserved[2] = qbits | (16384 if shard_one_rank else 0) | (0 if periodic else 256) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
         self._check(self.lib.blance_ctx_create(C.byref(opt), C.byref(h)))
@@ -178,6 +194,14 @@ class Planner:
         ident = C.create_string_buffer(box[0], 128)
         self._check(self.lib.blance_comm_init_rccl(self._h, world, rank, ident))
         return world
+
+    def comm_init_rccl_one_rank(self):
+        """A RCCL communicator of this one rank (no torch.distributed needed).  With Planner(shard_one_rank=True) the
+        chain passes then take their sharded branch and really issue ncclAllReduce / ncclAllGather."""
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.blance_comm_unique_id(buf))
+        self._check(self.lib.blance_comm_init_rccl(self._h, 1, 0, buf))
+        return 1
 
     def comm_set_callback(self, rank, n_ranks, allreduce, allgather=None):
         """An embedder's collectives: allreduce(address, count) sums `count` int32 values in place over the

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define BLANCE_ABI_VERSION 5
+#define BLANCE_ABI_VERSION 6
 
 /* status codes */
 #define BLANCE_OK                0
@@ -191,6 +191,9 @@ typedef struct blance_result {
      * all-blank part is k_pass_chain (hierarchy-rule states) or k_pass_queue / k_pass_tree / k_pass_seq (flat states) */
     double   stay_pass_ms;
     int64_t  stay_pass_launches;
+    /* out (ABI 6): stream synchronisations the host made inside this plan (each one reads a few flag words that decide what
+     * is launched next; the device idles for the round trip) */
+    int64_t  host_syncs;
 } blance_result;
 
 typedef struct blance_options {
@@ -200,7 +203,10 @@ typedef struct blance_options {
                                * 1024), [1] smallest pass handed to the bulk engines, [2] & 1 = k_pass_seq without
                                * verified-stay speculation (further bits of [2]: blance_amd/hip.py).
                                * & 256 = the all-blank chain pass WITHOUT its periodic form (csrc/k_period.h, on by
-                               * default since round 4; the environment's BLANCE_PERIODIC=0 does the same)       */
+                               * default since round 4; the environment's BLANCE_PERIODIC=0 does the same);
+                               * & 16384 = a communicator of ONE rank takes the sharded branch of every chain pass:
+                               * both collectives of "one plan on several GPUs" below execute (how ncclAllReduce /
+                               * ncclAllGather are exercised and timed on a one-GPU machine)                      */
 } blance_options;
 
 typedef struct blance_ctx blance_ctx;   /* opaque: device buffers, stream, events */
@@ -233,6 +239,10 @@ int blance_download(blance_ctx* ctx, blance_result* res);
  * after the call returns.  NULL when the runtime cannot provide the memory (use malloc then). */
 void* blance_host_alloc(size_t bytes);
 void blance_host_free(void* p);
+/* (ABI 6) Freed blocks are cached for the next blance_host_alloc -- up to 2 GiB of page-locked, unswappable memory per
+ * process.  blance_host_trim() returns every cached block to the system now; the destruction of a process's last context
+ * does the same.  Blocks the caller still holds are not touched. */
+void blance_host_trim(void);
 
 /* ---- CalcPartitionMoves for every partition at once (moves.go:41-136) ---------
  * The planner's consumer (orchestrate.go:273-287 calls it per partition): the

@@ -114,6 +114,39 @@ def test_sharded_plan_threads_one_process():
             pl.close()
 
 
+def test_one_rank_takes_the_sharded_branch():
+    """Planner(shard_one_rank=True): a communicator of ONE rank runs the sharded branch of every chain pass -- collective A
+    (all-reduce of [flags | load change]) and B (all-gather of the one slice) are both made, in that order, and the plan is
+    the single-rank plan.  On the device the same knob is how ncclAllReduce / ncclAllGather execute on a one-GPU box
+    (tests/test_hip_parity.py::test_rccl_one_rank_runs_both_collectives)."""
+    from blance_amd import dist_util, hip
+    from oracle import loader
+    from test_simt_emulated import build_emu
+    from helpers import sharded_cases
+    emu = build_emu()
+    cases, _, _ = sharded_cases()
+    pl = hip.Planner(lib_path=emu, chain_min_parts=8, shard_one_rank=True)
+    grp = dist_util.LocalGroup(1, True)
+    ar, ag = grp.rank_collectives(0)
+    kinds = []
+    pl.comm_set_callback(0, 1, lambda p, n: (kinds.append("reduce"), ar(p, n)), lambda p, n: (kinds.append("gather"), ag(p, n)))
+    for i, fp in enumerate(cases):
+        before = len(kinds)
+        got = pl.plan(fp)
+        assert got.digest() == loader.plan(fp).digest(), i
+        mine = kinds[before:]
+        assert mine == ["reduce", "gather"] * (len(mine) // 2), mine
+        assert len(mine) <= 2 * got.iterations
+    assert len(kinds) >= 2 * (3 + 3 + 3 + 2) and pl.comm_stats()[0] == len(kinds)
+    pl.close()
+    # without the knob a communicator of one rank makes no collective at all
+    pl = hip.Planner(lib_path=emu, chain_min_parts=8)
+    pl.comm_set_callback(0, 1, lambda p, n: kinds.append("x"), lambda p, n: kinds.append("x"))
+    n = len(kinds)
+    assert pl.plan(cases[0]).digest() == loader.plan(cases[0]).digest() and len(kinds) == n and pl.comm_stats()[0] == 0
+    pl.close()
+
+
 def test_max_over_ranks_world_size_2(tmp_path):
     out = _run_world2(tmp_path, """
         import os, sys

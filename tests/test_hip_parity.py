@@ -363,6 +363,45 @@ def test_region_chain_envelope_edges(planner):
     _same(planner.plan(fp), _oracle(fp), "regions of 640 leaves")
 
 
+@pytest.mark.parametrize("which", ["planner", "eager_planner"])
+def test_general_regime_b_reduced(request, which):
+    """bench.py's general regime (b) in pytest: config 3's model, tree and rule {2,1} with scrambled
+    NON-NUMERIC partition names (plan.go:525-528: the raw name is the key) and Zipf partition weights, 65,536 x 1,024 --
+    through the string interning (config3_named_weighted_case -> problem.build_problem) AND as the flat generator bench.py
+    uses; both must be the same problem and give the oracle's result (10 sweeps, not converged: weighted chain passes with
+    general steps + the weighted flat primary pass on k_pass_queue in its tie regime)."""
+    pl = request.getfixturevalue(which)
+    P, N = 65536, 1024
+    fp = synth.config3_named_weighted_flat(P, N)
+    want = _oracle(fp)
+    assert want.iterations == 10 and not want.converged
+    got = pl.plan(fp)
+    _same(got, want, "regime (b), flat generator")
+    assert got.struct.steps_batched > 0
+    fps = synth.case_to_flat(synth.config3_named_weighted_case(P, N))
+    for n in ("part_order", "part_weight", "part_has_weight", "vertex_leaf_lo", "vertex_leaf_hi", "node_leaf_pos"):
+        assert np.array_equal(fps.arrays[n], fp.arrays[n]), n
+    _same(pl.plan(fps), want, "regime (b), through the interning layer")
+
+
+@pytest.mark.parametrize("which", ["planner", "eager_planner"])
+def test_config3_with_node_weights_reduced(request, which):
+    """Config 3 with NodeWeights in {1, 1, 2, 4} on its hierarchy (plan.go:675-679: the score divided by the weight -- no
+    packed keys, no plane automaton: k_pass_chain's general path with weights), 65,536 x 1,024: the fresh plan, and the
+    rebalance of it after every tenth node left (events + weighted folded batches of k_pass_queue)."""
+    import literal_cases as L
+    pl = request.getfixturevalue(which)
+    P, N = 65536, 1024
+    c = synth.config_case(3, P=P, N=N)
+    c["nodeWeights"] = L.node_weights_1124(N)
+    fp = synth.case_to_flat(c)
+    want = _oracle(fp)
+    got = pl.plan(fp)
+    _same(got, want, "config 3 + node weights")
+    fp2 = synth.config3_rebalance_flat(fp, want)
+    _same(pl.plan(fp2), _oracle(fp2), "config 3 + node weights, rebalanced")
+
+
 def test_rccl_communicator_of_one_rank(planner):
     """blance_comm_unique_id / blance_comm_init_rccl on the device (librccl.so bound at run time): a communicator of one
     rank, after which plans run as before (the multi-rank exchange is covered on gloo by tests/test_dist.py)."""
@@ -382,6 +421,48 @@ def test_rccl_communicator_of_one_rank(planner):
     assert pl.comm_init_rccl(OneRank) == 1
     fp = synth.config_flat(3, P=4096, N=512)
     _same(pl.plan(fp), _oracle(fp), "after comm_init_rccl")
+    pl.close()
+
+
+def test_rccl_one_rank_runs_both_collectives():
+    """The RCCL transport itself on the one GPU there is: with Planner(shard_one_rank=True) a communicator of one rank takes
+    the sharded branch of every chain pass, so ncclAllReduce (collective A: [flags | load-vector change]) and ncclAllGather
+    (collective B: the output slice) really execute on the planner's stream -- dlsym'd signatures, enum values, in-place
+    semantics, stream ordering, the event pairs of blance_comm_time_ms.  Config 3's generator at 65,536 x 4,096 (32 regions):
+    the oracle's result, two collectives per chain pass (= per sweep), device time inside them > 0."""
+    fp = synth.config_flat(3, P=65536, N=4096)
+    want = _oracle(fp)
+    pl = hip.Planner(device_id=0, shard_one_rank=True)
+    assert pl.comm_init_rccl_one_rank() == 1
+    for rep in range(2):
+        calls0, words0 = pl.comm_stats()
+        ms0 = pl.comm_time_ms()
+        got = pl.plan(fp)
+        _same(got, want, ("one-rank RCCL plan", rep))
+        calls1, words1 = pl.comm_stats()
+        assert calls1 - calls0 == 2 * got.iterations, (calls0, calls1, got.iterations)
+        # A: 16 header words + (M + 1) x NX loads; B: the whole output (one slice), 1 + k words per step
+        a_words = 16 + (fp.n_states + 1) * fp.n_nodes_ext
+        assert words1 - words0 == got.iterations * (a_words + fp.n_parts * 3), (words1 - words0, a_words)
+        assert pl.comm_time_ms() > ms0
+    per_call_us = pl.comm_time_ms() * 1e3 / pl.comm_stats()[0]
+    assert 0.5 < per_call_us < 50000, per_call_us
+    pl.close()
+    # a weighted hierarchical plan and its rebalance (events: nodes outside their partition's region) the same way
+    c = synth.rebalance_case(P=20000, N=1024, hierarchy=True)
+    fresh = {p: {"name": p, "nodesByState": {}} for p in c["partitions"]}
+    opts = dict(partition_weights=c["partitionWeights"], state_stickiness=c["stateStickiness"],
+                node_weights=c["nodeWeights"], node_hierarchy=c["nodeHierarchy"], hierarchy_rules=c["hierarchyRules"])
+    fp1 = problem.build_problem({}, fresh, c["oldNodes"], [], c["oldNodes"], c["model"], **opts)
+    w1 = _oracle(fp1)
+    plan1, _ = problem.decode_result(fp1, w1)
+    fp2 = problem.build_problem(plan1, plan1, c["nodesAll"], c["nodesToRemove"], c["nodesToAdd"], c["model"], **opts)
+    pl = hip.Planner(device_id=0, shard_one_rank=True)
+    pl.comm_init_rccl_one_rank()
+    _same(pl.plan(fp1), w1, "weighted hierarchical plan over one-rank RCCL")
+    n1 = pl.comm_stats()[0]
+    _same(pl.plan(fp2), _oracle(fp2), "its rebalance over one-rank RCCL")
+    assert n1 > 0 and pl.comm_stats()[0] > n1
     pl.close()
 
 

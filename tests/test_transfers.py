@@ -52,6 +52,53 @@ def test_host_alloc_blocks_are_reused(emu_lib):
     lib.blance_host_free(C.c_void_p(12345))                  # not one of the library's: ignored
 
 
+def test_host_trim_and_last_context_release_the_cache(emu_lib):
+    """(ABI 6) blance_host_trim() returns the cached page-locked blocks to the system; so does the destruction of the
+    process's last context.  Blocks the caller still holds stay valid."""
+    lib = hip.load_library(emu_lib)
+    held = lib.blance_host_alloc(1 << 20)
+    p1 = lib.blance_host_alloc(3 << 20)
+    lib.blance_host_free(p1)
+    lib.blance_host_trim()
+    (C.c_char * 16).from_address(held)[:4] = b"abcd"         # still the caller's
+    lib.blance_host_free(held)
+    pl = hip.Planner(lib_path=emu_lib)
+    fp = synth.config_flat(2, P=300, N=20)
+    assert pl.plan(fp).digest() == _oracle(fp).digest()
+    pl.close()                                               # the last context of this process (if it is): cache dropped
+    p3 = lib.blance_host_alloc(1 << 20)
+    assert p3
+    lib.blance_host_free(p3)
+
+
+def test_arena_arrays_own_their_blocks(emu_lib):
+    """An array of a HostArena keeps its block: a result kept after the arena (and the FlatResult) are gone never aliases a
+    block that was handed out again; FlatProblem.pin() returns a copy and leaves the problem it was called on alone."""
+    import gc
+    fp = synth.config_flat(3, P=512, N=128)
+    before = {n: a.ctypes.data for n, a in fp.arrays.items()}
+    arena = hip.HostArena(emu_lib)
+    fpp = fp.pin(arena)
+    assert {n: a.ctypes.data for n, a in fp.arrays.items()} == before and fpp is not fp
+    assert all(np.array_equal(fpp.arrays[n], fp.arrays[n]) for n in fp.arrays)
+    pl = hip.Planner(lib_path=emu_lib, chain_min_parts=8)
+    pl.upload(fpp)
+    pl.plan_resident()
+    res = pl.download(arena)
+    want = _oracle(fp)
+    nodes, snapshot = res.out_nodes, res.out_nodes.copy()
+    del res, fpp
+    arena.close()
+    del arena
+    gc.collect()
+    other = hip.HostArena(emu_lib)                            # new allocations of the same sizes: must not land on `nodes`
+    junk = [other.empty(nodes.size, np.int32) for _ in range(4)]
+    for j in junk:
+        j[...] = -7
+    assert np.array_equal(nodes, snapshot) and np.array_equal(nodes[:want.out_nodes.size], want.out_nodes)
+    pl.close()
+
+
 BAD = [("long then not monotone", lambda fp: fp.arrays["assign_off"].__setitem__(3, 10 ** 6), abi.ERR_UNSUPPORTED),
        ("not monotone", lambda fp: fp.arrays["prev_off"].__setitem__(7, -5), abi.ERR_BAD_ARG),
        ("kind", lambda fp: fp.arrays["prev_kind"].__setitem__(5, 7), abi.ERR_BAD_ARG),

@@ -30,7 +30,7 @@ def main():
     outputs = {"blance_result": {"n_warnings", "iterations", "converged", "device_ms", "total_ms", "steps_total",
                                  "steps_sequential", "steps_batched", "kernel_launches", "pass_kernel_ms",
                                  "pass_kernel_launches", "flat_pass_ms", "flat_passes", "blank_pass_ms",
-                                 "blank_pass_launches", "stay_pass_ms", "stay_pass_launches"},
+                                 "blank_pass_launches", "stay_pass_ms", "stay_pass_launches", "host_syncs"},
                "blance_moves_result": {"device_ms"}}
     bad = []
     for struct, var, text in (("blance_problem", "pb", plan), ("blance_result", "res", plan),

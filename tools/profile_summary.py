@@ -13,16 +13,16 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["blance_amd/csrc/k_pass_chain.h", "blance_amd/csrc/k_pass_tree.h", "blance_amd/csrc/k_pass_seq.h",
-                  "blance_amd/csrc/k_flat.h", "blance_amd/csrc/k_sweep.h", "blance_amd/csrc/dev_common.h",
-                  "blance_amd/csrc/blance_hip.hip", "blance_amd/csrc/k_stay.h", "blance_amd/csrc/blance_kernels.h",
-                  "blance_amd/csrc/k_period.h", "blance_amd/csrc/k_pass_queue.h", "blance_amd/csrc/dev_prelude.h",
-                  "blance_amd/csrc/k_queue_walk.h"]
+def kernel_sources():
+    """Every source of libblance_hip.so (all of blance_amd/csrc/*.h and *.hip: a list kept by hand missed k_queue_walk.h once)."""
+    import glob
+    d = os.path.join(ROOT, "blance_amd", "csrc")
+    return sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")))
 
 
 def source_hash():
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in kernel_sources():
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
