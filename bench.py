@@ -33,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+T_START = time.perf_counter()
+T_BLOCKS = {}             # seconds per block of the line (block_seconds)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SHARDED_TIMEOUT_S = 180    # the sharded leg of N > 1 runs (a few plans of ~20-60 ms plus the communicator) never needs this long
 SCLK_GHZ = 2.4            # MI355X_MICROARCH.md: 256 CU x 2.4 GHz
@@ -49,6 +51,26 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def cpu_sample_config5(pl, parts, nodes):
+    """The CPU oracle beside config 5 ("configs 3/5 are sampled ... labelled"): the rebalance PlanNextMap -- every
+    state pass of all ten sweeps -- on 1/32 of the partitions over the SAME 4,096 nodes (a step is an O(nodes) scan whatever the
+    partition count, so assignments/s carries over), one core.  The plan it starts from is made on the GPU (untimed)."""
+    from blance_amd import synth
+    from oracle import loader
+    sample_parts = max(1024, parts // 32)
+    fp1 = synth.config5_initial(sample_parts, nodes)
+    fp = synth.config5_rebalance(fp1, pl.plan(fp1), sample_parts, nodes)
+    t0 = time.perf_counter()
+    res = loader.plan(fp)
+    dt = time.perf_counter() - t0
+    return {"value": synth.assignments(fp) / dt, "unit": "assignments/s", "cores": 1, "kind": "port", "extrapolated": True,
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "sample_seconds": dt,
+            "sample": "oracle/blance_oracle.c, the rebalance PlanNextMap (%d sweeps, both state passes of every sweep) on %d partitions x "
+                      "%d nodes = 1/32 of the partitions, same nodes / weights law / model; per-step cost is O(nodes), so assignments/s "
+                      "carries over: EXTRAPOLATED from the sample (all %d partitions: about 5 minutes on this core), %.1f s"
+                      % (res.iterations, sample_parts, nodes, parts, dt)}
 
 
 def cpu_baseline(parts, nodes, cfg, full=False):
@@ -230,7 +252,7 @@ def general_regime(pl, fp3, res3, steps):
     return out
 
 
-def other_configs(pl, steps):
+def other_configs(pl, steps, cpu=True, keep=None):
     """BASELINE.json's other single-GPU configurations under the same clock as the headline: config 2 in full
     (65,536 x 256) and config 5 at its named size -- the initial plan over the old nodes, then the rebalance after a tenth of
     the nodes left and a tenth joined (the configuration BASELINE names for 8 GPUs: its flat passes are ONE dependency chain
@@ -276,14 +298,200 @@ def other_configs(pl, steps):
         c5 = gold.get("config5") or {}
         fp1 = synth.config5_initial(1 << 20, 4096)
         r1 = one("BASELINE.json config 5, setup: the initial plan of 1048576 Zipf-weighted partitions over the 3686 old nodes (node "
-                 "weights, stickiness; flat)", 5, fp1, 1, 0, c5.get("initial"))
+                 "weights, stickiness; flat)", 5, fp1, 2, 1, c5.get("initial"))
         fp2 = synth.config5_rebalance(fp1, r1, 1 << 20, 4096)
         del fp1
         one("BASELINE.json config 5: the rebalance after a tenth of the nodes left and a tenth joined (prevMap = the initial plan)",
-            5, fp2, 1, 0, c5.get("rebalance"))
+            5, fp2, 2, 1, c5.get("rebalance"))
+        if keep is not None:
+            keep[0] = fp2                               # (the replicas block plans the same problem in a child process)
+        if cpu:
+            try:
+                out[-1]["cpu_baseline"] = cpu_sample_config5(pl, 1 << 20, 4096)
+            except Exception as e:
+                out[-1]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     except Exception as e:
         out.append({"config": 5, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
     return out
+
+
+def rccl_one_rank(fp, want_digest, device, steps, unsharded_ms):
+    """The RCCL transport on the one GPU there is: a communicator of ONE rank whose chain passes take the
+    sharded branch (blance_options.reserved[2] & 16384), so that collective A -- ncclAllReduce of [flags | load-vector change]
+    -- and collective B -- ncclAllGather of the output slice -- really run on the planner's stream, timed by the event pairs
+    of blance_comm_time_ms.  What it measures: the per-collective latency a sharded plan pays (launch + RCCL's kernel on one
+    rank; no xGMI hop); not a multi-GPU speed."""
+    from blance_amd import hip
+    try:
+        pl = hip.Planner(device_id=device, shard_one_rank=True)
+        pl.comm_init_rccl_one_rank()
+        pl.upload(fp)
+        pl.plan_resident()                             # warm-up: the communicator's first collectives set up its channels
+        calls0, words0 = pl.comm_stats()
+        ms0 = pl.comm_time_ms()
+        t0 = time.perf_counter()
+        dev = 0.0
+        r = None
+        for _ in range(steps):
+            r = pl.plan_resident()
+            dev += r.device_ms
+        dt = (time.perf_counter() - t0) / steps
+        calls1, words1 = pl.comm_stats()
+        ms1 = pl.comm_time_ms()
+        digest = pl.download().digest()
+        pl.close()
+        n = calls1 - calls0
+        return {"what": "one PlanNextMap on a RCCL communicator of ONE rank with the sharded branch forced: ncclAllReduce + ncclAllGather "
+                        "execute per chain pass (the latency a sharded plan pays per collective; no xGMI hop on one rank)",
+                "rccl_world_size": 1, "steps": steps, "ms_per_step": dt * 1e3, "device_ms_per_step": dev / steps,
+                "unsharded_ms_per_step": unsharded_ms, "sweeps_per_call": r.iterations,
+                "comm_calls_per_plan": n / float(steps), "comm_bytes_per_plan": 4.0 * (words1 - words0) / steps,
+                "comm_device_ms_per_plan": (ms1 - ms0) / steps, "us_per_collective": (ms1 - ms0) * 1e3 / n if n else None,
+                "comm_timing": "hipEvents on either side of every ncclAllReduce / ncclAllGather on the planner's stream",
+                "same_digest_as_unsharded_plan": digest == want_digest}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
+def replicas_worker(args):
+    """`bench.py --replicas-per-gpu 1,4,16,64 [--config 5|3]`: R independent plans at once on ONE MI355X -- R contexts (own stream,
+    buffers, staging) driven by R host threads of this process, the arrangement of an embedder that plans many indexes.  The
+    sequential passes leave 97-99.6 % of the chip idle, so this is the lever exactness leaves: aggregate assignments/s, the
+    slowest plan's latency and the host cores it takes.  Never the headline (parallelism: replicas xR on 1 GPU)."""
+    import threading
+    if args.sync_mode != "default":
+        # how a host thread waits for its stream: the runtime's default spins (one core per planning thread); "blocking" /
+        # "yield" let more contexts than cores plan at once (hipSetDeviceFlags, before the first context of the process)
+        import ctypes
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipSetDevice(args.device)
+        rc = rt.hipSetDeviceFlags({"blocking": 4, "yield": 2, "spin": 1}[args.sync_mode])
+        if rc:
+            print(json.dumps({"replicas_on_one_gpu": {"error": "hipSetDeviceFlags(%s) = %d" % (args.sync_mode, rc)}}), flush=True)
+            return
+    from blance_amd import abi, hip, synth
+    Rs = sorted(set(int(x) for x in args.replicas_per_gpu.split(",") if x))
+    cfg = args.config
+    P, N = args.parts or 1 << 20, args.nodes or 4096
+    with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+        gold = json.load(f)
+    full = P == 1 << 20 and N == 4096
+    t_start = time.perf_counter()
+    if cfg == 5:
+        if args.problem_npz:                            # (made by the parent: interning a million partitions takes a minute)
+            fp = abi.FlatProblem.load_npz(args.problem_npz)
+        else:
+            fp1 = synth.config5_initial(P, N)
+            pl0 = hip.Planner(device_id=args.device)
+            fp = synth.config5_rebalance(fp1, pl0.plan(fp1), P, N)
+            pl0.close()
+            del fp1
+        problems = lambda r: fp                         # noqa: E731 -- every context uploads and plans its own copy
+        want = (gold.get("config5") or {}).get("rebalance") if full else None
+        steps, warm = 1, 0                              # a plan is seconds: first-call allocations (ms) do not show
+        instances = "the same config-5 rebalance in every context (the library shares nothing between contexts)"
+    else:
+        rot = {}
+
+        def problems(r):                                # rotated instances: other per-node tables, the same plan as ids
+            r %= 8
+            if r not in rot:
+                rot[r] = synth.config_flat(3, P=P, N=N, **({"rotate": (512 * r) % N} if r else {}))
+            return rot[r]
+        want = gold.get("config3") if full else None
+        steps, warm = 5, 1
+        instances = "config 3 rotated by 512 (r mod 8) node names in context r (other hierarchy tables, the same plan as ids)"
+    planners, out = [], []
+    a = None
+    t1 = None
+    speed_prev = 1.0
+    for R in Rs:
+        if t1 is not None:
+            predicted = R * t1 * (steps + warm) / max(speed_prev, 1.0)
+            if time.perf_counter() - t_start + predicted > args.replica_budget_s:
+                out.append({"R": R, "skipped": "predicted %.0f s at the concurrency seen so far (x%.1f): beyond the %d s budget of this block"
+                                               % (predicted, speed_prev, args.replica_budget_s)})
+                continue
+        while len(planners) < R:
+            pl = hip.Planner(device_id=args.device)
+            pl.upload(problems(len(planners)))
+            planners.append(pl)
+        a = synth.assignments(problems(0))
+        bar = threading.Barrier(R + 1)
+        lat = [[] for _ in range(R)]
+        err = []
+
+        def work(i):
+            try:
+                for _ in range(warm):
+                    planners[i].plan_resident()
+                bar.wait()
+                for _ in range(steps):
+                    t0 = time.perf_counter()
+                    planners[i].plan_resident()
+                    lat[i].append(time.perf_counter() - t0)
+                bar.wait()
+            except BaseException as e:                  # noqa: BLE001
+                err.append(e)
+                bar.abort()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(R)]
+        for t in th:
+            t.start()
+        try:
+            bar.wait()
+            c0, w0 = sum(os.times()[:2]), time.perf_counter()
+            bar.wait()
+            wall = time.perf_counter() - w0
+            cpu_s = sum(os.times()[:2]) - c0
+        except threading.BrokenBarrierError:
+            wall = cpu_s = float("nan")
+        for t in th:
+            t.join()
+        if err:
+            out.append({"R": R, "error": "%s: %s" % (type(err[0]).__name__, str(err[0])[:200])})
+            break
+        ok = None
+        if want:
+            ok = all(planners[i].download().digest() == want["digest"] for i in range(R))
+        allv = [x for l in lat for x in l]
+        if t1 is None:
+            t1 = wall / steps * (1.0 / R if R > 1 else 1.0)      # (a list that does not start at 1: assume no concurrency)
+        speed_prev = max(1.0, R * t1 / (wall / steps))           # plans in flight at once, as seen at this R
+        out.append({"R": R, "parallelism": "replicas x%d on 1 GPU" % R, "steps_per_replica": steps, "wall_s": wall,
+                    "aggregate_value": R * a * steps / wall, "unit": "assignments/s",
+                    "plan_latency_ms": {"slowest": max(allv) * 1e3, "fastest": min(allv) * 1e3, "mean": sum(allv) / len(allv) * 1e3},
+                    "speedup_vs_R1": (R * a * steps / wall) / out[0]["aggregate_value"] if out and "aggregate_value" in out[0] else 1.0,
+                    "host_threads": R, "host_cores_used": cpu_s / wall if wall == wall and wall > 0 else None,
+                    "every_digest_is_the_oracles": ok})
+    for pl in planners:
+        pl.close()
+    print(json.dumps({"replicas_on_one_gpu": {
+        "config": cfg, "partitions": P, "nodes": N, "instances": instances, "headline": False,
+        "what": "R contexts of one process, one host thread each, planning at once on ONE MI355X; aggregate = R x assignments x steps / wall",
+        "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "host_wait": args.sync_mode, "host_cpus": os.cpu_count(),
+        "host_cpus_usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+        "block_seconds": time.perf_counter() - t_start, "runs": out}}), flush=True)
+
+
+def replicas_block(args, cfg, budget_s, problem_npz=None, rs=None, sync_mode=None):
+    """The replicas_on_one_gpu block of the default line: the worker above in a process of its own (GPU_MAX_HW_QUEUES must be in
+    the environment before the HIP runtime starts: by default the streams of a process share 4 hardware queues)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--replicas-worker", "--replicas-per-gpu", rs or args.replicas_per_gpu or "1,4,16,64",
+           "--config", str(cfg), "--replica-budget-s", str(budget_s), "--device", str(int(os.environ.get("LOCAL_RANK", "0"))),
+           "--sync-mode", sync_mode or args.sync_mode]
+    if problem_npz:
+        cmd += ["--problem-npz", problem_npz]
+    if args.parts:
+        cmd += ["--parts", str(args.parts)]
+    if args.nodes:
+        cmd += ["--nodes", str(args.nodes)]
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", str(args.hw_queues)))
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s + 240)
+        line = [x for x in p.stdout.splitlines() if x.startswith("{")]
+        return json.loads(line[-1])["replicas_on_one_gpu"] if line else {"error": (p.stdout + p.stderr)[-300:]}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def self_launch(args):
@@ -315,7 +523,28 @@ def main():
     ap.add_argument("--no-transfers", action="store_true", help="skip the transfers block (the problem uploaded and the result downloaded again, "
                     "pageable and page-locked): profiles of the plan itself use this")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (BASELINE configs 2 and 5 timed with digests, about 40 s)")
+    ap.add_argument("--replicas-per-gpu", default="", help="R[,R...]: ONLY the replicas_on_one_gpu block -- R contexts planning at once on one "
+                    "GPU (config 5 by default with --config 5, else config 3): aggregate assignments/s, slowest plan, host cores; never the headline")
+    ap.add_argument("--replica-budget-s", type=int, default=240, help="time budget of the replicas block (an R predicted to overrun it is skipped)")
+    ap.add_argument("--hw-queues", type=int, default=32, help="GPU_MAX_HW_QUEUES for the replicas block (the runtime's default maps all streams "
+                    "of a process onto 4 hardware queues)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--replicas-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--problem-npz", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--sync-mode", default="default", choices=["default", "spin", "yield", "blocking"],
+                    help="replicas block: how a host thread waits for its stream (hipSetDeviceFlags)")
+    ap.add_argument("--time-budget-s", type=int, default=270, help="optional blocks of the default line are skipped (and say so) once the run "
+                    "has taken this long: the headline, roofline, cpu_baseline and other_configs always run")
+    ap.add_argument("--no-replicas", action="store_true", help="skip the replicas_on_one_gpu blocks of the default line")
+    ap.add_argument("--no-rccl-one-rank", action="store_true", help="skip the one-rank RCCL leg (ncclAllReduce / ncclAllGather timed on this GPU)")
     args = ap.parse_args()
+
+    if args.replicas_worker:
+        return replicas_worker(args)
+    if args.replicas_per_gpu and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        # the standalone form: the block alone, for config 3 or 5, in a child with the hardware-queue count raised
+        print(json.dumps({"replicas_on_one_gpu": replicas_block(args, args.config, args.replica_budget_s)}), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -390,7 +619,10 @@ def main():
             dt = dist_util.max_over_ranks(dt)
         return dt, acc, r
 
+    T_BLOCKS["setup_and_first_upload"] = round(time.perf_counter() - T_START, 2)
+    t_h = time.perf_counter()
     dt, acc, r = timed(args.steps, args.warmup)
+    T_BLOCKS["headline"] = round(time.perf_counter() - t_h, 2)
     iterations, batched, sequential = r.iterations, r.steps_batched, r.steps_sequential
     assignments = synth.assignments(fp)
     value = assignments * args.steps * world / dt
@@ -408,6 +640,7 @@ def main():
     # the same problem uploaded again and the result downloaded again into buffers that exist -- pageable arrays (staged
     # through the context's page-locked buffer by a few threads) and arrays from blance_host_alloc (DMA where they lie)
     xfer = None
+    t_x = time.perf_counter()
     if rank == 0 and not rehearsal and not args.no_transfers:
         try:
             def again(f, arena):
@@ -441,6 +674,7 @@ def main():
             arena.close()
         except Exception as e:
             xfer = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    T_BLOCKS["transfers"] = round(time.perf_counter() - t_x, 2)
     out = None
     if rank == 0:
         digest = digest_all
@@ -456,16 +690,18 @@ def main():
         # committed profile of EXACTLY these kernel sources (hash checked, no exceptions), else null
         hbm, hbm_src = None, "not measured (--no-live-pmc)"
         if world == 1 and not rehearsal and not args.no_live_pmc:
+            t_p = time.perf_counter()
             hbm, hbm_src = live_pmc(args)
+            T_BLOCKS["live_pmc"] = round(time.perf_counter() - t_p, 2)
         if hbm is None:
             why = hbm_src
-            hbm, hbm_src = profile_json("r5_pmc_hbm_config%d.json" % args.config)
+            hbm, hbm_src = profile_json("r6_pmc_hbm_config%d.json" % args.config)
             hbm_src = "%s -- a committed profile of the same kernel sources, NOT measured in this run (%s)" % (hbm_src, why) if hbm else \
                       "none: %s; %s" % (why, hbm_src)
-        sq, sq_src = profile_json("r5_pmc_sq_config%d.json" % args.config)
+        sq, sq_src = profile_json("r6_pmc_sq_config%d.json" % args.config)
         survey_state = synth.algorithmic_bytes_per_state(fp)          # the reference's dense scan, per pass of a state
 
-        def kernel_line(label, prefix, words, ms, launches, chains, dense_bytes):
+        def kernel_line(label, prefix, words, ms, launches, chains, dense_bytes, walked=True):
             if not launches:
                 return None
             bytes_per_launch = 4.0 * words * P
@@ -481,6 +717,10 @@ def main():
                     "survey_8d_GBps": dense_bytes / (avg_ms * 1e-3) / 1e9,
                     "survey_8d_frac": dense_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": None, "traffic_from": hbm_src}
+            if line["survey_8d_frac"] > 1.0:
+                # 8(d) prices the reference's dense scan of every node per step; above 1 it cannot be a fraction of anything:
+                # the scan is NOT executed here (verified stays, region-local candidates, the periodic copy)
+                line["dense_scan_executed"] = False
             if hbm and headline_shape:
                 tot, calls = kernel_counters(hbm, prefix)
                 if calls:
@@ -494,7 +734,13 @@ def main():
                                      "simd_slots_used_frac": chains / float(N_CUS * SIMDS_PER_CU)}
                 crit = {"chains_per_launch": chains, "dependent_steps_per_chain": chain_steps,
                         "avg_ns_per_dependent_step": ns, "avg_cycles_per_dependent_step": ns * SCLK_GHZ}
-                if sq and headline_shape:
+                if not walked:
+                    # the periodic form walks two periods per region and COPIES the rest: per-step instruction figures of a
+                    # chain nobody walks mean nothing (round 5's line printed 0.0031 instructions per step)
+                    crit = {"chains_per_launch": chains, "dependent_steps_per_chain": chain_steps,
+                            "note": "periodic form: two periods per region walked, the periodic stretch copied (k_period.h); "
+                                    "no per-step issue figures for steps that are not walked"}
+                elif sq and headline_shape:
                     tot, calls = kernel_counters(sq, prefix)
                     if calls and tot.get("SQ_WAVES"):
                         instr = tot.get("SQ_INSTS_VALU", 0) + tot.get("SQ_INSTS_SALU", 0) + tot.get("SQ_INSTS_LDS", 0) + \
@@ -525,7 +771,7 @@ def main():
             kernels.append(kernel_line("all-blank replica pass of the first sweep (k_pass_chain_planes: scalar bit-plane automaton, one wave64 per "
                                        "hierarchy region; with k_period.h two periods walked and the periodic stretch copied)",
                                        ("k_pass_chain_planes", "k_pass_chain_blank", "k_period"), K_CW + 1 + kmax, acc["blank_ms"],
-                                       acc["blank_launches"], zones, dense_pass))
+                                       acc["blank_launches"], zones, dense_pass, walked=bool(args.no_periodic)))
             kernels.append(kernel_line("k_pass_chain<2,2,false> (the replica pass of a later sweep that still moves steps: one wave64 per "
                                        "hierarchy region walks its steps in order, verified stays 64 at a time)",
                                        ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"] - acc["stay_ms"],
@@ -570,7 +816,8 @@ def main():
                           if args.no_periodic else {})},
             "roofline": dict(dom, **{
                 "reference_dense_scan_equivalent_GBps": dense,
-                "survey_8d_whole_call": {"bytes": float(dense_call), "GBps": dense, "frac": dense / HBM_PEAK_GBS},
+                "survey_8d_whole_call": dict({"bytes": float(dense_call), "GBps": dense, "frac": dense / HBM_PEAK_GBS},
+                                             **({"dense_scan_executed": False} if dense / HBM_PEAK_GBS > 1.0 else {})),
                 "whole_call": whole,
                 "note": "two byte models, side by side.  frac = SCHEDULE bytes (what this implementation has to move per launch: one record in, "
                         "one choice out per step) over the launch time over 8 TB/s -- small, because the dominant kernel is bound by the "
@@ -597,20 +844,64 @@ def main():
                 want = json.load(f).get("config%d" % args.config)
             if want:
                 out["matches_oracle_digest"] = (want["rebalance"] if args.config == 5 else want)["digest"] == digest
+        # ---- the blocks beside the headline, in the order of their weight; each is timed (block_seconds), and the optional
+        # ones are skipped -- and say so -- once the run has used its time budget (a default run must finish within minutes)
+        blocks = out["block_seconds"] = dict(T_BLOCKS)
+
+        def timed_block(name, fn, optional=True):
+            if optional and time.perf_counter() - T_START > args.time_budget_s:
+                return {"skipped": "the run had used %d s when this block was due (--time-budget-s %d); run it alone"
+                                   % (time.perf_counter() - T_START, args.time_budget_s)}
+            t_ = time.perf_counter()
+            r_ = fn()
+            blocks[name] = round(time.perf_counter() - t_, 2)
+            return r_
         if world == 1:
             out["sharded"] = ("see sharded_on_one_gpu; N > 1 runs report the RCCL plan here" if args.config == 3 else
                               "not applicable: flat passes are one chain (DESIGN.md 7); only config 3's region chains shard")
-            if args.config == 3 and not args.no_sharded:
-                out["sharded_on_one_gpu"] = sharded_on_one_gpu(fp, digest, local_rank, dt / args.steps)
-        if world == 1 and args.config == 3 and not args.no_extra:
-            out["general_regime"] = general_regime(pl, fp, res, max(1, min(args.steps, 5)))
-        if world == 1 and args.config == 3 and headline_shape and not args.no_other_configs and not rehearsal:
-            out["other_configs"] = other_configs(pl, max(1, min(args.steps, 5)))
-            pl.upload(fp)                               # (what follows plans the headline problem)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.parts or (1 << 20) if args.config == 5 else P, N, args.config, full=not args.cpu_sample)
+            out["cpu_baseline"] = timed_block("cpu_baseline", lambda: cpu_baseline(
+                args.parts or (1 << 20) if args.config == 5 else P, N, args.config, full=not args.cpu_sample), optional=False)
+            if args.config != 3:
+                pl.upload(fp)                           # (config 5's sample planned another problem on this context)
+        fp5 = [None]
+        if world == 1 and args.config == 3 and headline_shape and not args.no_other_configs and not rehearsal:
+            out["other_configs"] = timed_block("other_configs", lambda: other_configs(
+                pl, max(1, min(args.steps, 5)), cpu=not args.no_cpu_baseline, keep=fp5), optional=False)
+            pl.upload(fp)                               # (what follows plans the headline problem)
+            for oc in out["other_configs"]:             # the CPU figure NEXT TO every GPU figure
+                if oc.get("config") == 2 and "error" not in oc and "cpu_baseline" in out:
+                    c2 = out["cpu_baseline"].get("config2_full") or {}
+                    oc["cpu_baseline"] = dict(c2, cores=1, kind="port", sample="oracle/blance_oracle.c on all of config 2, one core")
+        if world == 1 and args.config == 3 and not args.no_extra:
+            out["general_regime"] = timed_block("general_regime", lambda: general_regime(pl, fp, res, max(1, min(args.steps, 3))))
+        if world == 1 and args.config == 3 and not args.no_rccl_one_rank and not rehearsal:
+            out["rccl_one_rank"] = timed_block("rccl_one_rank", lambda: rccl_one_rank(
+                fp, digest, local_rank, max(3, min(args.steps, 10)), dt * 1e3 / args.steps))
+        if world == 1 and args.config == 3 and headline_shape and not args.no_replicas and not rehearsal:
+            # (children of their own: GPU_MAX_HW_QUEUES has to be in the environment before the HIP runtime starts)
+            def both():
+                r3 = replicas_block(args, 3, 40)
+                npz = None
+                if fp5[0] is not None:
+                    npz = "/dev/shm/blance_bench_config5_%d.npz" % os.getpid()
+                    try:
+                        fp5[0].save_npz(npz)
+                    except Exception:
+                        npz = None
+                try:
+                    r5 = replicas_block(args, 5, 90, problem_npz=npz)
+                finally:
+                    if npz and os.path.exists(npz):
+                        os.remove(npz)
+                return [r3, r5]
+            out["replicas_on_one_gpu"] = timed_block("replicas_on_one_gpu", both)
+        fp5[0] = None
+        if world == 1 and args.config == 3 and not args.no_sharded:
+            out["sharded_on_one_gpu"] = timed_block("sharded_on_one_gpu", lambda: sharded_on_one_gpu(fp, digest, local_rank, dt / args.steps))
         if world == 1 and not args.no_extra and not rehearsal:
-            out["host_end_to_end"] = host_end_to_end(args.config)
+            out["host_end_to_end"] = timed_block("host_end_to_end", lambda: host_end_to_end(args.config))
+        blocks["total"] = round(time.perf_counter() - T_START, 2)
     # ---- one plan over all ranks (config 4).  The line of the replicas is ready before this starts: RCCL is bound at
     # run time inside the library and has never met this node, so a watchdog prints that line if the leg does not return.
     sharded = None

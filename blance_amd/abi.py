@@ -158,6 +158,21 @@ class FlatProblem:
         q._keep = []
         return q
 
+    def save_npz(self, path):
+        """The problem as one .npz file (arrays + scalars; no name tables): how bench.py hands a problem to a child process."""
+        np.savez(path, __scalars__=np.array([[k, int(v)] for k, v in self.scalars.items()], dtype=object), **self.arrays)
+
+    @staticmethod
+    def load_npz(path):
+        fp = FlatProblem()
+        with np.load(path, allow_pickle=True) as z:
+            for k, v in z["__scalars__"]:
+                fp.scalars[str(k)] = int(v)
+            for n in z.files:
+                if n != "__scalars__":
+                    fp.set(n, z[n])
+        return fp
+
     def result_capacity(self):
         P, M = self.scalars["n_parts"], self.scalars["n_states"]
         if P * M == 0:

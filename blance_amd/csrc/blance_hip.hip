@@ -215,7 +215,12 @@ struct blance_ctx {
     int chain_group_state = -1;     // the state whose chain pass last grouped the steps by region (chain_order, chain_oi, reg_off) ...
     bool chain_group_static = false; // ... and whether it did so from the static order (sweeps >= 2)
     bool tops_moved = true;         // this sweep's top-state pass was not (known to be) one run of stays
+    bool flags_clean = false;       // the chain passes' flag words (scalars[4 .. 11]) are zero: nothing has set one since the last fill
+    bool rowcount_clean = false;    // f_row_count is zero (k_flat_row_count adds to it)
     bool top_prio_strict = false;   // every other state with constraints > 0 has a priority strictly behind the top state's
+    // every partition gets the same partitionSorter category in sweep 1 (decided at upload): the pass order IS the static
+    // order, no k_category / stable partition (plan.go:542-561) -- in the sweep's first state pass / in all of them
+    bool uniform_first = false, uniform_all = false;
     bool trace = false;             // BLANCE_TRACE, read once at context creation
     int dump_sweep = -1;            // BLANCE_DUMP_SWEEP (developer aid), likewise
     DevBuf dl_off, dl_nodes;        // blance_download: the result as CSR, compacted on the device
@@ -667,6 +672,28 @@ static int put(Mover& mv, DevBuf& b, const T* src, size_t n) {
 
 static inline int cdiv(int64_t a, int b) { return (int)((a + b - 1) / b); }
 
+// up to four zero fills and one copy of int32 words in one launch (k_sweep.h: k_fill_copy)
+struct FillCopyJob {
+    FillCopy a{};
+    int nz = 0;
+    int64_t most = 0;
+    void zero(void* p, int64_t words) {
+        if (words <= 0) return;
+        a.z[nz] = (int32_t*)p; a.zn[nz] = (int32_t)words; nz++;
+        if (words > most) most = words;
+    }
+    void copy(void* dst, const void* src, int64_t words) {
+        a.cd = (int32_t*)dst; a.cs = (const int32_t*)src; a.cn = (int32_t)words;
+        if (words > most) most = words;
+    }
+};
+static int run_fill_copy(blance_ctx* c, FillCopyJob& j);
+
+static int run_fill_copy(blance_ctx* c, FillCopyJob& j) {
+    if (j.most > 0) BLANCE_LAUNCH_NOSYNC(k_fill_copy, cdiv(j.most, 256), 256, 0, c->stream, j.a);
+    return 0;
+}
+
 static int upload_inner(blance_ctx* c, const blance_problem* pb);
 // copies may still be reading the caller's arrays (and the staging buffer) when an
 // error cuts the upload short: never return with copies in flight
@@ -763,6 +790,24 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     }
     // the lists' payloads: their lengths are the last offsets, which are sound now
     const int64_t na = pb->assign_off[PM], np = pb->prev_off[PM];
+    {
+        // partitionSorter's category (plan.go:542-561) is "0" only for partitions with nodes in nodesToRemove.  Without any:
+        // "2" for every partition when nodesToAdd == nil; "1" for every partition when nodesToAdd names no node.  A fresh
+        // plan (the partitions to assign hold nothing): "1" for every partition in the sweep's first state pass (nothing held,
+        // nothing in nodesToAdd), and -- when EVERY node of nodesNext is in nodesToAdd -- "2" for every partition in the later
+        // ones: the first pass gave each partition at least one node (slot 0 always finds a candidate among >= 1 nodes, by
+        // the rule or by the fallback of plan.go:216-218; nothing is excluded as "higher priority" yet) and that node is in
+        // nodesToAdd.  The category is computed from the LIVE lists, so it changes from pass to pass of a sweep.
+        bool any_added = false, all_alive_added = true;
+        for (int n = 0; n < NX; n++) {
+            if (pb->node_added[n]) any_added = true;
+            else if (n < N && !pb->node_removed[n]) all_alive_added = false;
+        }
+        const bool never = !c->any_removed && (pb->nodes_to_add_nil || !any_added);
+        c->uniform_first = never || (!c->any_removed && na == 0);
+        c->uniform_all = never || (!c->any_removed && na == 0 && all_alive_added && c->n_alive >= 1);
+        if (getenv("BLANCE_NO_UNIFORM_CATEGORY")) c->uniform_first = c->uniform_all = false;   // (tests: the partition kernels on such inputs too)
+    }
     PUT(a_nodes, pb->assign_nodes, na);
     PUT(p_nodes, pb->prev_nodes, np);
     if ((st = up.flush())) return st;
@@ -1136,6 +1181,7 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
         int32_t range[2] = {pos, end};
         HIPTRY(hipMemcpyAsync(c->reg_off.p, range, sizeof range, hipMemcpyHostToDevice, sm));
         HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+        c->flags_clean = false;
         cq.ntn_in_lds = lds_rows ? 1 : 0;
         if (!dispatch_chain(c, cq, q.NX)) return fail(BLANCE_ERR_UNSUPPORTED, "flat chain shape");
         int32_t fl[8] = {0};
@@ -1175,7 +1221,8 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     fq.row_count = c->f_row_count.as<int32_t>();
     fq.ntn = q.ntn; fq.rec = q.rec; fq.out = q.out; fq.scan = scal + 8;
     if (q.NP > 0) {                                 // only read by the stay test when NP > 0
-        HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)q.NX + 1), sm));
+        if (!c->rowcount_clean) HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)q.NX + 1), sm));
+        c->rowcount_clean = false;
         BLANCE_LAUNCH(k_flat_row_count, cdiv(P, 256), 256, 0, sm, fq, c->f_row_count.as<int32_t>());
         *launches += 1;
     }
@@ -1546,7 +1593,8 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     const int B = rr.n_regions, nbc = cdiv(P, kPartChunk);
     const int G = c->comm.n_ranks, rank = c->comm.rank;
     const bool sharded = (G > 1 || c->shard_one_rank) && B >= G;
-    HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+    if (!c->flags_clean) HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+    c->flags_clean = false;
     BLANCE_LAUNCH_NOSYNC(k_chain_classify, cdiv(P + 1, 256), 256, 0, sm, d, m, h.top_state,
                          a.order, rr.node_region.as<int32_t>(), c->regid.as<int32_t>(),
                          c->n_ev.as<int32_t>(), scal + 4);
@@ -1586,7 +1634,14 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     }
     if (c->trace)
         fprintf(stderr, "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
-    HIPTRY(hipMemsetAsync(c->ev_off.p, 0, sizeof(int32_t) * ((size_t)B + 1), sm));
+    const size_t cnt_words = (size_t)(M + 1) * NX;
+    {   // one launch: no events yet, the counters this pass starts from (what a redo restores), k_stay_by_top's flag
+        FillCopyJob fj;
+        fj.zero(c->ev_off.p, (int64_t)B + 1);
+        fj.zero(scal + 11, 1);
+        fj.copy(c->cnt_save.p, c->cnt.p, (int64_t)cnt_words);
+        if (run_fill_copy(c, fj)) return BLANCE_ERR_DEVICE;
+    }
     if (!cfl[0] && n_events > 0) {
         const int nec = cdiv(n_events, kPartChunk);
         BLANCE_LAUNCH_NOSYNC(k_chain_ev_fill, cdiv(P, 256), 256, 0, sm, d, m, h.top_state, a.order,
@@ -1619,8 +1674,6 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
                          rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
                          rr.cls_size.as<int32_t>(), 0,
                          c->crec.as<int32_t>(), scal + 4, try_stay ? c->topkey.as<int32_t>() : (int32_t*)nullptr);
-    const size_t cnt_words = (size_t)(M + 1) * NX;
-    HIPTRY(hipMemcpyAsync(c->cnt_save.p, c->cnt.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
     ChainParams cq;
     memset(&cq, 0, sizeof cq);
     cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
@@ -1679,7 +1732,6 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         sq.cnt = c->cnt.as<int32_t>(); sq.crec = c->crec.as<int32_t>();
         sq.top_off = c->top_off.as<int32_t>(); sq.top_order = c->top_order.as<int32_t>();
         sq.out = c->out.as<int32_t>(); sq.flag = scal + 11;
-        HIPTRY(hipMemsetAsync(scal + 11, 0, 4, sm));
         if (launch_stay_by_top(sm, sq, rr.n_stay_wgs, rr.max_size)) {
             int32_t sf[8] = {0};                        // [0] a step is not region-local (k_gather_chain), [7] not all stays
             HIPTRY(read_back(c, sf, scal + 4, sizeof sf));
@@ -1893,7 +1945,16 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
         const int any_removed = first ? c->any_removed : 0;
         const int NP = first ? h.n_prev : c->np_later;
         c->tops_moved = true;                                       // until this sweep's top-state pass turns out to be one run of stays
-        HIPTRY(hipMemsetAsync(scal, 0, 8, sm));                     // warn_count, not_match
+        {   // one launch: warn_count / not_match, the chain flags, stateNodeCounts (plan.go:94), the flat passes' row counts
+            FillCopyJob fj;
+            fj.zero(scal, 2);
+            fj.zero(scal + 4, 8);
+            fj.zero(c->cnt.p, (int64_t)(M + 1) * (NX + 1));
+            if (NP > 0 && c->f_row_count.p) fj.zero(c->f_row_count.p, (int64_t)NX + 1);
+            if (run_fill_copy(c, fj)) return BLANCE_ERR_DEVICE;
+            c->flags_clean = true;
+            c->rowcount_clean = NP > 0 && c->f_row_count.p;
+        }
         if (PM > 0) {
             if (first)
                 BLANCE_LAUNCH_NOSYNC(k_live_init, cdiv(PM, 256), 256, 0, sm, d, c->a_off.as<int32_t>(),
@@ -1903,8 +1964,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 BLANCE_LAUNCH_NOSYNC(k_live_refresh, cdiv(PM, 256), 256, 0, sm, d);
             launches++;
         }
-        // stateNodeCounts = countStateNodes(prevMap), plan.go:94
-        HIPTRY(hipMemsetAsync(c->cnt.p, 0, sizeof(int32_t) * (size_t)(M + 1) * (NX + 1), sm));
+        // stateNodeCounts = countStateNodes(prevMap), plan.go:94 (zeroed above)
         if (h.n_loads > 0) {
             BLANCE_LAUNCH_NOSYNC(k_count_loads, cdiv(h.n_loads, 256), 256, 0, sm, h.n_loads, NX, first ? 0 : 1,
                                  c->load_state.as<int32_t>(), c->load_node.as<int32_t>(),
@@ -1915,11 +1975,14 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             BLANCE_LAUNCH_NOSYNC(k_count_prev, cdiv(PM, 256), 256, 0, sm, d, c->cnt.as<int32_t>());
             launches++;
         }
+        int passes_this_sweep = 0;
         for (int m = 0; m < M; m++) {                               // plan.go:307-324
             const int k = c->state_constraints[m];
             if (k <= 0 || P == 0) continue;
             const int n_chunks = cdiv(P, kPartChunk);
-            if (first) {
+            const bool sort_cat = first && !(passes_this_sweep == 0 ? c->uniform_first : c->uniform_all);
+            passes_this_sweep++;
+            if (sort_cat) {
                 BLANCE_LAUNCH_NOSYNC(k_category, cdiv(P, 256), 256, 0, sm, d, m, any_removed, add_nil, c->cat.as<uint8_t>());
                 BLANCE_LAUNCH(k_part_count, n_chunks, 64, 64, sm, P, (const int32_t*)nullptr, c->cat.as<uint8_t>(),
                               c->part_order.as<int32_t>(), n_chunks, 3, c->chunk_counts.as<int32_t>());
@@ -1932,7 +1995,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 // nodes are in either, so every category is "1" (plan.go:542-561) and the pass order is the
                 // static order itself
             }
-            const int32_t* order = first ? c->order.as<int32_t>() : c->part_order.as<int32_t>();
+            // (the same holds in sweep 1 when every partition has one category, known at upload: uniform_category)
+            const int32_t* order = sort_cat ? c->order.as<int32_t>() : c->part_order.as<int32_t>();
             c->pass_ntn_ready = false;                              // nodeToNodeCounts := fresh (plan.go:266), zeroed when first needed
             const int OW = 1 + k;
             int higher_mask = 0;
@@ -1997,6 +2061,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             c->no_fast_keys = false;
             if (flat_chain) {
                 HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+                c->flags_clean = false;
                 BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, higher_mask,
                                      order, (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
                                      c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),

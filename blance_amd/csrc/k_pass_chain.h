@@ -129,11 +129,25 @@ static_assert(kCW % 4 == 0 && kStageVec == 24 && kChainStage * (kCW / 4) % 64 ==
         BLANCE_STAGE_EACH(BLANCE_STAGE_FETCH)                                                                     \
     }
 
+// HELPER WAVE (round 6).  A pass of (mostly) stays is bound by the instruction count of the stay test, one wave per region;
+// the test reads only LDS (the mirrors of the per-leaf registers, the staged records, the region's nodeToNodeCounts rows).
+// The kernel therefore runs as a workgroup of kChainWaves = 2 waves on two SIMDs of the CU: in a speculation round wave 0
+// tests steps [b, b + 64) and the helper steps [b + 64, b + 128) at the same time, under the same hypothesis ("every step
+// of the round stays": no counter changes, and a step's row is bumped only by steps with its top priority node).  The
+// helper's lanes additionally fail when a step of wave 0's half has their top priority node (it would have bumped their row);
+// wave 0 commits its prefix as before and, if that was all 64, the helper's prefix (row bumps from the records; the helper
+// has staged its steps' outputs already -- a slot that is not committed is written again by whatever commits it).  Two
+// LDS-only barriers per round.  Everything else (events, blank runs, general steps) is wave 0's, the helper parked.
+constexpr int kChainWaves = 2;
+constexpr int kChainCtl = 32;                       // words of the command block between the waves
+
 template <int NPTC, int KM, bool FAST>
-__global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
+__global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) {
     BLANCE_DYN_LDS(lds);
     if (q.flags[0]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const bool duo = uni((int)(blockDim.x >> 6)) > 1;
     const int rg = q.region_base + blockIdx.x;
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
@@ -156,8 +170,115 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     int* recbuf = cszL + size + ((4 - (int)(((unsigned char*)(cszL + size) - lds) >> 2)) & 3);
     int* outbuf = recbuf + kChainStage * kCW;        // [kChainStage][OW]
     int* markL = outbuf + kChainStage * q.OW;                 // [size + 1] first lane of a batch per top priority node
-    int* ntn_l = markL + size + 1;                   // [size][ST] nodeToNodeCounts rows, padded stride
+    int* markH = markL + size + 1;                   // [size + 1] the same for the helper wave's half of a round
+    int* ctl = markH + size + 1;                     // [kChainCtl] wave 0's command, the helper's answer
+    int* ntn_l = ctl + kChainCtl;                    // [size][ST] nodeToNodeCounts rows, padded stride
     const int ST = size + 1;
+    // ---- the stay test of one step (lane a of a wave tests step sb): plan.go:98-248 under the hypothesis that the step keeps
+    // its nodes.  Leaves the step's nodes in emission order in on[] / oi[]; `mark` is the calling wave's own table.
+    auto stay_test = [&](const int sb, const bool active, const int b0, const int a, int* mark, const int next_ev,
+                         const double bound_s, const int bound_n, int (&on)[KM], int (&oi)[KM], int& vtl_out) -> bool {
+        const int* rp = recbuf + (active ? sb : b0) * kCW;
+        bool fail = false;
+        const double vstick = __hiloint2double(rp[3], rp[2]);
+        const int vtl = rp[4];
+        vtl_out = vtl;
+        const int cn = rp[5];
+        if (!((cn >> 24) & 1) || (cn & 0xff) != k || ((cn >> 25) & 1)) fail = true;   // exactly k nodes, all here
+        if (rp[0] > next_ev) fail = true;                             // an event comes first
+        int oc[KM + 1];
+        double so[KM];
+        oc[0] = rp[6];
+#pragma unroll
+        for (int j = 0; j < KM; j++) {
+            on[j] = -3; so[j] = 0.0; oi[j] = 0; oc[j + 1] = -1;
+            if (j < k) {
+                int li = rp[kCOwn + j];
+                if (li < 0 || li >= size) { fail = true; li = 0; }
+                oi[j] = li;
+                on[j] = nidL[li];
+                oc[j + 1] = clsL[li];
+                // the partition's own nodes: candidates, scored exactly
+                if (!(flgL[li] & 1)) fail = true;
+                const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
+                so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
+                                    q.booster_kind, lp_tab, ff_tab);
+            }
+        }
+        // A step that keeps its nodes emits them in (score, position) order -- slot j takes the best
+        // node left (plan.go:185-226) -- which need not be the list order; no counter changes
+        // either way.  Sort them (insertion sort, k <= 4) and check the slots in that order.
+#pragma unroll
+        for (int j = 1; j < KM; j++) {
+#pragma unroll
+            for (int e = j; e > 0; e--) {
+                if (e < k && better(so[e], on[e], so[e - 1], on[e - 1])) {
+                    const double ts = so[e]; so[e] = so[e - 1]; so[e - 1] = ts;
+                    const int tn = on[e]; on[e] = on[e - 1]; on[e - 1] = tn;
+                    const int ti = oi[e]; oi[e] = oi[e - 1]; oi[e - 1] = ti;
+                    const int tc = oc[e + 1]; oc[e + 1] = oc[e]; oc[e] = tc;
+                }
+            }
+        }
+        // anchors top, own_0 .. own_{k-2}: their exclude classes must leave candidates,
+        // and own_j must not sit in a class excluded before its slot
+        {
+            int cov = 0;
+#pragma unroll
+            for (int j = 0; j < KM; j++) {
+                if (j < k) {
+                    if (oc[j] < 0 && !(q.flat && j == 0)) fail = true;
+                    bool dup = false;
+#pragma unroll
+                    for (int e = 0; e < KM; e++) if (e < j && oc[e] == oc[j]) dup = true;
+                    if (!dup && oc[j] >= 0) cov += cszL[oc[j]];
+                    if (cov >= size) fail = true;
+#pragma unroll
+                    for (int e = 0; e < KM; e++) if (e <= j && oc[e] >= 0 && oc[e] == oc[j + 1]) fail = true;
+                }
+            }
+        }
+        // every one of them below the bound
+#pragma unroll
+        for (int j = 0; j < KM; j++)
+            if (j < k && !better(so[j], on[j], bound_s, bound_n)) fail = true;
+        // an own node also listed in a higher priority state is no candidate (the
+        // record keeps such leaves under "higher"; gather refuses nodes held twice)
+        // an earlier step of the batch with the same top priority node would have bumped my row
+        if (NP > 0) {                              // (one LDS minimum per lane instead of 64 lane compares)
+            const int mt = (vtl >= 0 && vtl <= size) ? vtl : size;
+            if (active) atomicMin(&mark[mt], a);
+            BLANCE_WAVE_SYNC();
+            if (active && mark[mt] < a) fail = true;
+        }
+        if (!active) fail = false;
+        return fail;
+    };
+    if (wave != 0) {
+        // ---- the helper wave: parked on the barrier until wave 0 posts a round
+        for (;;) {
+            lds_barrier();                           // (A) posted; the tables are as the round sees them
+            if (uni(ctl[0]) == 0) break;
+            const int b0 = uni(ctl[1]), nbh = uni(ctl[2]);
+            const int sb = b0 + 64 + lane;
+            const bool active = sb < nbh;
+            int on[KM], oi[KM], vtl = 0;
+            const bool fail = stay_test(sb, active, b0, lane, markH, uni(ctl[3]), __hiloint2double(uni(ctl[5]), uni(ctl[4])), uni(ctl[6]),
+                                        on, oi, vtl);
+            if (active) {                            // what a stay emits, staged (committed by wave 0 -- or written again)
+                int* op = outbuf + sb * q.OW;
+                op[0] = k;
+#pragma unroll
+                for (int j = 0; j < KM; j++) if (j < k) op[1 + j] = on[j];
+            }
+            const unsigned long long fm = __ballot(fail || !active);
+            BLANCE_WAVE_SYNC();
+            if (NP > 0 && active) markH[(vtl >= 0 && vtl <= size) ? vtl : size] = INT_MAX;
+            if (lane == 0) { ctl[8] = (int)(unsigned)fm; ctl[9] = (int)(unsigned)(fm >> 32); }
+            lds_barrier();                           // (B) the answer is in
+        }
+        return;
+    }
     if (!FAST && NP > 0) {
         for (int i = lane; i < kLpTab; i += 64) lp_tab[i] = (double)i / (double)NP;
         for (int i = lane; i < kFfTab; i += 64) ff_tab[i] = (0.001 * (double)i) / (double)NP;
@@ -165,8 +286,8 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             for (int i = lane; i < (size + 1) * ST; i += 64) ntn_l[i] = 0;    // last row: "" (flat mode)
     }
     for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
-    for (int i = lane; i <= size; i += 64) markL[i] = INT_MAX;
-    __syncthreads();
+    for (int i = lane; i <= size; i += 64) { markL[i] = INT_MAX; markH[i] = INT_MAX; }
+    BLANCE_WAVE_SYNC();                              // (one wave: LDS is in order; the helper meets the tables behind barrier A)
 
     // lane l owns leaves lo + l + 64 u
     int nid[NPTC], cntv[NPTC], totv[NPTC], wv[NPTC], cls[NPTC], mycsz[NPTC];
@@ -205,7 +326,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
     // classes can never cover the region (then "empty set -> reset", plan.go:746, cannot occur)
     bool compact_ok = false;
     if (FAST) {
-        __syncthreads();
+        BLANCE_WAVE_SYNC();
         int prev = -1, mx = 0;
         bool mono = true;
         if (lane == 0) {
@@ -308,82 +429,16 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
             const int a = lane;
             const int sb = b + a;
             const bool active = sb < nb;
-            const int* rp = recbuf + (active ? sb : b) * kCW;
-            bool fail = false;
-            const double vstick = __hiloint2double(rp[3], rp[2]);
-            const int vtl = rp[4];
-            const int cn = rp[5];
-            if (!((cn >> 24) & 1) || (cn & 0xff) != k || ((cn >> 25) & 1)) fail = true;   // exactly k nodes, all here
-            if (rp[0] > next_ev_oi) fail = true;                      // an event comes first
-            int oi[KM], oc[KM + 1];
-            int on[KM];
-            double so[KM];
-            oc[0] = rp[6];
-#pragma unroll
-            for (int j = 0; j < KM; j++) {
-                on[j] = -3; so[j] = 0.0; oi[j] = 0; oc[j + 1] = -1;
-                if (j < k) {
-                    int li = rp[kCOwn + j];
-                    if (li < 0 || li >= size) { fail = true; li = 0; }
-                    oi[j] = li;
-                    on[j] = nidL[li];
-                    oc[j + 1] = clsL[li];
-                    // the partition's own nodes: candidates, scored exactly
-                    if (!(flgL[li] & 1)) fail = true;
-                    const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
-                    so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
-                                        q.booster_kind, lp_tab, ff_tab);
+            const bool round2 = duo && nb - b > 64;    // the helper wave tests the 64 steps behind mine
+            if (round2) {
+                if (lane == 0) {
+                    ctl[0] = 1; ctl[1] = b; ctl[2] = nb; ctl[3] = next_ev_oi;
+                    ctl[4] = __double2loint(gmin_s); ctl[5] = __double2hiint(gmin_s); ctl[6] = gmin_n;
                 }
+                lds_barrier();                         // (A)
             }
-            // A step that keeps its nodes emits them in (score, position) order -- slot j takes the best
-            // node left (plan.go:185-226) -- which need not be the list order; no counter changes
-            // either way.  Sort them (insertion sort, k <= 4) and check the slots in that order.
-#pragma unroll
-            for (int j = 1; j < KM; j++) {
-#pragma unroll
-                for (int e = j; e > 0; e--) {
-                    if (e < k && better(so[e], on[e], so[e - 1], on[e - 1])) {
-                        const double ts = so[e]; so[e] = so[e - 1]; so[e - 1] = ts;
-                        const int tn = on[e]; on[e] = on[e - 1]; on[e - 1] = tn;
-                        const int ti = oi[e]; oi[e] = oi[e - 1]; oi[e - 1] = ti;
-                        const int tc = oc[e + 1]; oc[e + 1] = oc[e]; oc[e] = tc;
-                    }
-                }
-            }
-            // anchors top, own_0 .. own_{k-2}: their exclude classes must leave candidates,
-            // and own_j must not sit in a class excluded before its slot
-            {
-                int cov = 0;
-#pragma unroll
-                for (int j = 0; j < KM; j++) {
-                    if (j < k) {
-                        if (oc[j] < 0 && !(q.flat && j == 0)) fail = true;
-                        bool dup = false;
-#pragma unroll
-                        for (int e = 0; e < KM; e++) if (e < j && oc[e] == oc[j]) dup = true;
-                        if (!dup && oc[j] >= 0) cov += cszL[oc[j]];
-                        if (cov >= size) fail = true;
-#pragma unroll
-                        for (int e = 0; e < KM; e++) if (e <= j && oc[e] >= 0 && oc[e] == oc[j + 1]) fail = true;
-                    }
-                }
-            }
-            // every one of them below the bound
-#pragma unroll
-            for (int j = 0; j < KM; j++)
-                if (j < k && !better(so[j], on[j], gmin_s, gmin_n)) fail = true;
-            // an own node also listed in a higher priority state is no candidate (the
-            // record keeps such leaves under "higher"; gather refuses nodes held twice)
-            // an earlier step of the batch with the same top priority node would have bumped my row
-            if (NP > 0) {                              // (one LDS minimum per lane instead of 64 lane compares)
-                const int mt = (vtl >= 0 && vtl <= size) ? vtl : size;
-                if (active) atomicMin(&markL[mt], a);
-                BLANCE_WAVE_SYNC();
-                if (active && markL[mt] < a) fail = true;
-                BLANCE_WAVE_SYNC();
-                if (active) markL[mt] = INT_MAX;
-            }
-            if (!active) fail = false;
+            int on[KM], oi[KM], vtl = 0;
+            const bool fail = stay_test(sb, active, b, a, markL, next_ev_oi, gmin_s, gmin_n, on, oi, vtl);
             const unsigned long long fm = __ballot(fail);
             int nok = fm ? __ffsll((long long)fm) - 1 : 64;
             if (nok > nb - b) nok = nb - b;
@@ -398,11 +453,33 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
                     }
                 }
             }
+            if (round2) {
+                lds_barrier();                         // (B) the helper's verdicts on steps [b + 64, b + 128)
+                if (nok == 64) {
+                    const unsigned long long hf = ((unsigned long long)(unsigned)ctl[9] << 32) | (unsigned)ctl[8];
+                    const int sh = b + 64 + a;
+                    const bool hact = sh < nb;
+                    const int* hp = recbuf + (hact ? sh : b) * kCW;
+                    const int ht = hp[4];
+                    // a step of my half with the same top priority node has bumped the row the helper's lane read
+                    bool hfail = ((hf >> a) & 1) != 0 || !hact;
+                    if (NP > 0 && hact && markL[(ht >= 0 && ht <= size) ? ht : size] != INT_MAX) hfail = true;
+                    const unsigned long long hm = __ballot(hfail);
+                    const int nok2 = hm ? __ffsll((long long)hm) - 1 : 64;
+                    if (!FAST && NP > 0 && a < nok2) {
+#pragma unroll
+                        for (int j = 0; j < KM; j++) if (j < k) ntn_l[ht * ST + hp[kCOwn + j]] += 1;       // plan.go:238-245
+                    }
+                    nok += nok2;
+                }
+            }
+            BLANCE_WAVE_SYNC();
+            if (NP > 0 && active) markL[(vtl >= 0 && vtl <= size) ? vtl : size] = INT_MAX;
             BLANCE_WAVE_SYNC();
             if (lane == 0) { spec_steps += nok; spec_batches++; }
             b += nok;
             if (b >= nb) break;
-            if (nok == 64) continue;
+            if (nok == 64 || nok == 128) continue;
             if (next_ev_oi < recbuf[b * kCW]) continue;          // an event is due before the step that failed
         }
         // ---- FAST mode, runs of blank steps (a partition that holds no node of this or
@@ -764,6 +841,10 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
       const int n_done = (!escaped || q.flat) ? b : 0;
       for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
     }
+    if (duo) {                                       // the helper leaves
+        if (lane == 0) ctl[0] = 0;
+        lds_barrier();
+    }
     if (!escaped) while (ev_cur < ev_end) apply_event();      // nodes that leave after this region's last step
     if (__ballot(range_bad)) { escaped = true; stop_range = true; }
     PH_DUMP(cend - cbeg);
@@ -773,7 +854,7 @@ __global__ __launch_bounds__(64) void k_pass_chain(ChainParams q) {
         if (!q.flat) return;
         // the rest of the pass continues from global memory: hand over the LDS rows
         if (!FAST && NP > 0 && q.ntn_in_lds) {
-            __syncthreads();
+            BLANCE_WAVE_SYNC();
             for (int i = lane; i < (size + 1) * size; i += 64) {
                 const int row = i / size, col = i - row * size;
                 const int cn = nidL[col];

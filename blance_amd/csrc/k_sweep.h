@@ -490,6 +490,22 @@ __global__ void k_vec_add(int n, const int32_t* a, const int32_t* b, int32_t* ou
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// Several small fills and one copy in ONE launch: the driver used to enqueue each as a hipMemsetAsync / hipMemcpyAsync of its
+// own (a fill kernel of the runtime per call, 25 of them per PlanNextMap at config 3).  All int32 words.
+struct FillCopy {
+    int32_t* z[4];          // zero z[i][0 .. zn[i])
+    int32_t zn[4];
+    int32_t* cd;            // cd[0 .. cn) = cs[0 .. cn)
+    const int32_t* cs;
+    int32_t cn;
+};
+__global__ void k_fill_copy(FillCopy a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (i < a.zn[j]) a.z[j][i] = 0;
+    if (i < a.cn) a.cd[i] = a.cs[i];
+}
+
 // ---- result as CSR on the device (blance_download): list lengths -> exclusive scan -> gather
 __global__ void k_result_len(DevProblem d, int32_t* len_out /* [P*M + 1] */) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
