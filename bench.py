@@ -749,7 +749,7 @@ def main():
                         crit.update({
                             "instructions_per_step_per_wave": per_step,
                             "cycles_per_instruction": ns * SCLK_GHZ / per_step if per_step else None,
-                            # one wave issues at most one instruction per ~4.5 cycles (tools/dev_lat_micro.hip, measured)
+                            # one wave issues at most one instruction per ~4.5 cycles (tools/profile/lat_micro.hip, measured)
                             "issue_bound_ns_per_step": per_step * 4.5 / SCLK_GHZ,
                             "issue_bound_frac": (per_step * 4.5 / SCLK_GHZ) / ns if ns else None,
                             "wave_active_frac": tot.get("SQ_ACTIVE_INST_ANY", 0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None,

@@ -279,7 +279,7 @@ struct blance_ctx {
     DevBuf fl_iota, fl_zero, fl_one, fl_reglo, fl_reghi;   // the whole cluster as one region (flat single chain)
     DevBuf n_ev, chain_oi, ev_key, ev_oi, ev_leaf, ev_w, ev_perm, ev_off, ev_counts;   // chain events
     bool flat_chain_ok = false;
-    DevBuf f_tot, f_g, f_top_g, f_top_n, f_row_count, f_m, f_moff, f_keys_a, f_keys_b, f_vals_a, f_vals_b, f_hist;
+    DevBuf f_tot, f_g, f_top_g, f_top_n, f_row_count, f_m, f_moff, f_keys_a, f_keys_b, f_vals_a, f_vals_b, f_hist, f_comp;
     int64_t steps_batched = 0;
     int64_t out_capacity = 0;
 
@@ -325,7 +325,7 @@ struct blance_ctx {
                           &ev_key, &ev_oi, &ev_leaf, &ev_w, &ev_perm, &ev_off, &ev_counts, &fl_iota, &fl_zero,
                           &fl_one, &fl_reglo, &fl_reghi, &f_tot, &f_g,
                           &f_top_g, &f_top_n, &f_row_count, &f_m, &f_moff, &f_keys_a, &f_keys_b, &f_vals_a,
-                          &f_vals_b, &f_hist};
+                          &f_vals_b, &f_hist, &f_comp};
         for (DevBuf* b : more) b->release();
     }
 };
@@ -1280,7 +1280,13 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             if (excl) {
                 int32_t bad = INT_MAX;
                 HIPTRY(hipMemcpyAsync(scal + 10, &bad, sizeof bad, hipMemcpyHostToDevice, sm));
-                BLANCE_LAUNCH(k_fresh_excl, 1, 1024, 2048 + 64, sm, fq, pos, R, sorted_vals, other_vals, scal + 10);
+                // (threads of a few steps each: coalesced record reads; up to 64 workgroups)
+                int G = cdiv(R, 4 * 1024);
+                G = G < 1 ? 1 : G > 64 ? 64 : G;
+                RESERVE(f_comp, (size_t)G * 1024 + 64 + 64);
+                unsigned char* comp = c->f_comp.as<unsigned char>();
+                BLANCE_LAUNCH(k_fresh_excl_scan, G, 1024, 2048 + 64, sm, fq, pos, R, sorted_vals, comp, comp + (size_t)G * 1024);
+                BLANCE_LAUNCH_NOSYNC(k_fresh_excl_apply, G, 1024, 0, sm, fq, pos, R, sorted_vals, comp, comp + (size_t)G * 1024, other_vals, scal + 10);
                 HIPTRY(read_back(c, &bad, scal + 10, sizeof bad));
                 HIPTRY(stream_sync(c));
                 *launches += 1;

@@ -469,14 +469,25 @@ __device__ __forceinline__ FreshStep fresh_step(int k, const int32_t* S, int t, 
     return r;
 }
 
-__global__ __launch_bounds__(1024) void k_fresh_excl(FlatParams q, int beg, int R, const int32_t* S /* [k R + k] */,
-                                                     int32_t* picks /* [k R] */, int32_t* first_bad) {
+// Two launches over G workgroups of 1024 threads, thread g owning steps [g per, g per + per) of the run (round 6; one
+// workgroup walked 64 steps per thread twice, 300 us for 65,536 steps):
+//   k_fresh_excl_scan  every thread composes its steps' functions; an inclusive scan under composition over the workgroup
+//                      leaves each thread's prefix in comp[] and the workgroup's whole function in blk[];
+//   k_fresh_excl_apply the state that enters a workgroup is the earlier workgroups' functions applied in turn to "nothing
+//                      pending"; a thread's entering state follows from its predecessor's prefix; the steps are replayed.
+// A function {0, 1} -> {0, 1} is two bits: f(x) = (f >> x) & 1.
+__device__ __forceinline__ int fresh_excl_per(int R, int G) { return (R + G * 1024 - 1) / (G * 1024); }
+
+__global__ __launch_bounds__(1024) void k_fresh_excl_scan(FlatParams q, int beg, int R, const int32_t* S /* [k R + k] */,
+                                                          unsigned char* comp_out /* [G * 1024] */, unsigned char* blk /* [G] */) {
     BLANCE_DYN_LDS(lds);
     unsigned char* comp = (unsigned char*)lds;       // [1024] composite step function of a thread's slice: bit x = f(x)
     unsigned char* tmp = comp + 1024;
     const int tid = threadIdx.x, k = q.k;
-    const int per = (R + 1023) / 1024;
-    const int t0 = tid * per < R ? tid * per : R, t1 = t0 + per < R ? t0 + per : R;
+    const int gid = blockIdx.x * 1024 + tid;
+    const int per = fresh_excl_per(R, (int)gridDim.x);
+    const long long s0 = (long long)gid * per;
+    const int t0 = s0 < R ? (int)s0 : R, t1 = t0 + per < R ? t0 + per : R;
     unsigned f = 2;                                  // identity: f(0) = 0, f(1) = 1
     int eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
     for (int t = t0; t < t1; t++) {
@@ -501,8 +512,22 @@ __global__ __launch_bounds__(1024) void k_fresh_excl(FlatParams q, int beg, int 
         comp[tid] = tmp[tid];
         __syncthreads();
     }
-    unsigned b = tid > 0 ? (comp[tid - 1] & 1u) : 0u;   // the run starts with nothing pending
-    eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
+    comp_out[gid] = comp[tid];
+    if (tid == 1023) blk[blockIdx.x] = comp[tid];
+}
+
+__global__ __launch_bounds__(1024) void k_fresh_excl_apply(FlatParams q, int beg, int R, const int32_t* S /* [k R + k] */,
+                                                           const unsigned char* comp /* [G * 1024] */, const unsigned char* blk,
+                                                           int32_t* picks /* [k R] */, int32_t* first_bad) {
+    const int tid = threadIdx.x, k = q.k;
+    const int gid = blockIdx.x * 1024 + tid;
+    const int per = fresh_excl_per(R, (int)gridDim.x);
+    const long long s0 = (long long)gid * per;
+    const int t0 = s0 < R ? (int)s0 : R, t1 = t0 + per < R ? t0 + per : R;
+    unsigned b = 0;                                  // the run starts with nothing pending
+    for (int j = 0; j < (int)blockIdx.x; j++) b = ((unsigned)blk[j] >> b) & 1u;
+    if (tid > 0) b = ((unsigned)comp[gid - 1] >> b) & 1u;
+    int eprev = t0 > 0 && t0 < R ? fresh_excluded(q, beg + t0 - 1) : -1;
     for (int t = t0; t < t1; t++) {
         const int e = fresh_excluded(q, beg + t);
         const FreshStep st = fresh_step(k, S, t, e, eprev);

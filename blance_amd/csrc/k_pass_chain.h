@@ -129,16 +129,20 @@ static_assert(kCW % 4 == 0 && kStageVec == 24 && kChainStage * (kCW / 4) % 64 ==
         BLANCE_STAGE_EACH(BLANCE_STAGE_FETCH)                                                                     \
     }
 
-// HELPER WAVE (round 6).  A pass of (mostly) stays is bound by the instruction count of the stay test, one wave per region;
+// HELPER WAVES (round 6).  A pass of (mostly) stays is bound by the instruction count of the stay test, one wave per region;
 // the test reads only LDS (the mirrors of the per-leaf registers, the staged records, the region's nodeToNodeCounts rows).
-// The kernel therefore runs as a workgroup of kChainWaves = 2 waves on two SIMDs of the CU: in a speculation round wave 0
-// tests steps [b, b + 64) and the helper steps [b + 64, b + 128) at the same time, under the same hypothesis ("every step
-// of the round stays": no counter changes, and a step's row is bumped only by steps with its top priority node).  The
-// helper's lanes additionally fail when a step of wave 0's half has their top priority node (it would have bumped their row);
-// wave 0 commits its prefix as before and, if that was all 64, the helper's prefix (row bumps from the records; the helper
-// has staged its steps' outputs already -- a slot that is not committed is written again by whatever commits it).  Two
-// LDS-only barriers per round.  Everything else (events, blank runs, general steps) is wave 0's, the helper parked.
-constexpr int kChainWaves = 2;
+// The kernel therefore runs as a workgroup of kChainWaves = 4 waves, one per SIMD of the CU: in a speculation round wave w
+// tests steps [b + 64 w, b + 64 w + 64), all at the same time and under the same hypothesis -- "every step of the round
+// stays": no counter changes, and a step's row of nodeToNodeCounts is bumped only by the steps with its top priority node
+// (plan.go:238-245).  What an EARLIER step of the round with my top priority node would have bumped is added in by the test
+// itself: every wave enters its steps' top priority nodes in its own table (the first lane per node; a second lane of the
+// same wave with that node fails, as before), and a lane of wave w looks its node up in the tables of waves 0 .. w - 1 -- a
+// hit names the one step of that wave whose row bumps it has to count (that step keeps its nodes if it is committed at all:
+// the round commits a prefix).  Wave 0 combines the verdicts, commits the prefix's row bumps from the records (the waves
+// have staged their steps' outputs already -- a slot that is not committed is written again by whatever commits it).  Three
+// LDS-only barriers per round of 256 steps.  Everything else (events, blank runs, general steps) is wave 0's alone, the
+// helpers parked on the barrier.
+constexpr int kChainWaves = 4;
 constexpr int kChainCtl = 32;                       // words of the command block between the waves
 
 template <int NPTC, int KM, bool FAST>
@@ -146,8 +150,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
     BLANCE_DYN_LDS(lds);
     if (q.flags[0]) return;
     const int lane = threadIdx.x & 63;
-    const int wave = uni((int)(threadIdx.x >> 6));
-    const bool duo = uni((int)(blockDim.x >> 6)) > 1;
+    const int wave = uni((int)(threadIdx.x >> 6)), NWv = uni((int)(blockDim.x >> 6));
     const int rg = q.region_base + blockIdx.x;
     const int lo = q.reg_lo[rg], hi = q.reg_hi[rg], size = hi - lo;
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
@@ -169,38 +172,76 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
     // [kChainStage][kCW], 16-byte aligned (inside the launch's slack; by offset, so that the pointer stays an LDS pointer)
     int* recbuf = cszL + size + ((4 - (int)(((unsigned char*)(cszL + size) - lds) >> 2)) & 3);
     int* outbuf = recbuf + kChainStage * kCW;        // [kChainStage][OW]
-    int* markL = outbuf + kChainStage * q.OW;                 // [size + 1] first lane of a batch per top priority node
-    int* markH = markL + size + 1;                   // [size + 1] the same for the helper wave's half of a round
-    int* ctl = markH + size + 1;                     // [kChainCtl] wave 0's command, the helper's answer
+    const int MS = size + 1;
+    int* markL = outbuf + kChainStage * q.OW;        // [kChainWaves][size + 1] per wave: first lane of its 64 steps per top priority node
+    int* ctl = markL + kChainWaves * MS;             // [kChainCtl] wave 0's command, the waves' verdicts
     int* ntn_l = ctl + kChainCtl;                    // [size][ST] nodeToNodeCounts rows, padded stride
     const int ST = size + 1;
-    // ---- the stay test of one step (lane a of a wave tests step sb): plan.go:98-248 under the hypothesis that the step keeps
-    // its nodes.  Leaves the step's nodes in emission order in on[] / oi[]; `mark` is the calling wave's own table.
-    auto stay_test = [&](const int sb, const bool active, const int b0, const int a, int* mark, const int next_ev,
-                         const double bound_s, const int bound_n, int (&on)[KM], int (&oi)[KM], int& vtl_out) -> bool {
+    // ---- the stay test of one step (lane a of wave w tests step sb of the round that starts at b0): plan.go:98-248 under the
+    // hypothesis that the step keeps its nodes.  stay_mark first (all waves), then -- behind a barrier when several waves
+    // take part -- stay_test, which leaves the step's nodes in emission order in on[].
+    auto stay_mark = [&](const int sb, const bool active, const int b0, const int a, const int w) {
+        if (NP > 0) {
+            const int vtl = recbuf[(active ? sb : b0) * kCW + 4];
+            if (active) atomicMin(&markL[w * MS + ((vtl >= 0 && vtl <= size) ? vtl : size)], a);
+        }
+    };
+    auto stay_unmark = [&](const int sb, const bool active, const int b0, const int w) {
+        if (NP > 0 && active) {
+            const int vtl = recbuf[sb * kCW + 4];
+            markL[w * MS + ((vtl >= 0 && vtl <= size) ? vtl : size)] = INT_MAX;
+        }
+        (void)b0;
+    };
+    auto stay_test = [&](const int sb, const bool active, const int b0, const int a, const int w, const int next_ev,
+                         const double bound_s, const int bound_n, int (&on)[KM]) -> bool {
         const int* rp = recbuf + (active ? sb : b0) * kCW;
         bool fail = false;
         const double vstick = __hiloint2double(rp[3], rp[2]);
         const int vtl = rp[4];
-        vtl_out = vtl;
+        const int mt = (vtl >= 0 && vtl <= size) ? vtl : size;
         const int cn = rp[5];
         if (!((cn >> 24) & 1) || (cn & 0xff) != k || ((cn >> 25) & 1)) fail = true;   // exactly k nodes, all here
         if (rp[0] > next_ev) fail = true;                             // an event comes first
-        int oc[KM + 1];
+        int oc[KM + 1], oi[KM], adj[KM];
         double so[KM];
         oc[0] = rp[6];
 #pragma unroll
         for (int j = 0; j < KM; j++) {
-            on[j] = -3; so[j] = 0.0; oi[j] = 0; oc[j + 1] = -1;
+            on[j] = -3; so[j] = 0.0; oi[j] = 0; oc[j + 1] = -1; adj[j] = 0;
             if (j < k) {
                 int li = rp[kCOwn + j];
                 if (li < 0 || li >= size) { fail = true; li = 0; }
                 oi[j] = li;
+            }
+        }
+        if (!FAST && NP > 0) {
+            // an earlier step of the round with my top priority node -- one per earlier wave at most among the steps that can be
+            // committed -- has bumped my row at ITS nodes (it keeps them, or the prefix ends before me): plan.go:238-245
+            for (int w2 = 0; w2 < w; w2++) {
+                const int pl = markL[w2 * MS + mt];
+                if (pl != INT_MAX) {
+                    const int* pr = recbuf + (b0 + 64 * w2 + pl) * kCW;
+#pragma unroll
+                    for (int j2 = 0; j2 < KM; j2++) {
+                        if (j2 < k) {
+                            const int x = pr[kCOwn + j2];
+#pragma unroll
+                            for (int j = 0; j < KM; j++) if (j < k && oi[j] == x) adj[j]++;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KM; j++) {
+            if (j < k) {
+                const int li = oi[j];
                 on[j] = nidL[li];
                 oc[j + 1] = clsL[li];
                 // the partition's own nodes: candidates, scored exactly
                 if (!(flgL[li] & 1)) fail = true;
-                const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] : 0;
+                const int nt = (!FAST && NP > 0) ? ntn_l[vtl * ST + li] + adj[j] : 0;
                 so[j] = chain_score(cntL[li], nt, totL[li], (flgL[li] >> 1) & 1, wgtL[li], NP, vstick,
                                     q.booster_kind, lp_tab, ff_tab);
             }
@@ -215,7 +256,6 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
                 if (e < k && better(so[e], on[e], so[e - 1], on[e - 1])) {
                     const double ts = so[e]; so[e] = so[e - 1]; so[e - 1] = ts;
                     const int tn = on[e]; on[e] = on[e - 1]; on[e - 1] = tn;
-                    const int ti = oi[e]; oi[e] = oi[e - 1]; oi[e - 1] = ti;
                     const int tc = oc[e + 1]; oc[e + 1] = oc[e]; oc[e] = tc;
                 }
             }
@@ -244,38 +284,36 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             if (j < k && !better(so[j], on[j], bound_s, bound_n)) fail = true;
         // an own node also listed in a higher priority state is no candidate (the
         // record keeps such leaves under "higher"; gather refuses nodes held twice)
-        // an earlier step of the batch with the same top priority node would have bumped my row
-        if (NP > 0) {                              // (one LDS minimum per lane instead of 64 lane compares)
-            const int mt = (vtl >= 0 && vtl <= size) ? vtl : size;
-            if (active) atomicMin(&mark[mt], a);
-            BLANCE_WAVE_SYNC();
-            if (active && mark[mt] < a) fail = true;
+        // an earlier step of MY wave's 64 with the same top priority node would have bumped my row
+        if (NP > 0 && active && markL[w * MS + mt] < a) fail = true;
+        return fail || !active;
+    };
+    // what a stay emits, staged (a slot that is not committed is written again by whatever commits it)
+    auto stay_stage = [&](const int sb, const bool active, const int (&on)[KM]) {
+        if (active) {
+            int* op = outbuf + sb * q.OW;
+            op[0] = k;
+#pragma unroll
+            for (int j = 0; j < KM; j++) if (j < k) op[1 + j] = on[j];
         }
-        if (!active) fail = false;
-        return fail;
     };
     if (wave != 0) {
-        // ---- the helper wave: parked on the barrier until wave 0 posts a round
+        // ---- a helper wave: parked on the barrier until wave 0 posts a round
         for (;;) {
             lds_barrier();                           // (A) posted; the tables are as the round sees them
             if (uni(ctl[0]) == 0) break;
             const int b0 = uni(ctl[1]), nbh = uni(ctl[2]);
-            const int sb = b0 + 64 + lane;
+            const int sb = b0 + 64 * wave + lane;
             const bool active = sb < nbh;
-            int on[KM], oi[KM], vtl = 0;
-            const bool fail = stay_test(sb, active, b0, lane, markH, uni(ctl[3]), __hiloint2double(uni(ctl[5]), uni(ctl[4])), uni(ctl[6]),
-                                        on, oi, vtl);
-            if (active) {                            // what a stay emits, staged (committed by wave 0 -- or written again)
-                int* op = outbuf + sb * q.OW;
-                op[0] = k;
-#pragma unroll
-                for (int j = 0; j < KM; j++) if (j < k) op[1 + j] = on[j];
-            }
-            const unsigned long long fm = __ballot(fail || !active);
-            BLANCE_WAVE_SYNC();
-            if (NP > 0 && active) markH[(vtl >= 0 && vtl <= size) ? vtl : size] = INT_MAX;
-            if (lane == 0) { ctl[8] = (int)(unsigned)fm; ctl[9] = (int)(unsigned)(fm >> 32); }
-            lds_barrier();                           // (B) the answer is in
+            stay_mark(sb, active, b0, lane, wave);
+            lds_barrier();                           // (M) every wave's table is complete
+            int on[KM];
+            const bool fail = stay_test(sb, active, b0, lane, wave, uni(ctl[3]), __hiloint2double(uni(ctl[5]), uni(ctl[4])), uni(ctl[6]), on);
+            stay_stage(sb, active, on);
+            const unsigned long long fm = __ballot(fail);
+            if (lane == 0) { ctl[8 + 2 * wave] = (int)(unsigned)fm; ctl[9 + 2 * wave] = (int)(unsigned)(fm >> 32); }
+            lds_barrier();                           // (B) the verdicts are in
+            stay_unmark(sb, active, b0, wave);
         }
         return;
     }
@@ -286,7 +324,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             for (int i = lane; i < (size + 1) * ST; i += 64) ntn_l[i] = 0;    // last row: "" (flat mode)
     }
     for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
-    for (int i = lane; i <= size; i += 64) { markL[i] = INT_MAX; markH[i] = INT_MAX; }
+    for (int i = lane; i < kChainWaves * MS; i += 64) markL[i] = INT_MAX;
     BLANCE_WAVE_SYNC();                              // (one wave: LDS is in order; the helper meets the tables behind barrier A)
 
     // lane l owns leaves lo + l + 64 u
@@ -429,57 +467,47 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             const int a = lane;
             const int sb = b + a;
             const bool active = sb < nb;
-            const bool round2 = duo && nb - b > 64;    // the helper wave tests the 64 steps behind mine
-            if (round2) {
+            const bool multi = NWv > 1 && nb - b > 64;   // the helper waves test the steps behind my 64
+            if (multi) {
                 if (lane == 0) {
                     ctl[0] = 1; ctl[1] = b; ctl[2] = nb; ctl[3] = next_ev_oi;
                     ctl[4] = __double2loint(gmin_s); ctl[5] = __double2hiint(gmin_s); ctl[6] = gmin_n;
                 }
                 lds_barrier();                         // (A)
             }
-            int on[KM], oi[KM], vtl = 0;
-            const bool fail = stay_test(sb, active, b, a, markL, next_ev_oi, gmin_s, gmin_n, on, oi, vtl);
+            stay_mark(sb, active, b, a, 0);
+            if (multi) lds_barrier();                  // (M)
+            else BLANCE_WAVE_SYNC();
+            int on[KM];
+            const bool fail = stay_test(sb, active, b, a, 0, next_ev_oi, gmin_s, gmin_n, on);
+            stay_stage(sb, active, on);
             const unsigned long long fm = __ballot(fail);
             int nok = fm ? __ffsll((long long)fm) - 1 : 64;
-            if (nok > nb - b) nok = nb - b;
-            if (a < nok) {
-                int* op = outbuf + sb * q.OW;
-                op[0] = k;
-#pragma unroll
-                for (int j = 0; j < KM; j++) {
-                    if (j < k) {
-                        op[1 + j] = on[j];
-                        if (!FAST && NP > 0) ntn_l[vtl * ST + oi[j]] += 1;      // plan.go:238-245
-                    }
+            if (multi) {
+                lds_barrier();                         // (B) the helpers' verdicts on the steps from b + 64 on
+                for (int w2 = 1; w2 < NWv && nok == 64 * w2; w2++) {
+                    const unsigned long long hf = ((unsigned long long)(unsigned)ctl[9 + 2 * w2] << 32) | (unsigned)ctl[8 + 2 * w2];
+                    nok += hf ? __ffsll((long long)hf) - 1 : 64;
                 }
             }
-            if (round2) {
-                lds_barrier();                         // (B) the helper's verdicts on steps [b + 64, b + 128)
-                if (nok == 64) {
-                    const unsigned long long hf = ((unsigned long long)(unsigned)ctl[9] << 32) | (unsigned)ctl[8];
-                    const int sh = b + 64 + a;
-                    const bool hact = sh < nb;
-                    const int* hp = recbuf + (hact ? sh : b) * kCW;
-                    const int ht = hp[4];
-                    // a step of my half with the same top priority node has bumped the row the helper's lane read
-                    bool hfail = ((hf >> a) & 1) != 0 || !hact;
-                    if (NP > 0 && hact && markL[(ht >= 0 && ht <= size) ? ht : size] != INT_MAX) hfail = true;
-                    const unsigned long long hm = __ballot(hfail);
-                    const int nok2 = hm ? __ffsll((long long)hm) - 1 : 64;
-                    if (!FAST && NP > 0 && a < nok2) {
+            // the committed prefix bumps its rows (plan.go:238-245); 64 steps at a time: no two of them share a row
+            if (!FAST && NP > 0) {
+                for (int u = 0; 64 * u < nok; u++) {
+                    if (64 * u + a < nok) {
+                        const int* hp = recbuf + (b + 64 * u + a) * kCW;
+                        const int ht = hp[4];
 #pragma unroll
-                        for (int j = 0; j < KM; j++) if (j < k) ntn_l[ht * ST + hp[kCOwn + j]] += 1;       // plan.go:238-245
+                        for (int j = 0; j < KM; j++) if (j < k) atomicAdd(&ntn_l[ht * ST + hp[kCOwn + j]], 1);
                     }
-                    nok += nok2;
+                    BLANCE_WAVE_SYNC();
                 }
             }
             BLANCE_WAVE_SYNC();
-            if (NP > 0 && active) markL[(vtl >= 0 && vtl <= size) ? vtl : size] = INT_MAX;
-            BLANCE_WAVE_SYNC();
+            stay_unmark(sb, active, b, 0);
             if (lane == 0) { spec_steps += nok; spec_batches++; }
             b += nok;
             if (b >= nb) break;
-            if (nok == 64 || nok == 128) continue;
+            if (nok > 0 && (nok & 63) == 0) continue;   // whole waves' worth of stays: try the next round from there
             if (next_ev_oi < recbuf[b * kCW]) continue;          // an event is due before the step that failed
         }
         // ---- FAST mode, runs of blank steps (a partition that holds no node of this or
@@ -841,7 +869,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
       const int n_done = (!escaped || q.flat) ? b : 0;
       for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
     }
-    if (duo) {                                       // the helper leaves
+    if (NWv > 1) {                                   // the helpers leave
         if (lane == 0) ctl[0] = 0;
         lds_barrier();
     }

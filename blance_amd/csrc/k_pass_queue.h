@@ -645,25 +645,23 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             pre[r] = (r < RW && RW <= kRecPre && idx < B0 * RW) ? q.rec[(size_t)q.beg * RW + idx] : 0;
         }
     }
+    if (RW <= kRecPre) {                             // the first batch's records into LDS
+        const int B0 = q.end - q.beg < 64 ? q.end - q.beg : 64;
+#pragma unroll
+        for (int r = 0; r < kRecPre; r++) {
+            const int idx = r * 64 + lane;
+            if (r < RW && idx < B0 * RW) recS[idx] = pre[r];
+        }
+    }
     for (int oi = q.beg; ; oi += 64) {
         oi = uni(oi); wcnt = uni(wcnt); stop_why = uni(stop_why);
         if (oi >= q.end || stop_why != kQStopNone) break;
         const int B = q.end - oi < 64 ? q.end - oi : 64;
-        BLANCE_QWAIT_BUMPS();                        // earlier bumps of nodeToNodeCounts / its bit maps are done before the reads below
-        if (RW <= kRecPre) {
-            // (the records of this batch were fetched while the last one was walked; now the next batch's are started)
-#pragma unroll
-            for (int r = 0; r < kRecPre; r++) {
-                const int idx = r * 64 + lane;
-                if (r < RW && idx < B * RW) recS[idx] = pre[r];
-            }
-            const int on = oi + 64, Bn = q.end - on < 64 ? q.end - on : 64;
-#pragma unroll
-            for (int r = 0; r < kRecPre; r++) {
-                const int idx = r * 64 + lane;
-                pre[r] = (r < RW && on < q.end && idx < Bn * RW) ? q.rec[(size_t)on * RW + idx] : 0;
-            }
-        } else {
+        // The batch's records are in LDS already (staged when the last batch ended, out of registers that were loaded while it
+        // was walked): the decoding below reads LDS only and runs while the last batch's bumps of nodeToNodeCounts and its
+        // bit maps are still on their way -- they are waited for where the first read of the matrix is issued.
+        if (RW > kRecPre) {
+            BLANCE_QWAIT_BUMPS();
             for (int r = 0; r < RW; r++) {
                 const int idx = r * 64 + lane;
                 if (idx < B * RW) recS[idx] = q.rec[(size_t)oi * RW + idx];
@@ -736,6 +734,22 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             }
         }
         PH(1);
+        BLANCE_QWAIT_BUMPS();                        // earlier bumps of nodeToNodeCounts / its bit maps are done before the reads below
+        if (RW <= kRecPre) {                         // the next batch's records: on their way while this one is walked
+            const int on = oi + 64, Bn = q.end - on < 64 ? q.end - on : 64;
+#pragma unroll
+            for (int r = 0; r < kRecPre; r++) {
+                const int idx = r * 64 + lane;
+                pre[r] = (r < RW && on < q.end && idx < Bn * RW) ? q.rec[(size_t)on * RW + idx] : 0;
+            }
+        }
+        // the own nodes' entries of the step's row: issued here so that they travel with the row bit maps below (one round
+        // trip to the L2 for both; a lane whose row an earlier step of the batch bumps reads them again at its turn)
+        if (NP > 0) {
+#pragma unroll
+            for (int j = 0; j < KM; j++)
+                if (simple && j < nown) ntn_own[j] = BLANCE_QLD(q.ntn + (size_t)row * N + ownv[j]);
+        }
         // ---- folded mode on / off
         {
             const bool want = NP > 0 && lean_ok && __ballot(act && !(simple && row == NX && nown == 0 && n_o <= 2 && hv[1] < 0)) == 0;
@@ -815,11 +829,6 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         }
         if (fold) dirty = false;                     // (the shared row is in LDS, kept exactly by the walk itself)
         BLANCE_WAVE_SYNC();
-        if (NP > 0) {
-#pragma unroll
-            for (int j = 0; j < KM; j++)
-                if (simple && j < nown) ntn_own[j] = BLANCE_QLD(q.ntn + (size_t)row * N + ownv[j]);
-        }
         // exact keys of the own nodes, sorted: what a stay emits (keeping the same nodes in another order changes no counter)
         u64 lastK = 0;
         int lastN = -1;
@@ -1469,6 +1478,14 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         // ---- the batch's outputs (up to the step that stopped the launch), and the bumps still pending
         const int done = stop_why == kQStopNone ? B : cur;
         BLANCE_WAVE_SYNC();
+        if (RW <= kRecPre && oi + 64 < q.end) {      // the next batch's records (arrived long ago) into LDS: nobody reads this batch's any more
+            const int Bn = q.end - (oi + 64) < 64 ? q.end - (oi + 64) : 64;
+#pragma unroll
+            for (int r = 0; r < kRecPre; r++) {
+                const int idx = r * 64 + lane;
+                if (r < RW && idx < Bn * RW) recS[idx] = pre[r];
+            }
+        }
         flush_bumps(done);
         for (int idx = lane; idx < done * OWs; idx += 64) q.out[(size_t)oi * OWs + idx] = outS[idx];
         PH(9);

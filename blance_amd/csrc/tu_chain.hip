@@ -8,7 +8,7 @@ namespace blance {
 template <int NPTC, int KM, bool FAST>
 static void launch_chain_v(hipStream_t stream, const ChainParams& q, size_t lds) {
     auto kern = k_pass_chain<NPTC, KM, FAST>;
-    // (two waves per region: the walking wave and its helper for the stay test, k_pass_chain.h)
+    // (kChainWaves waves per region: the walking wave and its helpers for the stay test, k_pass_chain.h)
     BLANCE_LAUNCH(kern, q.n_launch, 64 * kChainWaves, lds, stream, q);
 }
 
@@ -20,7 +20,7 @@ static void launch_chain_mode(hipStream_t stream, const ChainParams& q, size_t l
 
 static size_t chain_lds_base(const ChainParams& q, int max_size) {
     return sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
-           sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * (2 * ((size_t)max_size + 1) + kChainCtl) + 64;
+           sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * (kChainWaves * ((size_t)max_size + 1) + kChainCtl) + 64;
 }
 
 // the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU); flat mode may insist on

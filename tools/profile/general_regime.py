@@ -2,12 +2,12 @@
 """Developer aid: config 3 with scrambled names + Zipf partition weights (bench.py's general_regime workload b) at P x N
 through devbuild/libblance_prof.so (or the library BLANCE_DEV_LIB names) when it exists (per-launch statistics and phase clocks of k_pass_queue), BLANCE_TRACE style;
 BLANCE_DEV_PRODUCT=1: through the product library.
-    python tools/dev_general_regime.py [P N]"""
+    python tools/profile/general_regime.py [P N]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from blance_amd import hip, synth          # noqa: E402
 

@@ -2,12 +2,12 @@
 """Developer aid: config 3's plan rebalanced after every tenth node left (bench.py's general_regime workload a) at P x N, with
 the driver's trace (BLANCE_TRACE=1) / the queue kernel's statistics (BLANCE_QUEUE_STATS=1) when those are set; through
 devbuild/libblance_prof.so when it exists and BLANCE_DEV_PROF=1.
-    python tools/dev_rebalance_regime.py [P N [calls]]"""
+    python tools/profile/rebalance_regime.py [P N [calls]]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from blance_amd import hip, synth          # noqa: E402
 
