@@ -140,7 +140,8 @@ namespace blance {
 // command in LDS, joins the barrier, every wave scans its share of the nodes out of the LDS tables (keys, row bits,
 // counters -- all of them already there), leaves its k best (key, node) in LDS, second barrier, wave 0 merges.
 constexpr int kQueueWaves = 4;
-constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdTopL = 2, kQCmdExact = 3;
+constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdTopL = 2, kQCmdExact = 3, kQCmdStripe = 4;
+constexpr int kQStripeMin = 40;                     // entries a striped rebuild has to leave to be taken
 constexpr int kQTopL = 48;                          // entries each worker selects for the window's rebuild
 constexpr int kQScratch = 5632;                    // bytes the cooperative rebuild needs (aliases rowTag, which only a batch's validation uses)
 constexpr int kQCmdWords = 32, kQResWords = 4;      // a command block; one (key hi, key lo, node, -) result per wave and pick
@@ -484,6 +485,53 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         }
         if (lane == 0) { cntw[0] = wc; th65[0] = (int)(unsigned)(tK >> 32); th65[1] = (int)(unsigned)tK; th65[2] = tN; }
     };
+    // ---- the striped rebuild (worker 0 alone; folded batches): the window = every lane's smallest (key, node) below
+    // THETA' = the smallest of the lanes' SECOND smallest -- exactly the nodes below THETA' (a node outside is a lane's minimum
+    // >= THETA', or lies behind its lane's second) --, ranked by comparison against the 64 candidates in LDS.  One pass over the
+    // keys and 64 compares per lane instead of 48 successive wave minima on three waves: it comes out full when the smallest keys
+    // sit in different lanes -- many nodes of one load with consecutive ids, the regime in which a folded batch takes the
+    // window's front step after step and drains it every 64 steps -- and short otherwise (the caller then asks for topl_part).
+    // Results as exact_part's: winK / winN, cntw[0] = entries, th65 = THETA ((~0, INT_MAX): everything is in the window).
+    auto stripe_part = [&]() {
+        u64 m1 = ~0ull, m2 = ~0ull;
+        int n1 = INT_MAX, n2 = INT_MAX;
+        for (int i0 = 0; i0 < G; i0 += 8) {          // (8 independent LDS reads at a time; a lane's nodes ascend: ties keep the lower node in front)
+            u64 kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kv[u] = i0 + u < G ? gB[(i0 + u) * 64 + lane] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u64 v = kv[u];
+                const int n = (i0 + u) * 64 + lane;
+                const bool lt1 = v < m1, lt2 = v < m2;
+                m2 = lt1 ? m1 : (lt2 ? v : m2);
+                n2 = lt1 ? n1 : (lt2 ? n : n2);
+                m1 = lt1 ? v : m1;
+                n1 = lt1 ? n : n1;
+            }
+        }
+        if (m1 == ~0ull) n1 = INT_MAX;               // (no candidate in this lane)
+        if (m2 == ~0ull) n2 = INT_MAX;
+        const QMin t = wave_min_key_node(m2, n2);
+        const u64 tK = t.node == INT_MAX ? ~0ull : (((u64)t.hi << 32) | t.lo);
+        const int tN = t.node;
+        const bool in = n1 != INT_MAX && (tN == INT_MAX || qless(m1, n1, tK, tN));
+        runK[lane] = in ? m1 : ~0ull;
+        runN[lane] = in ? n1 : INT_MAX;
+        BLANCE_WAVE_SYNC();
+        int rank = 0;
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+            u64 ck[8];
+            int cn[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { ck[u] = runK[j0 + u]; cn[u] = runN[j0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank += qless(ck[u], cn[u], m1, n1) ? 1 : 0;
+        }
+        if (in) { winK[rank] = m1; winN[rank] = n1; }
+        const int cw = __popcll(__ballot(in));
+        if (lane == 0) { cntw[0] = cw; th65[0] = (int)(unsigned)(tK >> 32); th65[1] = (int)(unsigned)tK; th65[2] = tN; }
+    };
     if (wave != 0) {
         // ---- a helper wave: wait for a command, do its share, wait again
         for (;;) {
@@ -493,6 +541,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             if (op == kQCmdDense) dense_part();
             if (op == kQCmdTopL) topl_part();
             if (op == kQCmdExact && wave == 1) exact_part();
+            if (op == kQCmdStripe && wave == 1) stripe_part();
             lds_barrier();                           // (2) the answers are in
         }
         return;
@@ -545,14 +594,36 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     long long rb_cycles = 0, rb_scans = 0, rb_scan_cycles = 0;
 #endif
     int rb_wcnt = 0;                                 // entries the last rebuild left: a window that has not drained since is not rebuilt again
-    long long n_coop = 0;
+    long long n_coop = 0, n_stripe = 0;
+    int stripe_skip = 0;                             // rebuilds that do not try the striped form (the last try came out short)
+    int dense_streak = 0, dense_probe = 0;           // general steps in a row that ended in the dense scan; steps that went there directly
     // The window is rebuilt by the helper waves (topl_part): this wave posts the command, passes the barriers, and loads the
     // new window out of LDS.
     auto rebuild = [&]() {
 #ifdef BLANCE_PHASE_PROF
         const long long rb_t0 = clock64();
 #endif
-        if (!(q.spec & 64)) {
+        bool striped = false;
+        if (fold && stripe_skip == 0 && !(q.spec & 64) && NW > 1) {
+            // a folded batch drains the window from its front: try the one-pass striped form first (stripe_part)
+            if (lane == 0) hcmd[0] = kQCmdStripe;
+            lds_barrier();
+            lds_barrier();
+            const int wc = uni(cntw[0]);
+            const int tn = uni(th65[2]);
+            if (wc >= kQStripeMin || tn == INT_MAX) {
+                wk = lane < wc ? winK[lane] : ~0ull;
+                wn = lane < wc ? winN[lane] : INT_MAX;
+                wcnt = wc;
+                thK = uni64(((u64)(unsigned)th65[0] << 32) | (unsigned)th65[1]);
+                thN = tn;
+                striped = true;
+                n_stripe++;
+            } else stripe_skip = 16;                 // (the smallest keys share lanes: the next rebuilds do not try)
+            BLANCE_WAVE_SYNC();
+        } else if (stripe_skip > 0) stripe_skip--;
+        if (striped) {
+        } else if (!(q.spec & 64)) {
             if (lane == 0) hcmd[0] = kQCmdTopL;
             lds_barrier();                           // (1) posted
             lds_barrier();                           //     (the workers' own: their lists are in LDS)
@@ -582,6 +653,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         BLANCE_WAVE_SYNC();                          // (the scratch is rowTag's again after this)
         rb_wcnt = wcnt;
         n_rebuild++;
+        (void)n_stripe;
 #ifdef BLANCE_PHASE_PROF
         rb_cycles += clock64() - rb_t0;
 #endif
@@ -1212,7 +1284,14 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 }
             };
             int n_out = 0;
-            for (int attempt = (q.spec & 16) ? 2 : 0; ; attempt++) {      // (q.spec & 16: test knob, every general step scores every node)
+            // The window analysis in front of the dense scan (which candidates carry bits, can any pick be final below THETA)
+            // costs a third of what the scan does; in the tie regime -- many nodes at one load, every entry of the window held
+            // back by its matrix entry -- general step after general step ends in the scan.  After three in a row the steps
+            // go there directly (the scan is exact whatever the window holds), every eighth one looks at the window again.
+            bool went_dense = false;
+            int attempt = (q.spec & 16) ? 2 : 0;          // (q.spec & 16: test knob, every general step scores every node)
+            if (dense_streak >= 3 && ((++dense_probe) & 7) != 0) attempt = 2;
+            for (;; attempt++) {
                 attempt = uni(attempt);
 #pragma unroll
                 for (int j = 0; j < KM; j++) { bB[j] = ~0ull; bN[j] = INT_MAX; }
@@ -1290,6 +1369,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                     n_out = 0;
 #pragma unroll
                     for (int j = 0; j < KM; j++) if (j < k && bN[j] != INT_MAX) n_out++;
+                    went_dense = true;
                     break;
                 }
                 // window entries that are candidates for this partition (plan.go:142-156), and whose entry may be non-zero
@@ -1382,6 +1462,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
                 else attempt = 1;
             }
             PH(6);
+            dense_streak = went_dense ? (dense_streak < 1000 ? dense_streak + 1 : dense_streak) : 0;
             if (n_out < k) { stop_pos = oi + f; stop_why = kQStopShort; }      // fewer candidates than constraints: warnings
             if (stop_why != kQStopNone) { cur = f; break; }
             // a taken node that the partition holds in lower priority states is promoted (plan.go:294-297): it leaves those

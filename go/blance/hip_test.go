@@ -106,3 +106,19 @@ func TestHipMatchesPlanGo(t *testing.T) {
 	}
 	NodeScoreBooster = nil
 }
+
+// A call the device does not answer is reported: counters and the OnHipFallback hook (the API itself has no error channel).
+func TestHipFallbackIsReported(t *testing.T) {
+	var got []string
+	OnHipFallback = func(reason string) { got = append(got, reason) }
+	defer func() { OnHipFallback = nil; NodeScoreBooster = nil }()
+	before := HipStats()
+	NodeScoreBooster = func(w int, s float64) float64 { return 0 } // an arbitrary callback: not for the device
+	model := PartitionModel{"primary": &PartitionModelState{Priority: 0, Constraints: 1}}
+	parts := PartitionMap{"0": &Partition{Name: "0", NodesByState: map[string][]string{}}}
+	_, _, handled := planNextMapHip(PartitionMap{}, parts, []string{"a", "b"}, nil, []string{"a", "b"}, model, PlanNextMapOptions{})
+	after := HipStats()
+	if handled || after.Fallbacks != before.Fallbacks+1 || len(got) != 1 || got[0] == "" || after.LastReason != got[0] {
+		t.Fatalf("fallback not reported: handled %v, %+v -> %+v, hook %q", handled, before, after, got)
+	}
+}

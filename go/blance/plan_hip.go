@@ -44,6 +44,46 @@ var (
 	hipMu   sync.Mutex // the library serialises calls per context as well
 )
 
+// The API has no error channel (api.go:147-154): a call the device does not answer -- switched off, a custom sorter or
+// booster, no device, an input outside the envelope (INTEGRATION.md section 5), a device failure -- is answered by
+// plan.go's planner, silently as far as the caller's result goes.  HipStats and OnHipFallback say that it happened.
+type HipCounters struct {
+	DevicePlans uint64 // calls answered by the device
+	Fallbacks   uint64 // calls handed to the CPU planner
+	LastReason  string // why the last of those was (the refusal's text, or blance_last_error's)
+}
+
+var (
+	hipStatsMu sync.Mutex
+	hipStats   HipCounters
+	// OnHipFallback, when set, is called (outside every lock) with the reason of each call the CPU planner answers.
+	OnHipFallback func(reason string)
+)
+
+// HipStats returns the counters so far.
+func HipStats() HipCounters {
+	hipStatsMu.Lock()
+	defer hipStatsMu.Unlock()
+	return hipStats
+}
+
+func hipFellBack(reason string) {
+	hipStatsMu.Lock()
+	hipStats.Fallbacks++
+	hipStats.LastReason = reason
+	cb := OnHipFallback
+	hipStatsMu.Unlock()
+	if cb != nil {
+		cb(reason)
+	}
+}
+
+func hipAnswered() {
+	hipStatsMu.Lock()
+	hipStats.DevicePlans++
+	hipStatsMu.Unlock()
+}
+
 func hipContext() *C.blance_ctx {
 	hipOnce.Do(func() {
 		var opt C.blance_options
@@ -118,18 +158,22 @@ func planNextMapHip(
 	model PartitionModel,
 	options PlanNextMapOptions) (nextMap PartitionMap, warnings map[string][]string, handled bool) {
 	if !UseHIP {
+		hipFellBack("UseHIP is false")
 		return nil, nil, false
 	}
 	kind, err := boosterKindForDevice()
 	if err != nil {
+		hipFellBack(err.Error())
 		return nil, nil, false
 	}
 	ctx := hipContext()
 	if ctx == nil {
+		hipFellBack("no device context (blance_ctx_create failed)")
 		return nil, nil, false
 	}
 	f, err := internProblem(prevMap, partitionsToAssign, nodesAll, nodesToRemove, nodesToAdd, model, options, kind)
 	if err != nil {
+		hipFellBack(err.Error())
 		return nil, nil, false
 	}
 
@@ -214,13 +258,21 @@ func planNextMapHip(
 	res.warn_capacity = C.int64_t(PM)
 
 	hipMu.Lock()
+	runtime.LockOSThread() // blance_last_error is per OS thread: the two calls must not be split across threads
 	st := C.blance_plan(ctx, pb, res)
+	why := ""
+	if st != C.BLANCE_OK {
+		why = fmt.Sprintf("blance_plan status %d: %s", int(st), C.GoString(C.blance_last_error()))
+	}
+	runtime.UnlockOSThread()
 	hipMu.Unlock()
 	if st != C.BLANCE_OK {
 		// BLANCE_ERR_UNSUPPORTED: outside the envelope; anything else: the device failed -- the API
 		// has no error channel (api.go:147-154), so the CPU planner answers in both cases
+		hipFellBack(why)
 		return nil, nil, false
 	}
+	hipAnswered()
 	if int(res.iterations) == 0 { // MaxIterationsPerPlan <= 0: planNextMapEx returns (nil, nil)
 		return nil, nil, true
 	}
