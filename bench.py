@@ -177,7 +177,8 @@ def live_pmc(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(work, counter), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "1", "--warmup", "0",
-                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc", "--no-other-configs", "--no-transfers"]
+                   "--no-cpu-baseline", "--no-sharded", "--no-extra", "--no-live-pmc", "--no-other-configs", "--no-transfers",
+                   "--no-replicas", "--no-rccl-one-rank"]
             if args.parts:
                 cmd += ["--parts", str(args.parts)]
             if args.nodes:

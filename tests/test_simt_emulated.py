@@ -107,6 +107,35 @@ def test_region_chains(emu_lib):
     pl.close()
 
 
+def test_chain_rounds_of_several_waves(emu_lib):
+    """k_pass_chain's stay rounds on four waves (round 6): 256 steps tested at once, a lane adding the row bumps of the earlier
+    steps of the round that share its top priority node.  Small zones make top priority nodes repeat inside a round (16 and 32
+    leaves per zone: every 16th / 32nd step, also inside one wave's 64: the prefix then ends at the second one), zones of 128
+    leaves make them repeat across the waves only; k_stay_by_top is off so that the converged sweeps run here too; with
+    partition and node weights (no packed keys) and without."""
+    from blance_amd import problem
+    for rack, rpz, N, P in ((4, 4, 64, 3000), (8, 4, 128, 2500), (16, 8, 256, 4096)):
+        for weighted in (False, True):
+            c = synth.config_case(3, P=P, N=N)
+            c["nodeHierarchy"] = synth.hierarchy_names(N, rack=rack, racks_per_zone=rpz, zones_per_dc=2)
+            if weighted:
+                c["partitionWeights"] = {str(i): 1 + (i * 7) % 3 for i in range(P)}
+                c["nodeWeights"] = {("n%04d" % i): [1, 1, 2, 4][(i * 5) % 4] for i in range(N)}
+                c["stateStickiness"] = {"primary": 100, "replica": 10}
+            fp = synth.case_to_flat(c)
+            want = _oracle(fp)
+            for kw in (dict(stay_top="off"), dict()):
+                pl = hip.Planner(lib_path=emu_lib, chain_min_parts=8, **kw)
+                got = pl.plan(fp)
+                assert (got.digest(), got.iterations) == (want.digest(), want.iterations), (rack, rpz, N, weighted, kw)
+                assert got.struct.steps_batched > 0
+                # and the rebalance from it (events, general steps between the rounds)
+                fp2 = synth.config3_rebalance_flat(fp, want) if not weighted else None
+                if fp2 is not None:
+                    assert pl.plan(fp2).digest() == _oracle(fp2).digest(), (rack, rpz, N, "rebalance", kw)
+                pl.close()
+
+
 def test_stays_verified_per_top_priority_node(emu_lib):
     """k_stay_by_top tried in EVERY chain pass with NumPartitions > 0 (knob "force"): passes of stays are taken by it,
     any other pass makes it raise its flag and the chain kernel redoes the pass -- same results either way; and the
