@@ -1203,11 +1203,41 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
     return 0;
 }
 
+// The compact records a flat single chain walks (clusters of <= 256 names), made when a pass first needs them: a pass the
+// bulk runs settle entirely (config 2: every pass) never pays for the gather and its round trip.
+struct FlatChainPrep {
+    bool possible = false, done = false, ok = false;
+    DevProblem d;
+    int m = 0, higher_mask = 0;
+    const int32_t* order = nullptr;
+};
+static int flat_chain_prepare(blance_ctx* c, FlatChainPrep& fc, int64_t* launches) {
+    if (fc.done || !fc.possible) return 0;
+    fc.done = true;
+    const blance_problem& h = c->h;
+    hipStream_t sm = c->stream;
+    int32_t* scal = c->scalars.as<int32_t>();
+    HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
+    c->flags_clean = false;
+    BLANCE_LAUNCH(k_gather_chain, cdiv(h.n_parts, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, fc.d, fc.m, h.top_state, fc.higher_mask,
+                         fc.order, (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
+                         c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
+                         c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
+                         c->fl_one.as<int32_t>(), 1,
+                         c->crec.as<int32_t>(), scal + 4, (int32_t*)nullptr);
+    int32_t bad = 0;
+    HIPTRY(read_back(c, &bad, scal + 4, sizeof bad));
+    HIPTRY(stream_sync(c));
+    *launches += 1;
+    fc.ok = !bad;                                  // (bad: some step does not fit the compact record)
+    return 0;
+}
+
 // A flat pass (no hierarchy rule for the state): runs of certain stays and of
 // fresh identical partitions are resolved in bulk, the rest by k_pass_seq in
 // order on sub-ranges.  See the "Flat bulk engine" comment above the kernels.
 static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
-                         bool chain_ok) {
+                         FlatChainPrep& fc) {
     hipStream_t sm = c->stream;
     c->bits_stale = true;                           // (the bulk kernels below bump nodeToNodeCounts, not k_pass_queue's bit maps)
     const int P = q.P;
@@ -1307,8 +1337,9 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             }
         }
         int B = P - pos < seq_batch ? P - pos : seq_batch;
-        int e;
-        if (chain_ok) {                               // small cluster: one wave64 walks the batch
+        int e = flat_chain_prepare(c, fc, launches);
+        if (e) return e;
+        if (fc.ok) {                                  // small cluster: one wave64 walks the batch
             e = run_flat_chain(c, q, pos, pos + B, false, scal, launches);
             if (e < 0) return e;
         } else {
@@ -2065,29 +2096,22 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             bool flat_chain = c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && c->flat_chain_ok && k <= 4 &&
                               P >= c->chain_min_parts;
             c->no_fast_keys = false;
-            if (flat_chain) {
-                HIPTRY(hipMemsetAsync(scal + 4, 0, 32, sm));
-                c->flags_clean = false;
-                BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, higher_mask,
-                                     order, (const int32_t*)nullptr, c->state_stick.as<int32_t>(),
-                                     c->state_has_stick.as<uint8_t>(), c->fl_iota.as<int32_t>(),
-                                     c->fl_zero.as<int32_t>(), c->fl_reglo.as<int32_t>(), c->fl_iota.as<int32_t>(),
-                                     c->fl_one.as<int32_t>(), 1,
-                                     c->crec.as<int32_t>(), scal + 4, (int32_t*)nullptr);
-                int32_t bad = 0;
-                HIPTRY(read_back(c, &bad, scal + 4, sizeof bad));
-                HIPTRY(stream_sync(c));
-                launches++;
-                if (bad) flat_chain = false;       // some step does not fit the compact record
+            FlatChainPrep fc;
+            fc.possible = flat_chain; fc.d = d; fc.m = m; fc.higher_mask = higher_mask; fc.order = order;
+            const bool bulk = c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && (k == 1 || (k == 2 && NP == 0)) &&
+                              P >= c->chain_min_parts;
+            if (flat_chain && !bulk) {               // (the bulk driver asks for the records when a sub-range needs them)
+                const int pe = flat_chain_prepare(c, fc, &launches);
+                if (pe) return pe;
+                flat_chain = fc.ok;
             }
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
             int e;
             c->pass_kind.resize(n_pass + 1);
             // the flat bulk driver: k = 1, and the first sweep of a fresh plan (NumPartitions == 0) with k = 2
-            if (c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && (k == 1 || (k == 2 && NP == 0)) &&
-                P >= c->chain_min_parts) {
+            if (bulk) {
                 c->pass_kind[n_pass] = 1;
-                e = run_flat_pass(c, q, scal, &launches, &batched, flat_chain);
+                e = run_flat_pass(c, q, scal, &launches, &batched, fc);
             } else if (flat_chain) {
                 c->pass_kind[n_pass] = 0;
                 const size_t rows = sizeof(int32_t) * (size_t)(NX + 1) * (NX + 1);
