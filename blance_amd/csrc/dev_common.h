@@ -45,7 +45,7 @@ struct RedSlot { unsigned hi, lo; int n; int pad; };
 #ifdef BLANCE_PHASE_PROF     // developer build only: per-phase shader-clock totals of chain 0
 #define PH_DECL unsigned long long ph_acc[20] = {0}, ph_t0 = clock64(), ph_t1
 #define PH(i) do { ph_t1 = clock64(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
-#define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 12; i_++) \
+#define PH_DUMP(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 20; i_++) \
     printf("[phase %d] %.1f cycles/step\n", i_, (double)ph_acc[i_] / (double)(steps)); } } while (0)
 #elif defined(BLANCE_ASM_MARKS)   // developer build only: phase markers as comments in the ISA
 #define PH_DECL

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             const int sb = b + a;
             const bool active = sb < nb;
             const bool multi = NWv > 1 && nb - b > 64;   // the helper waves test the steps behind my 64
+            PH(12);
             if (multi) {
                 if (lane == 0) {
                     ctl[0] = 1; ctl[1] = b; ctl[2] = nb; ctl[3] = next_ev_oi;
@@ -475,14 +476,17 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
                 }
                 lds_barrier();                         // (A)
             }
+            PH(13);
             stay_mark(sb, active, b, a, 0);
             if (multi) lds_barrier();                  // (M)
             else BLANCE_WAVE_SYNC();
+            PH(14);
             int on[KM];
             const bool fail = stay_test(sb, active, b, a, 0, next_ev_oi, gmin_s, gmin_n, on);
             stay_stage(sb, active, on);
             const unsigned long long fm = __ballot(fail);
             int nok = fm ? __ffsll((long long)fm) - 1 : 64;
+            PH(15);
             if (multi) {
                 lds_barrier();                         // (B) the helpers' verdicts on the steps from b + 64 on
                 for (int w2 = 1; w2 < NWv && nok == 64 * w2; w2++) {
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
                     nok += hf ? __ffsll((long long)hf) - 1 : 64;
                 }
             }
+            PH(16);
             // the committed prefix bumps its rows (plan.go:238-245); 64 steps at a time: no two of them share a row
             if (!FAST && NP > 0) {
                 for (int u = 0; 64 * u < nok; u++) {
@@ -504,6 +509,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             }
             BLANCE_WAVE_SYNC();
             stay_unmark(sb, active, b, 0);
+            PH(17);
             if (lane == 0) { spec_steps += nok; spec_batches++; }
             b += nok;
             if (b >= nb) break;
@@ -864,10 +870,12 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
         if (__ballot(range_bad)) { escaped = true; stop_range = true; break; }
       }
       BLANCE_WAVE_SYNC();
+      PH(18);
       stop_at = base + b;
       // flat mode keeps the steps done before a stop; a region chain's pass is redone as a whole
       const int n_done = (!escaped || q.flat) ? b : 0;
       for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
+      PH(19);
     }
     if (NWv > 1) {                                   // the helpers leave
         if (lane == 0) ctl[0] = 0;
