@@ -111,20 +111,22 @@ constexpr int kKeyBias = 1 << 17;
 constexpr unsigned kKeyNone = 0xffffffffu;
 constexpr int kCompactMax = 8000;    // |count| bound of the compact keys of the blank-run loop
 
-constexpr int kStageVec = kChainStage * (kCW / 4) / 64;      // 16-byte words of a stage per lane
-static_assert(kCW % 4 == 0 && kStageVec == 24 && kChainStage * (kCW / 4) % 64 == 0, "BLANCE_STAGE_EACH lists 24 words per lane");
-// the 24 words as 24 named values: as an array the compiler keeps them in scratch memory, and a store to scratch
-// waits for the load it stores
-#define BLANCE_STAGE_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
-    X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
+constexpr int kChainWaves = 4;                     // waves of a region's workgroup (k_pass_chain below)
+constexpr int kStageVec = kChainStage * (kCW / 4) / (64 * kChainWaves);      // 16-byte words of a stage per lane of one wave
+static_assert(kCW % 4 == 0 && kStageVec == 6 && kChainStage * (kCW / 4) % (64 * kChainWaves) == 0, "BLANCE_STAGE_EACH lists 6 words per lane");
+// A stage's records (24 KB) travel as 16-byte loads, each wave of the workgroup its quarter (the records of the 64 steps it
+// tests in a round that starts with the stage): 6 per lane, ALL in flight at once and a stage ahead.  The words as named
+// values: as an array the compiler keeps them in scratch memory, and a store to scratch waits for the load it stores.
+#define BLANCE_STAGE_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define BLANCE_STAGE_DECL(t) int4 pre##t = {0, 0, 0, 0};
-#define BLANCE_STAGE_FETCH(t) { const int i_ = lane + 64 * t; pre##t = src_[i_ < n4_ ? i_ : 0]; }
-#define BLANCE_STAGE_COMMIT(t) dst_[lane + 64 * t] = pre##t;      /* the whole stage area: words past a short stage are never read */
+#define BLANCE_STAGE_FETCH(t) { const int i_ = q0_ + lane + 64 * t; pre##t = src_[i_ < n4_ ? i_ : 0]; }
+#define BLANCE_STAGE_COMMIT(t) dst_[q0_ + lane + 64 * t] = pre##t;      /* the whole quarter: words past a short stage are never read */
 // (words past a short stage re-read its first one: nothing outside the stage's records is touched; a record is 96 bytes,
 // 16-byte aligned)
 #define BLANCE_STAGE_FETCH_ALL(crec, base_, cend_)                                                               \
     {                                                                                                             \
         const int n4_ = ((cend_) - (base_) < kChainStage ? (cend_) - (base_) : kChainStage) * (kCW / 4);          \
+        const int q0_ = wave * (64 * kStageVec);                                                                  \
         const int4* src_ = (const int4*)((crec) + (size_t)(base_) * kCW);                                         \
         BLANCE_STAGE_EACH(BLANCE_STAGE_FETCH)                                                                     \
     }
@@ -139,10 +141,11 @@ static_assert(kCW % 4 == 0 && kStageVec == 24 && kChainStage * (kCW / 4) % 64 ==
 // same wave with that node fails, as before), and a lane of wave w looks its node up in the tables of waves 0 .. w - 1 -- a
 // hit names the one step of that wave whose row bumps it has to count (that step keeps its nodes if it is committed at all:
 // the round commits a prefix).  Wave 0 combines the verdicts, commits the prefix's row bumps from the records (the waves
-// have staged their steps' outputs already -- a slot that is not committed is written again by whatever commits it).  Three
-// LDS-only barriers per round of 256 steps.  Everything else (events, blank runs, general steps) is wave 0's alone, the
-// helpers parked on the barrier.
-constexpr int kChainWaves = 4;
+// have staged their steps' outputs already -- a slot that is not committed is written again by whatever commits it).  Every
+// wave bumps the rows of ITS committed steps (LDS atomics; a round that is not committed whole ends with one more barrier so
+// that wave 0 sees them).  The waves also share a stage's housekeeping (kQCmd 2, stage_service): each commits its quarter of
+// the stage's records from its own prefetch registers and writes its quarter of the finished stage's outputs to HBM.
+// Everything else (events, blank runs, general steps) is wave 0's alone, the helpers parked on the barrier.
 constexpr int kChainCtl = 32;                       // words of the command block between the waves
 
 template <int NPTC, int KM, bool FAST>
@@ -194,16 +197,17 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
         (void)b0;
     };
     auto stay_test = [&](const int sb, const bool active, const int b0, const int a, const int w, const int next_ev,
-                         const double bound_s, const int bound_n, int (&on)[KM]) -> bool {
+                         const double bound_s, const int bound_n, int (&on)[KM], int (&oi)[KM], int& vtl_out) -> bool {
         const int* rp = recbuf + (active ? sb : b0) * kCW;
         bool fail = false;
         const double vstick = __hiloint2double(rp[3], rp[2]);
         const int vtl = rp[4];
+        vtl_out = vtl;
         const int mt = (vtl >= 0 && vtl <= size) ? vtl : size;
         const int cn = rp[5];
         if (!((cn >> 24) & 1) || (cn & 0xff) != k || ((cn >> 25) & 1)) fail = true;   // exactly k nodes, all here
         if (rp[0] > next_ev) fail = true;                             // an event comes first
-        int oc[KM + 1], oi[KM], adj[KM];
+        int oc[KM + 1], adj[KM];
         double so[KM];
         oc[0] = rp[6];
 #pragma unroll
@@ -297,23 +301,73 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             for (int j = 0; j < KM; j++) if (j < k) op[1 + j] = on[j];
         }
     };
+    // the prefix's row bumps, every wave its own steps (plan.go:238-245): lanes below `mine` of this wave are committed
+    auto stay_bump = [&](const int a, const int mine, const int vtl, const int (&oi)[KM]) {
+        if (!FAST && NP > 0 && a < mine) {
+#pragma unroll
+            for (int j = 0; j < KM; j++) if (j < k) atomicAdd(&ntn_l[vtl * ST + oi[j]], 1);
+        }
+    };
+    // a round's committed prefix from the waves' verdicts (bit a of wave w: step b + 64 w + a is NOT a certain stay)
+    auto round_prefix = [&]() -> int {
+        int nok = 0;
+        for (int w2 = 0; w2 < NWv && nok == 64 * w2; w2++) {
+            const unsigned long long hf = ((unsigned long long)(unsigned)ctl[9 + 2 * w2] << 32) | (unsigned)ctl[8 + 2 * w2];
+            nok += hf ? __ffsll((long long)hf) - 1 : 64;
+        }
+        return uni(nok);
+    };
+    // ---- a stage's housekeeping, every wave a quarter (command 2; ctl[7]: 1 = this stage's records into LDS, 2 = the finished
+    // stage's outputs to HBM).  Quarter w = the 64 steps wave w tests in a round that starts with the stage.
+    BLANCE_STAGE_EACH(BLANCE_STAGE_DECL)
+    if (cbeg < cend) BLANCE_STAGE_FETCH_ALL(q.crec, cbeg, cend)
+    auto stage_service = [&](const int fl) {
+        // (the records first: their loads were issued a stage ago, and behind the output stores below the wait for them
+        // would be a wait for the stores -- loads and stores share the counter)
+        if (fl & 1) {
+            int4* dst_ = (int4*)recbuf;
+            const int q0_ = wave * (64 * kStageVec);
+            BLANCE_STAGE_EACH(BLANCE_STAGE_COMMIT)
+            BLANCE_WAVE_SYNC();                      // (a lane reads records other lanes of its wave wrote; LDS is in order within a wave)
+        }
+        if (fl & 2) {
+            const int pbase = uni(ctl[18]), nd = uni(ctl[19]);
+            const int hi = nd < 64 * wave + 64 ? nd : 64 * wave + 64;
+            for (int i = 64 * wave * q.OW + lane; i < hi * q.OW; i += 64) q.out[(size_t)pbase * q.OW + i] = outbuf[i];
+        }
+        if (fl & 1) {
+            const int sbase = uni(ctl[16]);
+            if (sbase + kChainStage < cend) BLANCE_STAGE_FETCH_ALL(q.crec, sbase + kChainStage, cend)
+        }
+    };
     if (wave != 0) {
-        // ---- a helper wave: parked on the barrier until wave 0 posts a round
+        // ---- a helper wave: parked on the barrier until wave 0 posts a command
         for (;;) {
             lds_barrier();                           // (A) posted; the tables are as the round sees them
-            if (uni(ctl[0]) == 0) break;
+            const int cmd = uni(ctl[0]);
+            if (cmd == 0) break;
+            if (cmd == 2) {
+                stage_service(uni(ctl[7]));
+                lds_barrier();                       // (S) the stage's records are in LDS, the last stage's outputs on their way
+                continue;
+            }
             const int b0 = uni(ctl[1]), nbh = uni(ctl[2]);
+            if (uni(ctl[7])) stage_service(uni(ctl[7]));     // (a stage's first round carries its housekeeping: my steps' records are mine)
             const int sb = b0 + 64 * wave + lane;
             const bool active = sb < nbh;
             stay_mark(sb, active, b0, lane, wave);
-            lds_barrier();                           // (M) every wave's table is complete
-            int on[KM];
-            const bool fail = stay_test(sb, active, b0, lane, wave, uni(ctl[3]), __hiloint2double(uni(ctl[5]), uni(ctl[4])), uni(ctl[6]), on);
+            lds_barrier();                           // (M) every wave's table is complete; so are the stage's records
+            int on[KM], oi[KM], vtl = 0;
+            const bool fail = stay_test(sb, active, b0, lane, wave, uni(ctl[3]), __hiloint2double(uni(ctl[5]), uni(ctl[4])), uni(ctl[6]),
+                                        on, oi, vtl);
             stay_stage(sb, active, on);
             const unsigned long long fm = __ballot(fail);
             if (lane == 0) { ctl[8 + 2 * wave] = (int)(unsigned)fm; ctl[9 + 2 * wave] = (int)(unsigned)(fm >> 32); }
             lds_barrier();                           // (B) the verdicts are in
+            const int nok = round_prefix();
+            stay_bump(lane, nok - 64 * wave, vtl, oi);
             stay_unmark(sb, active, b0, wave);
+            if (b0 + nok < nbh) lds_barrier();       // (C) wave 0 goes on alone inside the stage: it has to see the bumps
         }
         return;
     }
@@ -418,20 +472,24 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
     // issued when the previous stage starts and land in LDS when it ends -- one wave per CU has nothing else to hide the
     // HBM round trip behind (a copy loop of dword loads, 16 in flight, paid six round trips per stage: more than the
     // stage's steps).
-    BLANCE_STAGE_EACH(BLANCE_STAGE_DECL)
-    if (cbeg < cend) BLANCE_STAGE_FETCH_ALL(q.crec, cbeg, cend)
+    int prev_base = 0, prev_done = 0;              // the finished stage whose outputs are still in LDS
+    auto post_service = [&](const int fl, const int sbase) {
+        if (lane == 0) { ctl[0] = 2; ctl[7] = fl; ctl[16] = sbase; ctl[18] = prev_base; ctl[19] = prev_done; }
+        lds_barrier();                               // (A)
+        stage_service(fl);
+        lds_barrier();                               // (S)
+        prev_done = 0;
+    };
     for (int base = cbeg; base < cend && !escaped; base += kChainStage) {
       const int nb = cend - base < kChainStage ? cend - base : kChainStage;
       PH(0);
-      {
-          int4* dst_ = (int4*)recbuf;
-          BLANCE_STAGE_EACH(BLANCE_STAGE_COMMIT)
-      }
-      if (base + kChainStage < cend) BLANCE_STAGE_FETCH_ALL(q.crec, base + kChainStage, cend)
-      BLANCE_WAVE_SYNC();                            // one wave per workgroup: LDS is in order; a __syncthreads() would wait for the loads just issued
+      // The stage's housekeeping rides on its first round when that round is certain to come: no event can be due (the test
+      // for one reads the stage's first record), the last step was a stay.  Else it is a command of its own.
+      int pending_fl = 1 | (prev_done > 0 ? 2 : 0);
+      if (!(spec_ok && try_spec && next_ev_oi == INT_MAX && nb > 64)) { post_service(pending_fl, base); pending_fl = 0; }
       int b = 0;
       while (b < nb) {
-        while (next_ev_oi < recbuf[b * kCW]) apply_event();      // due before this step (pass order)
+        while (!pending_fl && next_ev_oi < recbuf[b * kCW]) apply_event();      // due before this step (pass order)
         // ---- Speculate that the next (up to 64) steps keep their nodes.  A stay
         // changes no counter, so under that hypothesis every step sees the state as
         // it is now and lane a can check step b + a on its own: the partition's
@@ -467,48 +525,38 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             const int a = lane;
             const int sb = b + a;
             const bool active = sb < nb;
-            const bool multi = NWv > 1 && nb - b > 64;   // the helper waves test the steps behind my 64
+            const bool multi = nb - b > 64;            // the helper waves test the steps behind my 64
             PH(12);
             if (multi) {
                 if (lane == 0) {
                     ctl[0] = 1; ctl[1] = b; ctl[2] = nb; ctl[3] = next_ev_oi;
                     ctl[4] = __double2loint(gmin_s); ctl[5] = __double2hiint(gmin_s); ctl[6] = gmin_n;
+                    ctl[7] = pending_fl; ctl[16] = base; ctl[18] = prev_base; ctl[19] = prev_done;
                 }
                 lds_barrier();                         // (A)
+                if (pending_fl) { stage_service(pending_fl); pending_fl = 0; prev_done = 0; }
             }
             PH(13);
             stay_mark(sb, active, b, a, 0);
             if (multi) lds_barrier();                  // (M)
             else BLANCE_WAVE_SYNC();
             PH(14);
-            int on[KM];
-            const bool fail = stay_test(sb, active, b, a, 0, next_ev_oi, gmin_s, gmin_n, on);
+            int on[KM], oi[KM], vtl = 0;
+            const bool fail = stay_test(sb, active, b, a, 0, next_ev_oi, gmin_s, gmin_n, on, oi, vtl);
             stay_stage(sb, active, on);
             const unsigned long long fm = __ballot(fail);
             int nok = fm ? __ffsll((long long)fm) - 1 : 64;
             PH(15);
             if (multi) {
-                lds_barrier();                         // (B) the helpers' verdicts on the steps from b + 64 on
-                for (int w2 = 1; w2 < NWv && nok == 64 * w2; w2++) {
-                    const unsigned long long hf = ((unsigned long long)(unsigned)ctl[9 + 2 * w2] << 32) | (unsigned)ctl[8 + 2 * w2];
-                    nok += hf ? __ffsll((long long)hf) - 1 : 64;
-                }
+                if (lane == 0) { ctl[8] = (int)(unsigned)fm; ctl[9] = (int)(unsigned)(fm >> 32); }
+                lds_barrier();                         // (B) every wave's verdicts
+                nok = round_prefix();
             }
             PH(16);
-            // the committed prefix bumps its rows (plan.go:238-245); 64 steps at a time: no two of them share a row
-            if (!FAST && NP > 0) {
-                for (int u = 0; 64 * u < nok; u++) {
-                    if (64 * u + a < nok) {
-                        const int* hp = recbuf + (b + 64 * u + a) * kCW;
-                        const int ht = hp[4];
-#pragma unroll
-                        for (int j = 0; j < KM; j++) if (j < k) atomicAdd(&ntn_l[ht * ST + hp[kCOwn + j]], 1);
-                    }
-                    BLANCE_WAVE_SYNC();
-                }
-            }
+            stay_bump(a, nok, vtl, oi);                // (my own steps; the helpers bump theirs)
             BLANCE_WAVE_SYNC();
             stay_unmark(sb, active, b, 0);
+            if (multi && b + nok < nb) lds_barrier();  // (C) the helpers' bumps before this wave goes on alone
             PH(17);
             if (lane == 0) { spec_steps += nok; spec_batches++; }
             b += nok;
@@ -874,13 +922,12 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
       stop_at = base + b;
       // flat mode keeps the steps done before a stop; a region chain's pass is redone as a whole
       const int n_done = (!escaped || q.flat) ? b : 0;
-      for (int i = lane; i < n_done * q.OW; i += 64) q.out[(size_t)base * q.OW + i] = outbuf[i];
+      prev_base = base; prev_done = n_done;          // (written out by the four waves when the next stage starts)
       PH(19);
     }
-    if (NWv > 1) {                                   // the helpers leave
-        if (lane == 0) ctl[0] = 0;
-        lds_barrier();
-    }
+    if (prev_done > 0) post_service(2, 0);           // the last stage's outputs
+    if (lane == 0) ctl[0] = 0;                       // the helpers leave
+    lds_barrier();
     if (!escaped) while (ev_cur < ev_end) apply_event();      // nodes that leave after this region's last step
     if (__ballot(range_bad)) { escaped = true; stop_range = true; }
     PH_DUMP(cend - cbeg);

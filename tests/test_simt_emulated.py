@@ -15,14 +15,17 @@ from randgen import random_case, random_regular_case
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_SRC = os.path.join(HERE, "simt", "emu_lib.cpp")
 EMU_SO = os.path.join(HERE, "simt", "_build", "libblance_emu.so")
-DEPS = [EMU_SRC, os.path.join(HERE, "simt", "hip_emu.h"), os.path.join(HERE, "..", "include", "blance_hip.h")] + [
-    os.path.join(HERE, "..", "blance_amd", "csrc", f) for f in
-    ("blance_hip.hip", "tu_seq.hip", "tu_tree.hip", "tu_queue.hip", "tu_chain.hip", "dev_prelude.h", "blance_kernels.h", "dev_common.h",
-     "k_pass_seq.h", "k_pass_tree.h", "k_pass_queue.h", "k_pass_chain.h", "k_flat.h", "k_sweep.h", "k_period.h", "k_stay.h")]
+def _deps():
+    """Everything the emulator library is compiled from: its own two files, the ABI header, and EVERY source under
+    blance_amd/csrc (a list kept by hand missed k_queue_walk.h once)."""
+    import glob
+    csrc = os.path.join(HERE, "..", "blance_amd", "csrc")
+    return [EMU_SRC, os.path.join(HERE, "simt", "hip_emu.h"), os.path.join(HERE, "..", "include", "blance_hip.h")] + \
+        sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")))
 
 
 def build_emu():
-    stale = (not os.path.exists(EMU_SO)) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in DEPS)
+    stale = (not os.path.exists(EMU_SO)) or any(os.path.getmtime(d) > os.path.getmtime(EMU_SO) for d in _deps())
     if stale:
         os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared",
