@@ -257,6 +257,7 @@ struct blance_ctx {
     bool queue_no_asm = false;      // test knob (& 4096): k_pass_queue's lean walk as compiled C++ only
     bool queue_force_dense = false; // test knob (& 2048): every general step of k_pass_queue scores every node
     bool queue_exact_rebuild = false; // test knob (& 8192): k_pass_queue's window always rebuilt by the exact selection
+    bool queue_bits_self = false;   // test knob (& 32768): k_pass_queue's walking wave copies the row bit maps itself (no helper)
     bool shard_one_rank = false;    // test knob (& 16384): a communicator of ONE rank takes the sharded branch of a chain pass, so that
                                     // both collectives really execute (ncclAllReduce / ncclAllGather on a one-GPU box)
     DevBuf ntn_bits;                // k_pass_queue: one bit per nodeToNodeCounts entry, zeroed with the matrix
@@ -514,6 +515,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     c->queue_no_asm = opt && (opt->reserved[2] & 4096);
     c->queue_exact_rebuild = opt && (opt->reserved[2] & 8192);
     c->shard_one_rank = opt && (opt->reserved[2] & 16384);
+    c->queue_bits_self = opt && (opt->reserved[2] & 32768);
     c->no_stay_top = opt && (opt->reserved[2] & 64);
     c->force_stay_top = opt && (opt->reserved[2] & 128);
     c->periodic = !(opt && (opt->reserved[2] & 256));
@@ -1073,7 +1075,8 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
     q.ntn_bits = c->ntn_bits.as<uint32_t>();
     q.stop = scal + 16;
     q.qstats = (long long*)(scal + 18);
-    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0) | (c->queue_exact_rebuild ? 64 : 0);
+    q.spec = (c->queue_general ? 8 : 0) | (c->queue_force_dense ? 16 : 0) | (c->queue_no_asm ? 32 : 0) | (c->queue_exact_rebuild ? 64 : 0) |
+             (c->queue_bits_self ? 128 : 0);
     int pos = q0.beg, chunk = 64;
     while (pos < q0.end) {
         q.beg = pos; q.end = q0.end;

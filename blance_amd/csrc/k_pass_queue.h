@@ -140,7 +140,7 @@ namespace blance {
 // command in LDS, joins the barrier, every wave scans its share of the nodes out of the LDS tables (keys, row bits,
 // counters -- all of them already there), leaves its k best (key, node) in LDS, second barrier, wave 0 merges.
 constexpr int kQueueWaves = 4;
-constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdTopL = 2, kQCmdExact = 3, kQCmdStripe = 4;
+constexpr int kQCmdExit = 0, kQCmdDense = 1, kQCmdTopL = 2, kQCmdExact = 3, kQCmdStripe = 4, kQCmdBits = 5;
 constexpr int kQStripeMin = 40;                     // entries a striped rebuild has to leave to be taken
 constexpr int kQTopL = 48;                          // entries each worker selects for the window's rebuild
 constexpr int kQScratch = 5632;                    // bytes the cooperative rebuild needs (aliases rowTag, which only a batch's validation uses)
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
     static_assert((kQueueWaves - 1) * 64 * 12 + 64 * 12 + 16 + 8 * kQueueWaves + 16 <= kQScratch, "scratch");
     int* hcmd = (int*)(ntL + NXp);                   // [kQCmdWords] wave 0's command to the helper waves
     int* hres = hcmd + kQCmdWords;                   // [kQueueWaves * KM * kQResWords] their answers
+    int* rowS = hres + kQueueWaves * KM * kQResWords;   // [64] the rows of the batch's steps (kQCmdBits)
 
     // ---- the dense step's share of one wave: the k best (key, node) among the candidates 64 i + lane, i in this wave's
     // columns, for the step the command describes -- clean entries by their keys in LDS, entries with their bit set read
@@ -532,6 +533,39 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         const int cw = __popcll(__ballot(in));
         if (lane == 0) { cntw[0] = cw; th65[0] = (int)(unsigned)(tK >> 32); th65[1] = (int)(unsigned)tK; th65[2] = tN; }
     };
+    // ---- the row bit maps of a batch's steps into LDS (round 6; the helper waves, while wave 0 tags dirty rows and scores the own
+    // nodes): helper h takes every third pair of rows; lanes 0..31 / 32..63 copy one 4 BW-byte row each per round (16-byte loads
+    // past the L1, all of a helper's rounds in flight at once).  Wave 0 has waited for the last batch's bumps before it posted.
+    auto bits_part = [&]() {
+        const int NH = NW - 1, hw = wave - 1;
+        const int Bb = uni(hcmd[1]);
+        const int BQ = BW >> 2, c = lane & 31, half = lane >> 5;
+        qv4 va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int g = hw + NH * u, r2 = 2 * g;
+            const int myrow = (g < 32 && r2 + half < Bb) ? rowS[r2 + half] : 0;
+            va[u] = q_load_row16((const qv4*)q.ntn_bits + (size_t)((g < 32 && r2 + half < Bb && c < BQ) ? myrow : 0) * BQ + (c < BQ ? c : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int g = hw + NH * (8 + u), r2 = 2 * g;
+            const int myrow = (g < 32 && r2 + half < Bb) ? rowS[r2 + half] : 0;
+            vb[u] = q_load_row16((const qv4*)q.ntn_bits + (size_t)((g < 32 && r2 + half < Bb && c < BQ) ? myrow : 0) * BQ + (c < BQ ? c : 0));
+        }
+        BLANCE_QROWS_ARRIVED(va);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int g = hw + NH * u, rr = 2 * g + half;
+            if (g < 32 && rr < Bb && c < BQ) ((qv4*)bitsL)[rr * BQ + c] = va[u];
+        }
+        BLANCE_QROWS_ARRIVED(vb);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int g = hw + NH * (8 + u), rr = 2 * g + half;
+            if (g < 32 && rr < Bb && c < BQ) ((qv4*)bitsL)[rr * BQ + c] = vb[u];
+        }
+    };
     if (wave != 0) {
         // ---- a helper wave: wait for a command, do its share, wait again
         for (;;) {
@@ -542,6 +576,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
             if (op == kQCmdTopL) topl_part();
             if (op == kQCmdExact && wave == 1) exact_part();
             if (op == kQCmdStripe && wave == 1) stripe_part();
+            if (op == kQCmdBits) bits_part();
             lds_barrier();                           // (2) the answers are in
         }
         return;
@@ -848,9 +883,17 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         }
         // ---- the row bit maps of the batch's steps: lanes 0..31 / 32..63 copy one 4 BW-byte row each per round
         // (16-byte loads past the L1; nothing bumps the maps before the batch ends)
+        bool bits_pending = false;
         if (NP > 0 && !fold) {
             const int BQ = BW >> 2;
-            if (BQ <= 32) {
+            if (BQ <= 32 && NW == kQueueWaves && !(q.spec & 128)) {
+                // the helper waves copy the rows (bits_part) while this wave goes on with what needs no bit: the dirty-row tags,
+                // the own nodes' exact keys; the second barrier stands in front of the walk  (q.spec & 128: test knob, this wave copies)
+                rowS[lane] = row;
+                if (lane == 0) { hcmd[0] = kQCmdBits; hcmd[1] = B; }
+                lds_barrier();                       // (1) posted
+                bits_pending = true;
+            } else if (BQ <= 32) {
                 // (all 32 rounds' loads in flight at once -- 128 registers, the wave has the file to itself -- one round trip to the L2)
                 qv4 v[4][8];
 #pragma unroll
@@ -954,6 +997,7 @@ __global__ __launch_bounds__(64 * kQueueWaves) void k_pass_queue(PassParams q) {
         if (act && !sfail) emit_stay();
         u64 stalemask = 0;                           // lanes whose own nodes' counters an earlier step of the batch changed
         BLANCE_WAVE_SYNC();
+        if (bits_pending) lds_barrier();             // (2) the batch's row bit maps are in LDS
 
         PH(3);
         int bumped_upto = 0;                         // steps [0, bumped_upto) of the batch have their rows bumped
@@ -1599,7 +1643,7 @@ static inline size_t queue_lds_bytes(int NX, int RW) {
     const size_t NXp = (size_t)((NX + 63) / 64) * 64, BW = ((NXp >> 5) + 3) & ~(size_t)3;
     const size_t RT = NXp + 64 > (size_t)kQScratch ? NXp + 64 : (size_t)kQScratch;      // rowTag / the cooperative rebuild's scratch
     return NXp * (8 + 4 + 4 + 4 + 1 + 1 + 2) + RT + sizeof(double) * (kLpTab + kFfTab) + sizeof(int32_t) * (size_t)(64 * RW) +
-           sizeof(int32_t) * 64 * 3 + sizeof(int32_t) * 64 * BW + 64 + sizeof(int32_t) * (kQCmdWords + kQueueWaves * 2 * kQResWords);
+           sizeof(int32_t) * 64 * 3 + sizeof(int32_t) * 64 * BW + 64 + sizeof(int32_t) * (kQCmdWords + kQueueWaves * 2 * kQResWords + 64);
 }
 
 }  // namespace blance

@@ -158,8 +158,9 @@ class Planner:
         # exact selection (one helper wave), never by the helper waves' striped form
         # 16384 = a communicator of ONE rank takes the sharded branch of every chain pass (both collectives execute:
         # how ncclAllReduce / ncclAllGather run on a one-GPU box)
+        # 32768 = its walking wave copies a batch's row bit maps itself (the helper waves do since round 6)
         qbits = {True: 0, "on": 0, False: 512, "off": 512, "general": 1024, "dense": 1024 | 2048, "lean-cpp": 4096,
-                 "exact-rebuild": 8192}[queue]
+                 "exact-rebuild": 8192, "bits-self": 32768}[queue]
         opt.reserved[2] = qbits | (16384 if shard_one_rank else 0) | (0 if periodic else 256) | {"auto": 0, "off": 64, "force": 128}[stay_top] | (0 if planes else 32) | (0 if seq_speculation else 1) | {"auto": 0, "off": 2, "dense": 4 | 8, "on": 8, "long": 8 | 16,
                                                           "dense-long": 4 | 8 | 16}[tree]
         h = C.c_void_p()
