@@ -704,7 +704,7 @@ def main():
         sq, sq_src = profile_json("r6_pmc_sq_config%d.json" % args.config)
         survey_state = synth.algorithmic_bytes_per_state(fp)          # the reference's dense scan, per pass of a state
 
-        def kernel_line(label, prefix, words, ms, launches, chains, dense_bytes, walked=True):
+        def kernel_line(label, prefix, words, ms, launches, chains, dense_bytes, walked=True, waves_per_chain=1):
             if not launches:
                 return None
             bytes_per_launch = 4.0 * words * P
@@ -733,8 +733,9 @@ def main():
             if chains:
                 chain_steps = -(-P // chains)
                 ns = avg_ms * 1e6 / chain_steps
-                line["occupancy"] = {"waves": chains, "cus": N_CUS, "simd_slots": N_CUS * SIMDS_PER_CU,
-                                     "simd_slots_used_frac": chains / float(N_CUS * SIMDS_PER_CU)}
+                line["occupancy"] = {"waves": chains * waves_per_chain, "cus": N_CUS, "simd_slots": N_CUS * SIMDS_PER_CU,
+                                     "simd_slots_used_frac": chains * waves_per_chain / float(N_CUS * SIMDS_PER_CU),
+                                     "waves_per_chain": waves_per_chain}
                 crit = {"chains_per_launch": chains, "dependent_steps_per_chain": chain_steps,
                         "avg_ns_per_dependent_step": ns, "avg_cycles_per_dependent_step": ns * SCLK_GHZ}
                 if not walked:
@@ -768,17 +769,19 @@ def main():
         dense_flat = max([survey_state[m] for m in range(M) if m not in kernel_states] or [0])
         if args.config == 5:
             kernels.append(kernel_line("k_pass_queue (flat replica pass, one wave64: the candidates as a sorted window over the lanes)",
-                                       ("k_pass_queue", "k_pass_tree"), RW + 1 + kmax, acc["pass_ms"], acc["pass_launches"], 1, dense_pass))
+                                       ("k_pass_queue", "k_pass_tree"), RW + 1 + kmax, acc["pass_ms"], acc["pass_launches"], 1, dense_pass,
+                                       waves_per_chain=4))           # (the walking wave and its three helper waves)
         else:
             zones = -(-N // 128)                     # zones of 8 racks x 16 nodes: one chain each
             kernels.append(kernel_line("all-blank replica pass of the first sweep (k_pass_chain_planes: scalar bit-plane automaton, one wave64 per "
                                        "hierarchy region; with k_period.h two periods walked and the periodic stretch copied)",
                                        ("k_pass_chain_planes", "k_pass_chain_blank", "k_period"), K_CW + 1 + kmax, acc["blank_ms"],
                                        acc["blank_launches"], zones, dense_pass, walked=bool(args.no_periodic)))
-            kernels.append(kernel_line("k_pass_chain<2,2,false> (the replica pass of a later sweep that still moves steps: one wave64 per "
-                                       "hierarchy region walks its steps in order, verified stays 64 at a time)",
+            kernels.append(kernel_line("k_pass_chain<2,2,false> (the replica pass of a later sweep that still moves steps: one workgroup of four "
+                                       "waves per hierarchy region -- one walks the region's steps in order, all four test 256 steps for stays at a time)",
                                        ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"] - acc["stay_ms"],
-                                       acc["pass_launches"] - acc["blank_launches"] - acc["stay_launches"], zones, dense_pass))
+                                       acc["pass_launches"] - acc["blank_launches"] - acc["stay_launches"], zones, dense_pass,
+                                       waves_per_chain=4))           # (k_pass_chain.h: kChainWaves -- the walking wave and three helpers of the stay test)
             kernels.append(kernel_line("k_stay_by_top (the replica pass of a converged sweep: every step verified as a stay by one thread per "
                                        "top priority node; the time includes the counting sort that groups the steps by top node)",
                                        ("k_stay_by_top",), K_CW + 1 + kmax, acc["stay_ms"], acc["stay_launches"], None, dense_pass))
