@@ -1253,6 +1253,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     fq.top_g = c->f_top_g.as<double>(); fq.top_n = c->f_top_n.as<int32_t>();
     fq.row_count = c->f_row_count.as<int32_t>();
     fq.ntn = q.ntn; fq.rec = q.rec; fq.out = q.out; fq.scan = scal + 8;
+    fq.int_keys = (q.NP == 0 && !c->any_node_weight) ? 1 : 0;
     if (q.NP > 0) {                                 // only read by the stay test when NP > 0
         if (!c->rowcount_clean) HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)q.NX + 1), sm));
         c->rowcount_clean = false;

@@ -160,6 +160,9 @@ struct FlatParams {
     int32_t* scan;                 // [0] first step that is not a certain stay, [1] first not fresh-identical
     int32_t* scan_part;            // [2][scan_waves] per wave of k_flat_scan: its first such step, reduced by k_flat_scan_min
     int32_t scan_waves;
+    int32_t int_keys;              // a fresh run's sort keys as the integers they are (NumPartitions == 0, no node has a weight: a
+                                   // score is count + picks * weight exactly) instead of their fp64 images: fewer varying bytes,
+                                   // one radix pass less; any order-preserving injection gives the same sorted values
 };
 
 }  // namespace blance

@@ -410,7 +410,9 @@ __global__ void k_fresh_emit(FlatParams q, int beg, int R, const int32_t* m_off,
     int n = lo, c = e - m_off[n];
     int w = q.rec[(size_t)beg * q.RW + 1];
     int ntn0 = q.NP > 0 ? q.ntn[(size_t)q.NX * q.N + n] : 0;
-    keys[e] = fresh_key(q, n, q.cnt[q.s * q.NX + n], q.tot[n], ntn0, w, c);
+    // (int_keys: node_score is (double)(cnt + c w) + 0.0 + 0.0 - 0.0 then, plan.go:664-686 with NumPartitions == 0 and no weight)
+    keys[e] = q.int_keys ? (unsigned long long)((long long)q.cnt[q.s * q.NX + n] + (long long)c * w + (1ll << 32))
+                         : fresh_key(q, n, q.cnt[q.s * q.NX + n], q.tot[n], ntn0, w, c);
     vals[e] = n;
 }
 
