@@ -51,6 +51,22 @@ def trace(db, calls, out, title):
              "%-62s %6s %12s %12s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "share")]
     for r in rows:
         lines.append("%-62s %6d %12.3f %12.1f %12.1f %12.1f %6.1f%%" % (short(r[0]), r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot))
+    # where the device idles between kernels (host round trips, launch latency): gaps between consecutive dispatches
+    try:
+        disp = cur.execute("select d.start, d.end from %s d order by d.start" % g("kernel_dispatch")).fetchall()
+        gaps, end = [], None
+        for s0, e0 in disp:
+            if end is not None and s0 > end:
+                gaps.append(s0 - end)
+            end = e0 if end is None or e0 > end else end
+        inner = sorted(x for x in gaps if x < 2e6)          # (gaps of milliseconds are between calls / around uploads: not a plan's)
+        lines.append("")
+        lines.append("device idle between consecutive kernels (gaps under 2 ms, i.e. inside calls): %d gaps, %.3f ms in total = %.3f ms per call; "
+                     "%d of them over 5 us (%.3f ms), the median %.1f us" % (
+                         len(inner), sum(inner) / 1e6, sum(inner) / 1e6 / calls, sum(1 for x in inner if x > 5e3),
+                         sum(x for x in inner if x > 5e3) / 1e6, (inner[len(inner) // 2] / 1e3) if inner else 0.0))
+    except Exception as e:                                   # (older databases: no timestamps table layout we know)
+        lines.append("(no gap statistics: %s)" % str(e)[:80])
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))
 
