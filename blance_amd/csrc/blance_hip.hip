@@ -238,6 +238,8 @@ struct blance_ctx {
     size_t comm_events_used = 0;
     double comm_ms = 0.0;                    // device time between those pairs, all plans so far
     int64_t n_syncs = 0, plan_syncs = 0;     // stream_sync() calls so far / inside the last plan
+    int speculate = 1;                       // host decisions taken before their words are read back (BLANCE_SPECULATE=0|1|fail)
+    int64_t spec_refuted = 0;                // ... and how often one had to be taken back
 
     // host copy of the small parts of the problem
     blance_problem h{};
@@ -270,7 +272,7 @@ struct blance_ctx {
         bool ok = false;
         int n_regions = 0, max_size = 0;
         DevBuf node_region, reg_lo, reg_hi, leaf_cls, cls_size;
-        DevBuf wg_region, wg_chunk;     // k_stay_by_top: workgroup b walks the tops at leaves reg_lo + 64 chunk + lane of its region
+        DevBuf wg_region, wg_chunk;     // k_stay_by_top: entry b of its work table = the tops at leaves reg_lo + 64 chunk .. + 63 of its region
         int n_stay_wgs = 0, n_leaves = 0;
         int cls_run = 0;                // S if every exclude class is an aligned run of S = 2^e <= 64 node-carrying leaves, else 0
     };
@@ -522,6 +524,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     if (const char* pe = getenv("BLANCE_PERIODIC")) c->periodic = atoi(pe) != 0;      // BLANCE_PERIODIC=0: the way out
     if (const char* pc = getenv("BLANCE_PERIODIC_CUT")) c->periodic_cut = atoi(pc);
     c->trace = getenv("BLANCE_TRACE") != nullptr;
+    if (const char* sp = getenv("BLANCE_SPECULATE")) c->speculate = !strcmp(sp, "fail") ? 2 : atoi(sp) != 0;   // 0: every decision read back first
     if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess) {
@@ -564,6 +567,7 @@ static hipError_t read_back(blance_ctx* c, void* dst, const void* dev, size_t by
 }
 static hipError_t stream_sync(blance_ctx* c) {
     c->n_syncs++;
+    if (c->trace) fprintf(stderr, "[blance] host synchronisation %lld (%zu words read back)\n", (long long)c->n_syncs, c->rb_used / 4);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess)
         for (const blance_ctx::RbItem& it : c->rb_items) memcpy(it.dst, (const char*)c->rb_buf + it.off, it.bytes);
@@ -1618,10 +1622,28 @@ static void comm_poison(blance_ctx* c) {
     (void)stream_sync(c);
 }
 
+// The host round trips a chain pass may save, and what it left open.
+//   allow_spec: the classification of a pass that reuses its grouping is ASSUMED clean (no events, no orphans) instead of
+//     read back; the words are checked with the pass's own flags, and `redo` says the assumption was wrong: nothing of the
+//     pass stands, the caller runs it again without.
+//   defer: the pass's own verdict (k_stay_by_top's, the all-blank kernel's, the chain kernel's flags) is not read here
+//     either: the pass is taken to stand, k_scatter is enqueued behind a Gate on those words, and `pending` tells the
+//     caller which words to look at with its next readback (the sweep's convergence word: one round trip for both).  A
+//     verdict that comes back bad has changed nothing but the counters (cnt_save holds them): the caller runs the pass
+//     again with no_stay / no_lean / skip set accordingly.
+struct ChainRun {
+    bool allow_spec = true, defer = false, no_stay = false, no_lean = false, skip = false;
+    bool redo = false;
+    int pending = 0;               // 0: settled; 1: k_stay_by_top's verdict, 2: the all-blank kernel's, 3: the chain kernel's is still on the device
+    bool spec = false;             // the classification was assumed
+    Gate gate = kNoGate;
+};
+constexpr int kFlagStayMoved = 22, kFlagForced = 23;     // words of scal + 4: k_stay_by_top's "not all stays"; BLANCE_SPECULATE=fail
+
 // 0 = ok (*done tells whether the pass was made; if not, the counters are as before and the caller
-// runs the pass in order), < 0 = error
-static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launches_io, int64_t* batched_io, int* n_pass_io,
-                          bool* done, bool* a_done) {
+// runs the pass in order), < 0 = error.
+static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* launches_io, int64_t* batched_io, int* n_pass_io,
+                               bool* done, bool* a_done, ChainRun& run) {
     const blance_problem& h = c->h;
     const DevProblem& d = a.d;
     const int N = h.n_nodes, NX = h.n_nodes_ext, M = h.n_states, P = h.n_parts, L = c->L;
@@ -1661,25 +1683,44 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     } else if (c->trace) fprintf(stderr, "[blance] chain pass state %d: the grouping by region of the last sweep stands\n", m);
     // events: how many?  (also: is every step region-local at all, are there orphan nodes); a sharded
     // plan reads the chain offsets in the same round trip (the slice sizes of collective B)
+    // A pass that reuses its grouping has nothing else to learn from this round trip: with the top priority nodes where they
+    // were, events and orphans come from this state's own nodes having left their partition's region since -- rare enough to
+    // assume there are none and to look at flags[6], flags[7] only when the pass's own flags come back.
+    const bool spec = run.allow_spec && !regroup && !sharded && c->speculate > 0;
+    const bool defer = run.defer && !sharded && c->speculate > 0;
+    run.spec = spec;
+    run.pending = 0;
+    run.redo = false;
+    auto gate_on = [&](uint32_t words) {               // (the words of scal + 4 a deferred verdict depends on)
+        Gate g;
+        g.flags = scal + 4;
+        g.mask = words | (1u << kFlagForced) | (spec ? (1u << 6) | (1u << 7) : 0u);
+        return g;
+    };
     int32_t n_events = 0, cfl[8] = {0};
-    HIPTRY(read_back(c, cfl, scal + 4, sizeof cfl));
-    if (regroup) {                                     // (always: the next sweep may reuse the grouping, the host's copy with it)
-        c->h_reg_off.resize((size_t)B + 1);
-        HIPTRY(read_back(c, c->h_reg_off.data(), c->reg_off.p, sizeof(int32_t) * ((size_t)B + 1)));
+    if (!spec) {
+        HIPTRY(read_back(c, cfl, scal + 4, sizeof cfl));
+        if (regroup) {                                     // (always: the next sweep may reuse the grouping, the host's copy with it)
+            c->h_reg_off.resize((size_t)B + 1);
+            HIPTRY(read_back(c, c->h_reg_off.data(), c->reg_off.p, sizeof(int32_t) * ((size_t)B + 1)));
+        }
+        HIPTRY(stream_sync(c));
     }
-    HIPTRY(stream_sync(c));
+    // (speculate == 2, tests: every assumption is treated as refuted)
+    auto refuted = [&](const int32_t* f) { return spec && (f[6] || f[7] || c->speculate == 2); };
     if (!cfl[0] && cfl[7]) {                            // rare: nodes outside their partition's region
         SCANTRY(P + 1, c->n_ev.as<int32_t>());   // -> event slots
         HIPTRY(read_back(c, &n_events, c->n_ev.as<int32_t>() + P, sizeof n_events));
         HIPTRY(stream_sync(c));
     }
     if (c->trace)
-        fprintf(stderr, "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
+        fprintf(stderr, spec ? "[blance] chain pass state %d: classification assumed clean (checked with the pass's flags)\n" :
+                               "[blance] chain pass state %d: %d events, not-local %d, orphans %d\n", m, n_events, cfl[0], cfl[6]);
     const size_t cnt_words = (size_t)(M + 1) * NX;
     {   // one launch: no events yet, the counters this pass starts from (what a redo restores), k_stay_by_top's flag
         FillCopyJob fj;
         fj.zero(c->ev_off.p, (int64_t)B + 1);
-        fj.zero(scal + 11, 1);
+        fj.zero(scal + 4 + kFlagStayMoved, 1);
         fj.copy(c->cnt_save.p, c->cnt.p, (int64_t)cnt_words);
         if (run_fill_copy(c, fj)) return BLANCE_ERR_DEVICE;
     }
@@ -1701,7 +1742,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     }
     // A pass of stays only (the last sweep of every plan that converges)?  Worth a try when the state's pass of the
     // sweep before was one but for a few steps: k_stay_by_top checks every step in parallel.
-    const bool try_stay = !sharded && !c->no_stay_top && NP > 0 && !cfl[0] && !cfl[6] && !cfl[7] && rr.max_size <= kStayMaxLeaves &&
+    const bool try_stay = !sharded && !run.no_stay && !c->no_stay_top && NP > 0 && !cfl[0] && !cfl[6] && !cfl[7] && rr.max_size <= kStayMaxLeaves &&
                           rr.n_stay_wgs > 0 && (c->force_stay_top || c->last_stays[m] * 100 >= (int64_t)P * 99);
     if (try_stay) {
         RESERVE(topkey, sizeof(int32_t) * ((size_t)P + 1));
@@ -1772,14 +1813,27 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         sq.alive = c->alive.as<uint8_t>(); sq.node_weight = c->node_weight.as<int32_t>(); sq.node_has_weight = c->node_has_weight.as<uint8_t>();
         sq.cnt = c->cnt.as<int32_t>(); sq.crec = c->crec.as<int32_t>();
         sq.top_off = c->top_off.as<int32_t>(); sq.top_order = c->top_order.as<int32_t>();
-        sq.out = c->out.as<int32_t>(); sq.flag = scal + 11;
+        sq.out = c->out.as<int32_t>(); sq.flag = scal + 4 + kFlagStayMoved;
         if (launch_stay_by_top(sm, sq, rr.n_stay_wgs, rr.max_size)) {
-            int32_t sf[8] = {0};                        // [0] a step is not region-local (k_gather_chain), [7] not all stays
-            HIPTRY(read_back(c, sf, scal + 4, sizeof sf));
-            HIPTRY(stream_sync(c));
             launches += 5;
-            stayed = !sf[0] && !sf[7];
-            if (c->trace) fprintf(stderr, "[blance] chain pass state %d: stays verified per top priority node: %s\n", m, stayed ? "all of them" : "no");
+            if (defer) {
+                stayed = true;                          // (until the caller's readback says otherwise)
+                run.pending = 1;
+                run.gate = gate_on(1u | (1u << kFlagStayMoved));
+                if (c->trace) fprintf(stderr, "[blance] chain pass state %d: stays per top priority node, the verdict is read with the sweep's\n", m);
+            } else {
+                int32_t sf[8] = {0}, moved = 0;         // [0] a step is not region-local (k_gather_chain); moved: not all stays
+                HIPTRY(read_back(c, sf, scal + 4, sizeof sf));
+                HIPTRY(read_back(c, &moved, scal + 4 + kFlagStayMoved, sizeof moved));
+                HIPTRY(stream_sync(c));
+                if (refuted(sf)) {                      // (k_stay_by_top changes no counter)
+                    run.redo = true;
+                    *launches_io += launches;
+                    return 0;
+                }
+                stayed = !sf[0] && !moved;
+                if (c->trace) fprintf(stderr, "[blance] chain pass state %d: stays verified per top priority node: %s\n", m, stayed ? "all of them" : "no");
+            }
         }
     }
     if (stayed) {
@@ -1789,7 +1843,8 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         n_pass++;
         c->last_stays[m] = P;
         if (dump_pass(c, a.it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
-        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, OW, c->chain_order.as<int32_t>(), c->out.as<int32_t>());
+        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, OW, c->chain_order.as<int32_t>(), c->out.as<int32_t>(),
+                             run.pending ? run.gate : kNoGate);
         launches++;
         *batched_io += P;
         *done = true;
@@ -1800,7 +1855,7 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     // whole slice or changes nothing that is not restored below (a rank-local decision: the full
     // kernel makes the same choices)
     bool lean = false;
-    if (NP == 0 && !c->any_node_weight && rr.max_size <= 256 && k <= 4 && !cfl[0]) {
+    if (NP == 0 && !run.no_lean && !c->any_node_weight && rr.max_size <= 256 && k <= 4 && !cfl[0]) {
         bool walked = false;
         if (c->periodic && !sharded && n_events == 0 && !cfl[6] && !cfl[7]) {
             // k_period.h: regions whose records repeat are walked for two periods; the rest of the periodic stretch is
@@ -1857,12 +1912,23 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
             }
         }
         if (!walked && (c->no_planes || !launch_chain_planes(sm, cq, rr.max_size))) launch_chain_blank(sm, cq, rr.max_size);
-        int32_t fl[2] = {0, 0};
-        HIPTRY(read_back(c, fl, scal + 4, sizeof fl));
-        HIPTRY(stream_sync(c));
+        int32_t fl[8] = {0};
         launches++;
+        if (defer) {                                    // (taken to have done the pass until the caller's readback says otherwise)
+            run.pending = 2;
+            run.gate = gate_on(1u | 2u);
+        } else {
+            HIPTRY(read_back(c, fl, scal + 4, sizeof fl));
+            HIPTRY(stream_sync(c));
+            if (refuted(fl)) {
+                HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+                run.redo = true;
+                *launches_io += launches;
+                return 0;
+            }
+        }
         if (c->trace) fprintf(stderr, "[blance] chain pass state %d: all-blank kernel (%s) %s\n", m, c->no_planes ? "lanes" : "planes",
-                              !fl[0] && !fl[1] ? "did the pass" : "escaped");
+                              run.pending ? "launched, its flags are read with the sweep's" : !fl[0] && !fl[1] ? "did the pass" : "escaped");
         if (!fl[0] && !fl[1]) {
             lean = true;
         } else if (!fl[0]) {                            // not all blank: the full kernel, from the same state
@@ -1896,14 +1962,27 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
         HIPTRY(read_back(c, fl, xb, sizeof fl));
         launches++;
     } else if (!lean) {                              // (the all-blank kernel's flags were read above: all clear)
-        HIPTRY(read_back(c, fl, scal + 4, 32));
+        if (defer) {
+            run.pending = 3;
+            run.gate = gate_on(1u | 2u);
+        } else {
+            HIPTRY(read_back(c, fl, scal + 4, 32));
+        }
     }
-    if (sharded || !lean) HIPTRY(stream_sync(c));
+    if (!run.pending && (sharded || !lean)) HIPTRY(stream_sync(c));
     if (fl[8]) return fail(BLANCE_ERR_COMM, "another rank of the sharded plan failed");
-    if (c->trace)
+    if (!run.pending && !lean && refuted(fl)) {      // (the all-blank kernel's words were checked above)
+        c->pass_ntn_ready = false;
+        HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * cnt_words, hipMemcpyDeviceToDevice, sm));
+        n_pass--;
+        run.redo = true;
+        *launches_io += launches;
+        return 0;
+    }
+    if (c->trace && !run.pending)
         fprintf(stderr, "[blance] chain pass state %d: %d of %d steps committed as verified stays in %d batches\n",
                 m, fl[2], P, fl[3]);
-    c->last_stays[m] = (!fl[0] && !fl[1]) ? fl[2] : 0;
+    c->last_stays[m] = (!fl[0] && !fl[1]) ? fl[2] : 0;          // (a pending verdict: the caller fills this in)
     if (!fl[0] && !fl[1]) {
         if (sharded) {
             // every rank's chains wrote their own regions' loads and their own steps' outputs
@@ -1939,7 +2018,8 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
             }
         }
         if (dump_pass(c, a.it, m, P, OW, c->chain_oi.as<int32_t>())) return BLANCE_ERR_DEVICE;
-        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, OW, c->chain_order.as<int32_t>(), c->out.as<int32_t>());
+        BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, OW, c->chain_order.as<int32_t>(), c->out.as<int32_t>(),
+                             run.pending ? run.gate : kNoGate);
         launches++;
         *batched_io += P;
         *done = true;
@@ -1949,6 +2029,17 @@ static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launch
     }
     *launches_io += launches;
     return 0;
+}
+
+static int run_chain_pass(blance_ctx* c, const ChainPassArgs& a, int64_t* launches_io, int64_t* batched_io, int* n_pass_io,
+                          bool* done, bool* a_done, ChainRun& run) {
+    int e = run_chain_pass_once(c, a, launches_io, batched_io, n_pass_io, done, a_done, run);
+    if (e || !run.redo) return e;
+    c->spec_refuted++;
+    if (c->trace) fprintf(stderr, "[blance] chain pass state %d: the assumed classification did not hold, the pass runs again\n", a.m);
+    run.allow_spec = false;
+    run.defer = false;
+    return run_chain_pass_once(c, a, launches_io, batched_io, n_pass_io, done, a_done, run);
 }
 
 static int plan_locked(blance_ctx* c, blance_result* res) {
@@ -1972,12 +2063,19 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
 
     HIPTRY(hipEventRecord(c->ev0, sm));
     HIPTRY(hipMemsetAsync(scal, 0, 256, sm));
+    if (c->speculate == 2) {                                         // (tests: every deferred verdict comes back bad, every gate is closed)
+        static const int32_t one = 1;
+        HIPTRY(hipMemcpyAsync(scal + 4 + kFlagForced, &one, sizeof one, hipMemcpyHostToDevice, sm));
+    }
     if (P > 0) {
         BLANCE_LAUNCH_NOSYNC(k_flags_init, cdiv(P, 256), 256, 0, sm, P, c->part_in_prev.as<uint8_t>(), c->part_never_equal.as<uint8_t>(),
                              d.in_prev, d.never_equal);
     }
     int iterations = 0, converged = 0;
-    int32_t hs[26] = {0};                                            // the scalar words read back after every sweep
+    int32_t hs[32] = {0};                                            // the scalar words read back after every sweep
+    int m_last = -1;                                                 // the last state a sweep makes a pass for
+    for (int m = 0; m < M; m++)
+        if (c->state_constraints[m] > 0 && P > 0) m_last = m;
     for (int it = 0; it < h.max_iterations; it++) {                 // plan.go:32
         const bool first = it == 0;
         d.node_removed = first ? c->node_removed.as<uint8_t>() : c->zeros_nx.as<uint8_t>();   // plan.go:53-55
@@ -2017,9 +2115,20 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             launches++;
         }
         int passes_this_sweep = 0;
-        for (int m = 0; m < M; m++) {                               // plan.go:307-324
+        // The sweep's last pass, when it is a chain pass, leaves its verdict on the device (ChainRun::defer) and the words
+        // come back with the convergence word: one round trip for both.  A bad verdict brings the loop back for that
+        // state alone (retry says how), with everything the pass enqueued behind its gate undone by never having run.
+        int m_from = 0;
+        ChainRun retry;
+        bool retrying = false, counted = false;
+        for (;;) {
+        ChainRun pend;
+        int64_t batched0 = batched, steps0 = steps;
+        int n_pass0 = n_pass, passes0 = passes_this_sweep;
+        for (int m = m_from; m < M; m++) {                          // plan.go:307-324
             const int k = c->state_constraints[m];
             if (k <= 0 || P == 0) continue;
+            if (m == m_last) { batched0 = batched; steps0 = steps; n_pass0 = n_pass; passes0 = passes_this_sweep; }
             const int n_chunks = cdiv(P, kPartChunk);
             const bool sort_cat = first && !(passes_this_sweep == 0 ? c->uniform_first : c->uniform_all);
             passes_this_sweep++;
@@ -2053,13 +2162,17 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             // ---- region chains, when the state's single hierarchy rule allows them
             bool done = false;
             if (c->engine != BLANCE_ENGINE_SEQUENTIAL && !h.hierarchy_rules_nil && r1 - r0 == 1 &&
-                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4) {
+                c->rule_regions[r0].ok && P >= c->chain_min_parts && k <= 4 && !(retrying && retry.skip)) {
                 // (same_tops: the top state's pass was one run of stays AND no other state can take a partition's top priority
                 // node away in between -- plan.go:146-154 keeps only nodes of STRICTLY higher priority states out of a pass)
                 ChainPassArgs ca{d, m, k, NP, OW, RW, higher_mask, r0, it, order,
                                  !first && !c->tops_moved && m != h.top_state && c->top_prio_strict};
                 bool a_done = false;
-                const int e = run_chain_pass(c, ca, &launches, &batched, &n_pass, &done, &a_done);
+                ChainRun run;
+                if (retrying) run = retry;
+                run.defer = !retrying && m == m_last;
+                const int e = run_chain_pass(c, ca, &launches, &batched, &n_pass, &done, &a_done, run);
+                if (!e && run.pending) pend = run;
                 if (e) {
                     const bool sharded = (c->comm.n_ranks > 1 || c->shard_one_rank) && c->rule_regions[r0].n_regions >= c->comm.n_ranks;
                     if (sharded && !a_done) comm_poison(c);       // the other ranks are (or will be) in collective A
@@ -2130,22 +2243,53 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
             n_pass++;
             if (dump_pass(c, it, m, P, q.OW, nullptr)) return BLANCE_ERR_DEVICE;
-            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, order, c->out.as<int32_t>());
+            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, order, c->out.as<int32_t>(), kNoGate);
             }
             launches += 7;
             steps += P;
         }
-        iterations++;
+        if (!counted) iterations++;
+        counted = true;
         // convergence (plan.go:36-45) + write-back (plan.go:49-52)
         if (P > 0) {
-            BLANCE_LAUNCH(k_converge, cdiv(P, 256), 256, 0, sm, d, scal + 1);          // (uses a wave ballot)
+            BLANCE_LAUNCH(k_converge, cdiv(P, 256), 256, 0, sm, d, scal + 1, pend.pending ? pend.gate : kNoGate);   // (uses a wave ballot)
             launches++;
         }
-        // one readback per sweep: the convergence word with the warnings count, and -- complete with the last sweep --
-        // the statistics words behind them (steps k_pass_seq committed as verified stays, the queue kernel's counters)
+        // one readback per sweep: the convergence word with the warnings count, the chain flags (a deferred verdict) and --
+        // complete with the last sweep -- the statistics words behind them (steps k_pass_seq committed as verified stays,
+        // the queue kernel's counters)
         HIPTRY(read_back(c, hs, scal, sizeof hs));
         HIPTRY(stream_sync(c));
         HIPTRY(hipGetLastError());
+        if (!pend.pending) break;
+        {
+            const int32_t* f = hs + 4;
+            const bool refuted = (pend.spec && (f[6] || f[7])) || f[kFlagForced];
+            const bool bad = pend.pending == 1 ? (f[0] || f[kFlagStayMoved]) : (f[0] || f[1]);
+            if (c->trace)
+                fprintf(stderr, "[blance] chain pass state %d: deferred verdict (%s): %s; %d verified stays in %d batches\n", m_last,
+                        pend.pending == 1 ? "k_stay_by_top" : pend.pending == 2 ? "all-blank kernel" : "chain kernel",
+                        refuted ? "assumption refuted" : bad ? "the pass did not stand" : "stands", f[2], f[3]);
+            if (!refuted && !bad) {
+                if (pend.pending == 3) c->last_stays[m_last] = f[2];
+                break;
+            }
+            // nothing behind the gate ran: the live lists and prevMap are as the pass found them; the counters are not
+            c->spec_refuted++;
+            retry = ChainRun();
+            if (refuted) retry.allow_spec = false;
+            else if (pend.pending == 1) retry.no_stay = true;
+            else if (pend.pending == 2) retry.no_lean = true;
+            else retry.skip = true;                                 // (straight to the pass in order)
+            if (pend.pending != 1 || refuted) {
+                c->pass_ntn_ready = false;
+                HIPTRY(hipMemcpyAsync(c->cnt.p, c->cnt_save.p, sizeof(int32_t) * (size_t)(M + 1) * NX, hipMemcpyDeviceToDevice, sm));
+            }
+            batched = batched0; steps = steps0; n_pass = n_pass0; passes_this_sweep = passes0;
+            retrying = true;
+            m_from = m_last;
+        }
+        }
         if (hs[2]) return fail(BLANCE_ERR_UNSUPPORTED, "hierarchy fold overflowed the device's interval budget");
         c->n_warnings = hs[0];
         if (!hs[1]) { converged = 1; break; }

@@ -74,6 +74,14 @@ constexpr int kChainMaxLeaves = 512;             // leaves of one region (one wa
 constexpr int kCW = 24;
 constexpr int kCOwn = 7, kCHigh = 11, kCLow = 15, kCLowState = 19;
 
+// A launch the host enqueues BEFORE it has read the words that decide whether it should run (one round trip less per
+// decision): the kernel looks at the words itself.  closed = some word flags[b], b a set bit of mask, is non-zero.
+struct Gate {
+    const int32_t* flags;
+    uint32_t mask;
+};
+constexpr Gate kNoGate = {nullptr, 0u};
+
 struct ChainParams {
     int32_t N, NX, M, L;
     int32_t s, k, NP, OW;
@@ -116,7 +124,7 @@ struct ChainParams {
 };
 
 // k_stay_by_top (k_stay.h): a chain pass of stays verified by one thread per top priority node
-constexpr int kStayMaxLeaves = 256;
+constexpr int kStayMaxLeaves = 512;
 struct StayParams {
     int32_t N, NX, M, s, k, NP, OW, booster_kind;
     const int32_t* wg_region;      // [grid] region of workgroup b ...

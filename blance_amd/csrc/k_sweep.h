@@ -590,9 +590,21 @@ __global__ __launch_bounds__(256) void k_ntn_bits(int N, int rows, int BW, const
 
 // Apply the pass's choices to the live lists (plan.go:290-299); list edits only
 // touch the step's own partition, so this runs in parallel after the pass.
-__global__ void k_scatter(DevProblem d, int m, int OW, const int32_t* order, const int32_t* out) {
+__device__ __forceinline__ bool gate_closed(const Gate& g) {
+    uint32_t mk = g.mask;
+    bool closed = false;
+    while (mk) {
+        const int b = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        closed |= g.flags[b] != 0;
+    }
+    return closed;
+}
+
+__global__ void k_scatter(DevProblem d, int m, int OW, const int32_t* order, const int32_t* out, Gate gate) {
     int oi = blockIdx.x * blockDim.x + threadIdx.x;
     if (oi >= d.P) return;
+    if (gate_closed(gate)) return;                   // (the pass did not stand: the host runs it again and scatters then)
     int p = order[oi];
     const int32_t* o = out + (size_t)oi * OW;
     int n_out = o[0] & 0xffff, is_nil = o[0] >> 16;
@@ -625,7 +637,8 @@ __global__ void k_scatter(DevProblem d, int m, int OW, const int32_t* order, con
 
 // Convergence test (plan.go:36-45) fused with the write-back prevMap[name] =
 // partitionsToAssign[name] = nextMap[name] (plan.go:49-52).
-__global__ void k_converge(DevProblem d, int32_t* not_match) {
+__global__ void k_converge(DevProblem d, int32_t* not_match, Gate gate) {
+    if (gate_closed(gate)) return;                   // (uniform: the sweep's last pass did not stand, the host comes back)
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = p < d.P;
     if (!in_range) p = d.P - 1;                      // keep the wave whole for the ballot below

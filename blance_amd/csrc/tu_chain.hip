@@ -89,9 +89,10 @@ bool launch_chain_planes(hipStream_t stream, const ChainParams& q, int max_size)
 
 bool launch_stay_by_top(hipStream_t stream, const StayParams& q, int n_wgs, int max_size) {
     if (max_size > kStayMaxLeaves || q.k < 1 || q.k > 4 || n_wgs < 1) return false;
-    const size_t lds = sizeof(int32_t) * ((size_t)max_size * (7 + 64) + 2) + sizeof(double) * (kLpTab + kFfTab) + 64;
-    if (q.k <= 2) { auto kern = k_stay_by_top<2>; BLANCE_LAUNCH(kern, n_wgs, 64, lds, stream, q); }
-    else { auto kern = k_stay_by_top<4>; BLANCE_LAUNCH(kern, n_wgs, 64, lds, stream, q); }
+    // (a workgroup per kStayWaves top priority nodes, a wave each: kStaySplit workgroups per entry of the work table)
+    const size_t lds = sizeof(int32_t) * ((size_t)max_size * (7 + kStayWaves) + kStayWaves + 2) + sizeof(double) * kStayWaves + 64;
+    if (q.k <= 2) { auto kern = k_stay_by_top<2>; BLANCE_LAUNCH(kern, n_wgs * kStaySplit, 64 * kStayWaves, lds, stream, q); }
+    else { auto kern = k_stay_by_top<4>; BLANCE_LAUNCH(kern, n_wgs * kStaySplit, 64 * kStayWaves, lds, stream, q); }
     return true;
 }
 

@@ -108,7 +108,8 @@ def test_periodic_stretch_is_taken(capfd):
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stderr.splitlines() if "periodic records" in ln]
     assert line and "in 4 of 4 regions (period 128" in line[0] and "15360 of 16384 steps copied" in line[0], out.stderr[-2000:]
-    assert "all-blank kernel (planes) did the pass" in out.stderr
+    # (the sweep's last pass: its flags come back with the convergence word)
+    assert "all-blank kernel (planes) did the pass" in out.stderr or "deferred verdict (all-blank kernel): stands" in out.stderr
 
 
 @pytest.mark.parametrize("cut", [300, 1000, 4000])

@@ -59,12 +59,13 @@ def trace(db, calls, out, title):
             if end is not None and s0 > end:
                 gaps.append(s0 - end)
             end = e0 if end is None or e0 > end else end
-        inner = sorted(x for x in gaps if x < 2e6)          # (gaps of milliseconds are between calls / around uploads: not a plan's)
         lines.append("")
-        lines.append("device idle between consecutive kernels (gaps under 2 ms, i.e. inside calls): %d gaps, %.3f ms in total = %.3f ms per call; "
-                     "%d of them over 5 us (%.3f ms), the median %.1f us" % (
-                         len(inner), sum(inner) / 1e6, sum(inner) / 1e6 / calls, sum(1 for x in inner if x > 5e3),
-                         sum(x for x in inner if x > 5e3) / 1e6, (inner[len(inner) // 2] / 1e3) if inner else 0.0))
+        lines.append("device idle between consecutive kernels (a gap = the next kernel starts after everything before it has ended), %d calls:" % calls)
+        for lo, hi, what in ((0, 5e3, "under 5 us: launch back to back"), (5e3, 2e4, "5 - 20 us"), (2e4, 1e5, "20 - 100 us: a host round trip inside a call"),
+                             (1e5, 2e6, "0.1 - 2 ms: between calls (the host's work between two blance_plan_resident), uploads"),
+                             (2e6, 1e18, "over 2 ms")):
+            sel = [x for x in gaps if lo <= x < hi]
+            lines.append("   %-92s %5d gaps, %9.3f ms in total, %7.3f ms per call" % (what, len(sel), sum(sel) / 1e6, sum(sel) / 1e6 / calls))
     except Exception as e:                                   # (older databases: no timestamps table layout we know)
         lines.append("(no gap statistics: %s)" % str(e)[:80])
     open(out, "w").write("\n".join(lines) + "\n")
