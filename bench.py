@@ -770,7 +770,7 @@ def main():
         if args.config == 5:
             kernels.append(kernel_line("k_pass_queue (flat replica pass, one wave64: the candidates as a sorted window over the lanes)",
                                        ("k_pass_queue", "k_pass_tree"), RW + 1 + kmax, acc["pass_ms"], acc["pass_launches"], 1, dense_pass,
-                                       waves_per_chain=4))           # (the walking wave and its three helper waves)
+                                       waves_per_chain=8))           # (the walking wave and its seven helper waves)
         else:
             zones = -(-N // 128)                     # zones of 8 racks x 16 nodes: one chain each
             kernels.append(kernel_line("all-blank replica pass of the first sweep (k_pass_chain_planes: scalar bit-plane automaton, one wave64 per "
@@ -781,7 +781,7 @@ def main():
                                        "waves per hierarchy region -- one walks the region's steps in order, all four test 256 steps for stays at a time)",
                                        ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"] - acc["stay_ms"],
                                        acc["pass_launches"] - acc["blank_launches"] - acc["stay_launches"], zones, dense_pass,
-                                       waves_per_chain=4))           # (k_pass_chain.h: kChainWaves -- the walking wave and three helpers of the stay test)
+                                       waves_per_chain=8))           # (k_pass_chain.h: kChainWaves -- the walking wave and seven helpers of the stay test)
             kernels.append(kernel_line("k_stay_by_top (the replica pass of a converged sweep: every step verified as a stay by one thread per "
                                        "top priority node; the time includes the counting sort that groups the steps by top node)",
                                        ("k_stay_by_top",), K_CW + 1 + kmax, acc["stay_ms"], acc["stay_launches"], None, dense_pass))

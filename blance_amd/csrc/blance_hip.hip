@@ -238,6 +238,7 @@ struct blance_ctx {
     size_t comm_events_used = 0;
     double comm_ms = 0.0;                    // device time between those pairs, all plans so far
     int64_t n_syncs = 0, plan_syncs = 0;     // stream_sync() calls so far / inside the last plan
+    int chain_waves = 0;                     // k_pass_chain's workgroup: 0 = 8 waves when the LDS is there, else 4 (BLANCE_CHAIN_WAVES=4|8)
     int speculate = 1;                       // host decisions taken before their words are read back (BLANCE_SPECULATE=0|1|fail)
     int64_t spec_refuted = 0;                // ... and how often one had to be taken back
 
@@ -524,6 +525,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     if (const char* pe = getenv("BLANCE_PERIODIC")) c->periodic = atoi(pe) != 0;      // BLANCE_PERIODIC=0: the way out
     if (const char* pc = getenv("BLANCE_PERIODIC_CUT")) c->periodic_cut = atoi(pc);
     c->trace = getenv("BLANCE_TRACE") != nullptr;
+    if (const char* cw = getenv("BLANCE_CHAIN_WAVES")) c->chain_waves = atoi(cw);
     if (const char* sp = getenv("BLANCE_SPECULATE")) c->speculate = !strcmp(sp, "fail") ? 2 : atoi(sp) != 0;   // 0: every decision read back first
     if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
@@ -1176,7 +1178,7 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
     memset(&cq, 0, sizeof cq);
     cq.N = q.N; cq.NX = q.NX; cq.M = q.M; cq.L = q.L; cq.s = q.s; cq.k = q.k; cq.NP = q.NP; cq.OW = q.OW;
     cq.booster_kind = q.booster_kind;
-    cq.n_regions = 1; cq.n_launch = 1; cq.flat = 1;
+    cq.n_regions = 1; cq.n_launch = 1; cq.flat = 1; cq.waves = c->chain_waves;
     cq.reg_lo = c->fl_reglo.as<int32_t>(); cq.reg_hi = c->fl_reghi.as<int32_t>();
     cq.reg_off = c->reg_off.as<int32_t>();
     cq.leaf_node = c->fl_iota.as<int32_t>(); cq.leaf_cls = c->fl_iota.as<int32_t>(); cq.cls_size = c->fl_one.as<int32_t>();
@@ -1761,6 +1763,7 @@ static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* l
     cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
     cq.NP = NP; cq.OW = OW; cq.booster_kind = h.booster_kind;
     cq.n_regions = B;
+    cq.waves = c->chain_waves;
     cq.cls_run = rr.cls_run;
     // a sharded plan: this rank walks the chains of its slice of the regions
     auto slice_lo = [&](int r) { return (int)((int64_t)B * r / G); };

@@ -118,6 +118,7 @@ struct ChainParams {
     const int32_t* ev_w;           // [E] by this much
     const int32_t* crec;           // [P * kCW] compact step records in chain order
     int32_t* out;                  // [P * OW]
+    int32_t waves;                 // waves of a region's workgroup: 0 = the launcher decides (8 when the LDS is there), 4, 8
     int32_t* flags;                // [0] a step is not region-local, [1] a chain had to escape,
                                    // [2] steps committed as verified stays, [3] stay batches,
                                    // [4] flat mode: first step not done, [5] stopped by the key range

@@ -111,11 +111,12 @@ constexpr int kKeyBias = 1 << 17;
 constexpr unsigned kKeyNone = 0xffffffffu;
 constexpr int kCompactMax = 8000;    // |count| bound of the compact keys of the blank-run loop
 
-constexpr int kChainWaves = 4;                     // waves of a region's workgroup (k_pass_chain below)
-constexpr int kStageVec = kChainStage * (kCW / 4) / (64 * kChainWaves);      // 16-byte words of a stage per lane of one wave
-static_assert(kCW % 4 == 0 && kStageVec == 6 && kChainStage * (kCW / 4) % (64 * kChainWaves) == 0, "BLANCE_STAGE_EACH lists 6 words per lane");
-// A stage's records (24 KB) travel as 16-byte loads, each wave of the workgroup its quarter (the records of the 64 steps it
-// tests in a round that starts with the stage): 6 per lane, ALL in flight at once and a stage ahead.  The words as named
+constexpr int kChainWaves = 8;                     // most waves of a region's workgroup (k_pass_chain below; launched with 4 or 8)
+constexpr int kStageVec = kCW / 4;                 // 16-byte words of a stage per lane of one wave: the records of its 64 steps
+static_assert(kCW % 4 == 0 && kStageVec == 6, "BLANCE_STAGE_EACH lists 6 words per lane");
+// A stage = 64 steps per wave of the workgroup (256 steps on four waves, 512 on eight).  Its records (96 bytes a step) travel
+// as 16-byte loads, each wave of the workgroup its share (the records of the 64 steps it tests in a round that starts with
+// the stage): 6 per lane, ALL in flight at once and a stage ahead.  The words as named
 // values: as an array the compiler keeps them in scratch memory, and a store to scratch waits for the load it stores.
 #define BLANCE_STAGE_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define BLANCE_STAGE_DECL(t) int4 pre##t = {0, 0, 0, 0};
@@ -125,7 +126,7 @@ static_assert(kCW % 4 == 0 && kStageVec == 6 && kChainStage * (kCW / 4) % (64 * 
 // 16-byte aligned)
 #define BLANCE_STAGE_FETCH_ALL(crec, base_, cend_)                                                               \
     {                                                                                                             \
-        const int n4_ = ((cend_) - (base_) < kChainStage ? (cend_) - (base_) : kChainStage) * (kCW / 4);          \
+        const int n4_ = ((cend_) - (base_) < stage ? (cend_) - (base_) : stage) * (kCW / 4);                     \
         const int q0_ = wave * (64 * kStageVec);                                                                  \
         const int4* src_ = (const int4*)((crec) + (size_t)(base_) * kCW);                                         \
         BLANCE_STAGE_EACH(BLANCE_STAGE_FETCH)                                                                     \
@@ -133,7 +134,8 @@ static_assert(kCW % 4 == 0 && kStageVec == 6 && kChainStage * (kCW / 4) % (64 * 
 
 // HELPER WAVES (round 6).  A pass of (mostly) stays is bound by the instruction count of the stay test, one wave per region;
 // the test reads only LDS (the mirrors of the per-leaf registers, the staged records, the region's nodeToNodeCounts rows).
-// The kernel therefore runs as a workgroup of kChainWaves = 4 waves, one per SIMD of the CU: in a speculation round wave w
+// The kernel therefore runs as a workgroup of 4 or 8 waves (one or two per SIMD of the CU; eight when the LDS they need is
+// there: a stage of 512 steps): in a speculation round wave w
 // tests steps [b + 64 w, b + 64 w + 64), all at the same time and under the same hypothesis -- "every step of the round
 // stays": no counter changes, and a step's row of nodeToNodeCounts is bumped only by the steps with its top priority node
 // (plan.go:238-245).  What an EARLIER step of the round with my top priority node would have bumped is added in by the test
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
     const int cbeg = q.reg_off[rg], cend = q.reg_off[rg + 1];
     if (cbeg >= cend && !(q.ev_off && q.ev_off[rg] != q.ev_off[rg + 1])) return;   // no step, no event
     const int N = q.N, NX = q.NX, M = q.M, NP = q.NP, s = q.s, k = q.k;
+    const int stage = 64 * NWv;                      // steps whose records / outputs are in LDS at a time
     // LDS: quotient tables, mirrors of the per-leaf registers (read by the stay
     // validators), a kChainStage-step staging area for records and outputs (no global memory
     // operation inside the step loop), the region's nodeToNodeCounts rows
@@ -172,12 +175,12 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
     int* flgL = wgtL + size;                         // bit 0 alive (in nodesNext), bit 1 has weight
     int* clsL = flgL + size;                         // exclude class of the leaf's node, -1 if none
     int* cszL = clsL + size;                         // leaves covered by class c
-    // [kChainStage][kCW], 16-byte aligned (inside the launch's slack; by offset, so that the pointer stays an LDS pointer)
+    // [stage][kCW], 16-byte aligned (inside the launch's slack; by offset, so that the pointer stays an LDS pointer)
     int* recbuf = cszL + size + ((4 - (int)(((unsigned char*)(cszL + size) - lds) >> 2)) & 3);
-    int* outbuf = recbuf + kChainStage * kCW;        // [kChainStage][OW]
+    int* outbuf = recbuf + stage * kCW;              // [stage][OW]
     const int MS = size + 1;
-    int* markL = outbuf + kChainStage * q.OW;        // [kChainWaves][size + 1] per wave: first lane of its 64 steps per top priority node
-    int* ctl = markL + kChainWaves * MS;             // [kChainCtl] wave 0's command, the waves' verdicts
+    int* markL = outbuf + stage * q.OW;              // [NWv][size + 1] per wave: first lane of its 64 steps per top priority node
+    int* ctl = markL + NWv * MS;                     // [kChainCtl] wave 0's command, the waves' verdicts
     int* ntn_l = ctl + kChainCtl;                    // [size][ST] nodeToNodeCounts rows, padded stride
     const int ST = size + 1;
     // ---- the stay test of one step (lane a of wave w tests step sb of the round that starts at b0): plan.go:98-248 under the
@@ -331,13 +334,13 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             BLANCE_WAVE_SYNC();                      // (a lane reads records other lanes of its wave wrote; LDS is in order within a wave)
         }
         if (fl & 2) {
-            const int pbase = uni(ctl[18]), nd = uni(ctl[19]);
+            const int pbase = uni(ctl[26]), nd = uni(ctl[27]);
             const int hi = nd < 64 * wave + 64 ? nd : 64 * wave + 64;
             for (int i = 64 * wave * q.OW + lane; i < hi * q.OW; i += 64) q.out[(size_t)pbase * q.OW + i] = outbuf[i];
         }
         if (fl & 1) {
-            const int sbase = uni(ctl[16]);
-            if (sbase + kChainStage < cend) BLANCE_STAGE_FETCH_ALL(q.crec, sbase + kChainStage, cend)
+            const int sbase = uni(ctl[24]);
+            if (sbase + stage < cend) BLANCE_STAGE_FETCH_ALL(q.crec, sbase + stage, cend)
         }
     };
     if (wave != 0) {
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
             for (int i = lane; i < (size + 1) * ST; i += 64) ntn_l[i] = 0;    // last row: "" (flat mode)
     }
     for (int i = lane; i < size; i += 64) cszL[i] = q.cls_size[lo + i];
-    for (int i = lane; i < kChainWaves * MS; i += 64) markL[i] = INT_MAX;
+    for (int i = lane; i < NWv * MS; i += 64) markL[i] = INT_MAX;
     BLANCE_WAVE_SYNC();                              // (one wave: LDS is in order; the helper meets the tables behind barrier A)
 
     // lane l owns leaves lo + l + 64 u
@@ -474,14 +477,14 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
     // stage's steps).
     int prev_base = 0, prev_done = 0;              // the finished stage whose outputs are still in LDS
     auto post_service = [&](const int fl, const int sbase) {
-        if (lane == 0) { ctl[0] = 2; ctl[7] = fl; ctl[16] = sbase; ctl[18] = prev_base; ctl[19] = prev_done; }
+        if (lane == 0) { ctl[0] = 2; ctl[7] = fl; ctl[24] = sbase; ctl[26] = prev_base; ctl[27] = prev_done; }
         lds_barrier();                               // (A)
         stage_service(fl);
         lds_barrier();                               // (S)
         prev_done = 0;
     };
-    for (int base = cbeg; base < cend && !escaped; base += kChainStage) {
-      const int nb = cend - base < kChainStage ? cend - base : kChainStage;
+    for (int base = cbeg; base < cend && !escaped; base += stage) {
+      const int nb = cend - base < stage ? cend - base : stage;
       PH(0);
       // The stage's housekeeping rides on its first round when that round is certain to come: no event can be due (the test
       // for one reads the stage's first record), the last step was a stay.  Else it is a command of its own.
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) 
                 if (lane == 0) {
                     ctl[0] = 1; ctl[1] = b; ctl[2] = nb; ctl[3] = next_ev_oi;
                     ctl[4] = __double2loint(gmin_s); ctl[5] = __double2hiint(gmin_s); ctl[6] = gmin_n;
-                    ctl[7] = pending_fl; ctl[16] = base; ctl[18] = prev_base; ctl[19] = prev_done;
+                    ctl[7] = pending_fl; ctl[24] = base; ctl[26] = prev_base; ctl[27] = prev_done;
                 }
                 lds_barrier();                         // (A)
                 if (pending_fl) { stage_service(pending_fl); pending_fl = 0; prev_done = 0; }

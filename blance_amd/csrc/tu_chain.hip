@@ -6,47 +6,61 @@
 namespace blance {
 
 template <int NPTC, int KM, bool FAST>
-static void launch_chain_v(hipStream_t stream, const ChainParams& q, size_t lds) {
+static void launch_chain_v(hipStream_t stream, const ChainParams& q, size_t lds, int waves) {
     auto kern = k_pass_chain<NPTC, KM, FAST>;
-    // (kChainWaves waves per region: the walking wave and its helpers for the stay test, k_pass_chain.h)
-    BLANCE_LAUNCH(kern, q.n_launch, 64 * kChainWaves, lds, stream, q);
+    // (the walking wave and its helpers for the stay test, k_pass_chain.h)
+    BLANCE_LAUNCH(kern, q.n_launch, 64 * waves, lds, stream, q);
 }
 
 template <int NPTC, int KM>
-static void launch_chain_mode(hipStream_t stream, const ChainParams& q, size_t lds, bool fast) {
-    if (fast) launch_chain_v<NPTC, KM, true>(stream, q, lds);
-    else launch_chain_v<NPTC, KM, false>(stream, q, lds);
+static void launch_chain_mode(hipStream_t stream, const ChainParams& q, size_t lds, bool fast, int waves) {
+    if (fast) launch_chain_v<NPTC, KM, true>(stream, q, lds, waves);
+    else launch_chain_v<NPTC, KM, false>(stream, q, lds, waves);
 }
 
-static size_t chain_lds_base(const ChainParams& q, int max_size) {
+// (a stage = 64 steps per wave: records and outputs; a table of top priority nodes per wave)
+static size_t chain_lds_base(const ChainParams& q, int max_size, int waves) {
     return sizeof(double) * (kLpTab + kFfTab + (size_t)max_size) + sizeof(int32_t) * 7 * (size_t)max_size +
-           sizeof(int32_t) * kChainStage * (size_t)(kCW + q.OW) + sizeof(int32_t) * (kChainWaves * ((size_t)max_size + 1) + kChainCtl) + 64;
+           sizeof(int32_t) * 64 * waves * (size_t)(kCW + q.OW) + sizeof(int32_t) * (waves * ((size_t)max_size + 1) + kChainCtl) + 64;
 }
 
-// the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU); flat mode may insist on
-// global rows
-bool chain_rows_in_lds(const ChainParams& q, int max_size) {
+static bool chain_rows_fit(const ChainParams& q, int max_size, int waves) {
     const size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
-    if (!q.flat || q.ntn_in_lds) return ntn_bytes <= 100 * 1024 && chain_lds_base(q, max_size) + ntn_bytes <= 156 * 1024;
+    return ntn_bytes <= 100 * 1024 && chain_lds_base(q, max_size, waves) + ntn_bytes <= 156 * 1024;
+}
+
+// the region's nodeToNodeCounts rows live in LDS when they fit beside the rest (160 KB per CU; beside the four-wave
+// workgroup's smaller stage if not beside the eight-wave one's); flat mode may insist on global rows
+bool chain_rows_in_lds(const ChainParams& q, int max_size) {
+    if (!q.flat || q.ntn_in_lds) return chain_rows_fit(q, max_size, 4);
     return false;
+}
+
+// waves of a region's workgroup: eight (rounds of 512 steps) unless the rows then no longer fit in LDS; q.waves = 4 / 8 insists
+static int chain_waves(const ChainParams& q, int max_size) {
+    if (q.waves == 4 || q.waves == kChainWaves) return q.waves;
+    const bool rows = q.NP > 0 && chain_rows_in_lds(q, max_size);
+    return (!rows || chain_rows_fit(q, max_size, kChainWaves)) ? kChainWaves : 4;
 }
 
 // one wave64 per region; lanes own NPTC leaves each, k <= KM picks per step
 bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast) {
     int nptc = (max_size + 63) / 64;
     size_t ntn_bytes = sizeof(int32_t) * (size_t)(max_size + 1) * (max_size + 1);
-    size_t lds = chain_lds_base(q, max_size);
     q.ntn_in_lds = chain_rows_in_lds(q, max_size);
+    int waves = chain_waves(q, max_size);
+    if (q.NP > 0 && q.ntn_in_lds && !chain_rows_fit(q, max_size, waves)) waves = 4;      // (insisted on eight: not at the rows' expense)
+    size_t lds = chain_lds_base(q, max_size, waves);
     if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
     if (q.k <= 2) {
-        if (nptc <= 2) launch_chain_mode<2, 2>(stream, q, lds, fast);
-        else if (nptc <= 4) launch_chain_mode<4, 2>(stream, q, lds, fast);
-        else if (nptc <= 8) launch_chain_mode<8, 2>(stream, q, lds, fast);
+        if (nptc <= 2) launch_chain_mode<2, 2>(stream, q, lds, fast, waves);
+        else if (nptc <= 4) launch_chain_mode<4, 2>(stream, q, lds, fast, waves);
+        else if (nptc <= 8) launch_chain_mode<8, 2>(stream, q, lds, fast, waves);
         else return false;
     } else if (q.k <= 4) {
-        if (nptc <= 2) launch_chain_mode<2, 4>(stream, q, lds, fast);
-        else if (nptc <= 4) launch_chain_mode<4, 4>(stream, q, lds, fast);
-        else if (nptc <= 8) launch_chain_mode<8, 4>(stream, q, lds, fast);
+        if (nptc <= 2) launch_chain_mode<2, 4>(stream, q, lds, fast, waves);
+        else if (nptc <= 4) launch_chain_mode<4, 4>(stream, q, lds, fast, waves);
+        else if (nptc <= 8) launch_chain_mode<8, 4>(stream, q, lds, fast, waves);
         else return false;
     } else {
         return false;
