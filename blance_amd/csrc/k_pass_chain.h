@@ -150,8 +150,12 @@ static_assert(kCW % 4 == 0 && kStageVec == 6, "BLANCE_STAGE_EACH lists 6 words p
 // Everything else (events, blank runs, general steps) is wave 0's alone, the helpers parked on the barrier.
 constexpr int kChainCtl = 32;                       // words of the command block between the waves
 
+// (regions of more than 256 leaves: eight leaves a lane need the registers of a wave that has its SIMD to itself -- four waves)
+template <int NPTC>
+constexpr int chain_waves_max() { return NPTC >= 8 ? 4 : kChainWaves; }
+
 template <int NPTC, int KM, bool FAST>
-__global__ __launch_bounds__(64 * kChainWaves) void k_pass_chain(ChainParams q) {
+__global__ __launch_bounds__(64 * chain_waves_max<NPTC>()) void k_pass_chain(ChainParams q) {
     BLANCE_DYN_LDS(lds);
     if (q.flags[0]) return;
     const int lane = threadIdx.x & 63;

@@ -50,6 +50,7 @@ bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast) {
     q.ntn_in_lds = chain_rows_in_lds(q, max_size);
     int waves = chain_waves(q, max_size);
     if (q.NP > 0 && q.ntn_in_lds && !chain_rows_fit(q, max_size, waves)) waves = 4;      // (insisted on eight: not at the rows' expense)
+    if (nptc >= 8) waves = 4;                        // (chain_waves_max: such a wave needs more than half a SIMD's registers)
     size_t lds = chain_lds_base(q, max_size, waves);
     if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
     if (q.k <= 2) {
