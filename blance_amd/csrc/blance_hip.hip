@@ -238,6 +238,9 @@ struct blance_ctx {
     size_t comm_events_used = 0;
     double comm_ms = 0.0;                    // device time between those pairs, all plans so far
     int64_t n_syncs = 0, plan_syncs = 0;     // stream_sync() calls so far / inside the last plan
+    // known at upload (no readback needed for them in the first sweep's first pass): the partitions to assign hold no node at
+    // all; no load counter starts above zero (no extra loads, nothing counted from prevMap)
+    bool assign_empty = false, counts_start_zero = false;
     int chain_waves = 0;                     // k_pass_chain's workgroup: 0 = 8 waves when the LDS is there, else 4 (BLANCE_CHAIN_WAVES=4|8)
     int speculate = 1;                       // host decisions taken before their words are read back (BLANCE_SPECULATE=0|1|fail)
     int64_t spec_refuted = 0;                // ... and how often one had to be taken back
@@ -841,6 +844,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     if (ps.L > L) L = ps.L;
     c->L = L;
     c->np_later = pb->n_prev + (int)ps.fresh;              // plan.go:50
+    c->assign_empty = na == 0;
+    c->counts_start_zero = pb->n_loads == 0 && ps.aprev == 0;
     c->out_capacity = ps.cap;
 
     for (auto& rr : c->rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
@@ -1131,7 +1136,9 @@ static int launch_scan_excl(blance_ctx* c, int n, int32_t* data) {
 
 // stable LSD radix sort of the n (key, value) pairs in the f_*_a buffers; *sorted_vals = the buffer the sorted
 // values ended in (a or b: no copy back), *other_vals = the other one (free for the caller)
-static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches, int32_t** sorted_vals, int32_t** other_vals) {
+// (known_varying: the key bits that can differ at all, when the caller can tell -- no varbits launch, no round trip)
+static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches, int32_t** sorted_vals, int32_t** other_vals,
+                            const unsigned long long* known_varying) {
     const int n_tiles = cdiv(n, kSortTile);
     unsigned long long* ka = c->f_keys_a.as<unsigned long long>();
     unsigned long long* kb = c->f_keys_b.as<unsigned long long>();
@@ -1140,11 +1147,15 @@ static int radix_sort_pairs(blance_ctx* c, int n, int64_t* launches, int32_t** s
     // byte positions equal in every key need no pass (scores of one pass share most of their bits)
     unsigned long long* vbits = (unsigned long long*)(c->scalars.as<int32_t>() + 14);
     unsigned long long varying = 0;
-    HIPTRY(hipMemsetAsync(vbits, 0, sizeof varying, c->stream));
-    BLANCE_LAUNCH(k_sort_varbits, cdiv(n, 256 * kVarbitsPer), 256, 0, c->stream, n, ka, vbits);
-    HIPTRY(read_back(c, &varying, vbits, sizeof varying));
-    HIPTRY(stream_sync(c));
-    *launches += 1;
+    if (known_varying) {
+        varying = *known_varying;
+    } else {
+        HIPTRY(hipMemsetAsync(vbits, 0, sizeof varying, c->stream));
+        BLANCE_LAUNCH(k_sort_varbits, cdiv(n, 256 * kVarbitsPer), 256, 0, c->stream, n, ka, vbits);
+        HIPTRY(read_back(c, &varying, vbits, sizeof varying));
+        HIPTRY(stream_sync(c));
+        *launches += 1;
+    }
     int done = 0;
     for (int shift = 0; shift < 64; shift += 8) {
         if (((varying >> shift) & 0xff) == 0) continue;
@@ -1245,8 +1256,9 @@ static int flat_chain_prepare(blance_ctx* c, FlatChainPrep& fc, int64_t* launche
 // A flat pass (no hierarchy rule for the state): runs of certain stays and of
 // fresh identical partitions are resolved in bulk, the rest by k_pass_seq in
 // order on sub-ranges.  See the "Flat bulk engine" comment above the kernels.
+// opening: the first pass of a plan's first sweep -- what the upload knows about it needs no scan (run_flat_pass's callers)
 static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
-                         FlatChainPrep& fc) {
+                         FlatChainPrep& fc, bool opening) {
     hipStream_t sm = c->stream;
     c->bits_stale = true;                           // (the bulk kernels below bump nodeToNodeCounts, not k_pass_queue's bit maps)
     const int P = q.P;
@@ -1279,16 +1291,24 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             dirty = false;
             *launches += 1;
         }
-        const int scan_blocks = cdiv(P - pos, 256);
-        fq.scan_waves = scan_blocks * 4;
-        if (c->scan_part.reserve(sizeof(int32_t) * 2 * ((size_t)fq.scan_waves + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
-        fq.scan_part = c->scan_part.as<int32_t>();
-        BLANCE_LAUNCH(k_flat_scan, scan_blocks, 256, 0, sm, fq, pos, P);
-        BLANCE_LAUNCH(k_flat_scan_min, 1, 1024, 256, sm, fq.scan_waves, (const int32_t*)fq.scan_part, scal + 8);
         int32_t got[2] = {0, 0};
-        HIPTRY(read_back(c, got, scal + 8, sizeof got));
-        HIPTRY(stream_sync(c));
-        *launches += 1;
+        // A plan from nothing: the partitions to assign hold no node and have no weights of their own -- no step of the
+        // opening pass is a stay (k_flat_scan: a stay keeps the ONE node the partition holds) and every step is fresh and
+        // identical to the first (weight 1, nothing held anywhere): the scan's answer without the scan.
+        const bool known_run = opening && pos == 0 && c->assign_empty && c->h.partition_weights_nil && c->speculate > 0;
+        if (known_run) {
+            got[0] = 0; got[1] = P;
+        } else {
+            const int scan_blocks = cdiv(P - pos, 256);
+            fq.scan_waves = scan_blocks * 4;
+            if (c->scan_part.reserve(sizeof(int32_t) * 2 * ((size_t)fq.scan_waves + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+            fq.scan_part = c->scan_part.as<int32_t>();
+            BLANCE_LAUNCH(k_flat_scan, scan_blocks, 256, 0, sm, fq, pos, P);
+            BLANCE_LAUNCH(k_flat_scan_min, 1, 1024, 256, sm, fq.scan_waves, (const int32_t*)fq.scan_part, scal + 8);
+            HIPTRY(read_back(c, got, scal + 8, sizeof got));
+            HIPTRY(stream_sync(c));
+            *launches += 1;
+        }
         int first_nonstay = got[0] > P ? P : got[0], first_nonfresh = got[1] > P ? P : got[1];
         if (first_nonstay - pos >= kMinStayRun || (first_nonstay == P && first_nonstay > pos)) {
             const bool whole = pos == 0 && first_nonstay == P;      // the pass is one run of stays: no one reads the matrix
@@ -1314,7 +1334,16 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
                                  c->f_keys_a.as<unsigned long long>(), c->f_vals_a.as<int32_t>());
             int32_t *sorted_vals = nullptr, *other_vals = nullptr;
-            int e = radix_sort_pairs(c, RS, launches, &sorted_vals, &other_vals);
+            // Integer keys from counters that all start at zero (known_run: step weight 1): node n's elements are 2^32 + 0, 1,
+            // 2 ..; the RS smallest take floor or ceil of RS / A from each of the A nodes in the race, so the largest key is
+            // 2^32 + ceil(RS / A) - 1 and every bit below its top one varies -- what k_sort_varbits would report.
+            unsigned long long kv = 0;
+            const bool known_keys = known_run && fq.int_keys && c->counts_start_zero;
+            if (known_keys) {
+                const long long max_c = ((long long)RS + c->n_alive - 1) / c->n_alive - 1;
+                while (kv < (unsigned long long)max_c) kv = 2 * kv + 1;
+            }
+            int e = radix_sort_pairs(c, RS, launches, &sorted_vals, &other_vals, known_keys ? &kv : nullptr);
             if (e) return e;
             const int32_t* picks = sorted_vals;
             if (excl) {
@@ -2231,7 +2260,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             // the flat bulk driver: k = 1, and the first sweep of a fresh plan (NumPartitions == 0) with k = 2
             if (bulk) {
                 c->pass_kind[n_pass] = 1;
-                e = run_flat_pass(c, q, scal, &launches, &batched, fc);
+                e = run_flat_pass(c, q, scal, &launches, &batched, fc, first && passes_this_sweep == 1 && !retrying);
             } else if (flat_chain) {
                 c->pass_kind[n_pass] = 0;
                 const size_t rows = sizeof(int32_t) * (size_t)(NX + 1) * (NX + 1);
