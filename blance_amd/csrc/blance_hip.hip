@@ -204,6 +204,14 @@ struct blance_ctx {
     DevBuf scan_sums;               // tile totals of launch_scan_excl
     DevBuf scan_part;               // k_flat_scan's per-wave results
     DevBuf topkey, top_counts, top_off, top_order;   // k_stay_by_top: steps grouped by the leaf of their top priority node
+    // That grouping made AHEAD of the sweep that wants it: on a second stream, beside the chain kernel of the sweep before (a
+    // few dozen workgroups on 256 CUs).  It holds as long as the grouping by region it was made from does (group_epoch).
+    hipStream_t side = nullptr;
+    hipEvent_t side_go = nullptr, side_done = nullptr;
+    DevBuf side_sums;               // (launch_scan_excl's tile totals on that stream)
+    bool side_pending = false;      // work on `side` the planner's stream has not waited for yet
+    int top_group_state = -1;       // top_off / top_order are those of this state's chain order ...
+    int64_t top_group_epoch = -1, group_epoch = 0;   // ... as grouped at this count of regroupings
     std::vector<int64_t> last_stays; // [state] steps the last chain pass of that state committed as verified stays
     bool no_stay_top = false;       // test knob (& 64): never k_stay_by_top
     bool force_stay_top = false;    // test knob (& 128): try k_stay_by_top in every chain pass with NumPartitions > 0
@@ -532,7 +540,8 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     if (const char* sp = getenv("BLANCE_SPECULATE")) c->speculate = !strcmp(sp, "fail") ? 2 : atoi(sp) != 0;   // 0: every decision read back first
     if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipStreamCreate(&c->side) != hipSuccess ||
+        hipEventCreate(&c->side_go) != hipSuccess || hipEventCreate(&c->side_done) != hipSuccess) {
         delete c;
         return fail(BLANCE_ERR_DEVICE, "stream/event creation failed");
     }
@@ -545,6 +554,7 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     comm_release(c);
     c->free_all();
     for (hipEvent_t e : c->pass_events) (void)hipEventDestroy(e);
@@ -552,6 +562,9 @@ extern "C" void blance_ctx_destroy(blance_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->side_go) (void)hipEventDestroy(c->side_go);
+    if (c->side_done) (void)hipEventDestroy(c->side_done);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     if (--g_live_contexts == 0) pin_trim();          // the process's last context: the cache of page-locked blocks goes too
 }
@@ -1118,18 +1131,19 @@ static int dispatch_pass(blance_ctx* c, const PassParams& q0) {
 
 // exclusive scan of n ints on the planner's stream (k_sweep.h: one workgroup for short arrays, tile
 // totals + per-tile scans over the whole chip for long ones)
-static int launch_scan_excl(blance_ctx* c, int n, int32_t* data) {
+static int launch_scan_excl_on(blance_ctx* c, hipStream_t stream, DevBuf& sums, int n, int32_t* data) {
     if (n <= 4 * kScanTile) {
-        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, n, data);
+        BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, stream, n, data);
         return 0;
     }
     const int tiles = cdiv(n, kScanTile);
-    if (c->scan_sums.reserve(sizeof(int32_t) * ((size_t)tiles + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
-    BLANCE_LAUNCH(k_scan_tile_sums, tiles, 1024, 256, c->stream, n, data, c->scan_sums.as<int32_t>());
-    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, c->stream, tiles, c->scan_sums.as<int32_t>());
-    BLANCE_LAUNCH(k_scan_apply, tiles, 1024, 256, c->stream, n, data, c->scan_sums.as<int32_t>());
+    if (sums.reserve(sizeof(int32_t) * ((size_t)tiles + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
+    BLANCE_LAUNCH(k_scan_tile_sums, tiles, 1024, 256, stream, n, data, sums.as<int32_t>());
+    BLANCE_LAUNCH(k_scan_excl, 1, 1024, 256, stream, tiles, sums.as<int32_t>());
+    BLANCE_LAUNCH(k_scan_apply, tiles, 1024, 256, stream, n, data, sums.as<int32_t>());
     return 0;
 }
+static int launch_scan_excl(blance_ctx* c, int n, int32_t* data) { return launch_scan_excl_on(c, c->stream, c->scan_sums, n, data); }
 #define SCANTRY(n, data) do { int e__ = launch_scan_excl(c, (n), (data)); if (e__) return e__; } while (0)
 
 
@@ -1197,6 +1211,7 @@ static int run_flat_chain(blance_ctx* c, PassParams q, int beg, int end, bool ld
     cq.cnt = q.cnt; cq.ntn = q.ntn; cq.crec = c->crec.as<int32_t>(); cq.out = q.out; cq.flags = scal + 4;
     int pos = beg;
     c->chain_group_state = -1;                       // (reg_off is this chain's range from here on)
+    c->group_epoch++;
     while (pos < end) {
         int32_t range[2] = {pos, end};
         HIPTRY(hipMemcpyAsync(c->reg_off.p, range, sizeof range, hipMemcpyHostToDevice, sm));
@@ -1710,6 +1725,7 @@ static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* l
                       (const uint8_t*)nullptr, (const int32_t*)nullptr, a.order, nbc, B, nbits,
                       c->bucket_counts.as<int32_t>(), c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>());
         c->chain_group_state = m;
+        c->group_epoch++;
         c->chain_group_static = a.order == c->part_order.as<int32_t>();
     } else if (c->trace) fprintf(stderr, "[blance] chain pass state %d: the grouping by region of the last sweep stands\n", m);
     // events: how many?  (also: is every step region-local at all, are there orphan nodes); a sharded
@@ -1773,20 +1789,58 @@ static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* l
     }
     // A pass of stays only (the last sweep of every plan that converges)?  Worth a try when the state's pass of the
     // sweep before was one but for a few steps: k_stay_by_top checks every step in parallel.
-    const bool try_stay = !sharded && !run.no_stay && !c->no_stay_top && NP > 0 && !cfl[0] && !cfl[6] && !cfl[7] && rr.max_size <= kStayMaxLeaves &&
-                          rr.n_stay_wgs > 0 && (c->force_stay_top || c->last_stays[m] * 100 >= (int64_t)P * 99);
-    if (try_stay) {
+    const bool stay_fits = !sharded && !c->no_stay_top && NP > 0 && !cfl[0] && !cfl[6] && !cfl[7] && rr.max_size <= kStayMaxLeaves && rr.n_stay_wgs > 0;
+    const bool try_stay = stay_fits && !run.no_stay && (c->force_stay_top || c->last_stays[m] * 100 >= (int64_t)P * 99);
+    // k_stay_by_top's work list (the steps grouped by the leaf of their top priority node: four launches over all steps)
+    // depends on the grouping by region and on the top priority nodes only.  One made for this state at the same count of
+    // regroupings still holds; and a pass that does NOT try k_stay_by_top makes it for the next sweep's on the second
+    // stream, beside its own chain kernel.
+    const bool group_stands = c->top_group_state == m && c->top_group_epoch == c->group_epoch;
+    const bool group_ahead = stay_fits && !try_stay && !group_stands && c->speculate > 0 && a.it + 1 < h.max_iterations;
+    const int BL = rr.n_leaves;
+    if (try_stay || group_ahead) {
         RESERVE(topkey, sizeof(int32_t) * ((size_t)P + 1));
         RESERVE(top_order, sizeof(int32_t) * ((size_t)P + 1));
         RESERVE(top_off, sizeof(int32_t) * ((size_t)rr.n_leaves + 2));
         RESERVE(top_counts, sizeof(int32_t) * ((size_t)rr.n_leaves * nbc + 1));
+        if (c->side_pending) {                         // (what the second stream reads and writes is about to be used here)
+            HIPTRY(hipStreamWaitEvent(sm, c->side_done, 0));
+            c->side_pending = false;
+        }
     }
+    const bool group_now = (try_stay && !group_stands) || group_ahead;
     BLANCE_LAUNCH(k_gather_chain, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (kCW + 1) + 64, sm, d, m, h.top_state, a.higher_mask,
                          c->chain_order.as<int32_t>(), c->chain_oi.as<int32_t>(), c->state_stick.as<int32_t>(),
                          c->state_has_stick.as<uint8_t>(), c->node_leaf_pos.as<int32_t>(),
                          rr.node_region.as<int32_t>(), rr.reg_lo.as<int32_t>(), rr.leaf_cls.as<int32_t>(),
                          rr.cls_size.as<int32_t>(), 0,
-                         c->crec.as<int32_t>(), scal + 4, try_stay ? c->topkey.as<int32_t>() : (int32_t*)nullptr);
+                         c->crec.as<int32_t>(), scal + 4, group_now ? c->topkey.as<int32_t>() : (int32_t*)nullptr);
+    // steps grouped by the leaf of their top priority node, pass order inside a group (stable counting sort)
+    auto group_by_top = [&](hipStream_t st, DevBuf& sums) -> int {
+        int lbits = 1;
+        while ((1 << lbits) < BL) lbits++;
+        BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * BL + 64, st, P, c->topkey.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, BL, c->top_counts.as<int32_t>());
+        const int se = launch_scan_excl_on(c, st, sums, BL * nbc, c->top_counts.as<int32_t>());
+        if (se) return se;
+        BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(BL + 1, 64), 64, 0, st, BL, nbc, P, c->top_counts.as<int32_t>(), c->top_off.as<int32_t>());
+        BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * BL + 64, st, P, c->topkey.as<int32_t>(),
+                      (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, nbc, BL, lbits,
+                      c->top_counts.as<int32_t>(), c->top_order.as<int32_t>(), (int32_t*)nullptr);
+        c->top_group_state = m;
+        c->top_group_epoch = c->group_epoch;
+        launches += 5;
+        return 0;
+    };
+    if (group_ahead) {
+        HIPTRY(hipEventRecord(c->side_go, sm));        // (the keys are written)
+        HIPTRY(hipStreamWaitEvent(c->side, c->side_go, 0));
+        const int ge = group_by_top(c->side, c->side_sums);
+        if (ge) return ge;
+        HIPTRY(hipEventRecord(c->side_done, c->side));
+        c->side_pending = true;
+        if (c->trace) fprintf(stderr, "[blance] chain pass state %d: the steps grouped by top priority node for the next sweep, on the second stream\n", m);
+    }
     ChainParams cq;
     memset(&cq, 0, sizeof cq);
     cq.N = N; cq.NX = NX; cq.M = M; cq.L = L; cq.s = m; cq.k = k;
@@ -1825,17 +1879,10 @@ static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* l
     HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
     bool stayed = false;
     if (try_stay) {
-        // steps grouped by the leaf of their top priority node, pass order inside a group (stable counting sort)
-        const int BL = rr.n_leaves;
-        int lbits = 1;
-        while ((1 << lbits) < BL) lbits++;
-        BLANCE_LAUNCH(k_part_count, nbc, 64, sizeof(int32_t) * BL + 64, sm, P, c->topkey.as<int32_t>(),
-                      (const uint8_t*)nullptr, (const int32_t*)nullptr, nbc, BL, c->top_counts.as<int32_t>());
-        SCANTRY(BL * nbc, c->top_counts.as<int32_t>());
-        BLANCE_LAUNCH_NOSYNC(k_region_offsets, cdiv(BL + 1, 64), 64, 0, sm, BL, nbc, P, c->top_counts.as<int32_t>(), c->top_off.as<int32_t>());
-        BLANCE_LAUNCH(k_part_scatter, nbc, 64, sizeof(int32_t) * BL + 64, sm, P, c->topkey.as<int32_t>(),
-                      (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, nbc, BL, lbits,
-                      c->top_counts.as<int32_t>(), c->top_order.as<int32_t>(), (int32_t*)nullptr);
+        if (!group_stands) {
+            const int ge = group_by_top(sm, c->scan_sums);
+            if (ge) return ge;
+        } else if (c->trace) fprintf(stderr, "[blance] chain pass state %d: the steps' grouping by top priority node stands\n", m);
         StayParams sq;
         memset(&sq, 0, sizeof sq);
         sq.N = N; sq.NX = NX; sq.M = M; sq.s = m; sq.k = k; sq.NP = NP; sq.OW = OW; sq.booster_kind = h.booster_kind;
@@ -1847,7 +1894,7 @@ static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* l
         sq.top_off = c->top_off.as<int32_t>(); sq.top_order = c->top_order.as<int32_t>();
         sq.out = c->out.as<int32_t>(); sq.flag = scal + 4 + kFlagStayMoved;
         if (launch_stay_by_top(sm, sq, rr.n_stay_wgs, rr.max_size)) {
-            launches += 5;
+            launches += 1;
             if (defer) {
                 stayed = true;                          // (until the caller's readback says otherwise)
                 run.pending = 1;
@@ -2091,6 +2138,9 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
     c->queue_launches = c->queue_stops = 0;
     c->comm_events_used = 0;
     c->chain_group_state = -1;
+    c->group_epoch++;
+    c->top_group_state = -1;
+    if (c->side_pending) { HIPTRY(hipStreamSynchronize(c->side)); c->side_pending = false; }
     const int64_t syncs0 = c->n_syncs;
 
     HIPTRY(hipEventRecord(c->ev0, sm));

@@ -8,7 +8,8 @@ namespace blance {
 template <int NPTC, int KM, bool FAST>
 static void launch_chain_v(hipStream_t stream, const ChainParams& q, size_t lds, int waves) {
     auto kern = k_pass_chain<NPTC, KM, FAST>;
-    // (the walking wave and its helpers for the stay test, k_pass_chain.h)
+    // (the walking wave and its helpers for the stay test, k_pass_chain.h; never more than the instance's launch bounds)
+    if (waves > chain_waves_max<NPTC>()) waves = chain_waves_max<NPTC>();
     BLANCE_LAUNCH(kern, q.n_launch, 64 * waves, lds, stream, q);
 }
 
@@ -50,7 +51,7 @@ bool launch_chain(hipStream_t stream, ChainParams& q, int max_size, bool fast) {
     q.ntn_in_lds = chain_rows_in_lds(q, max_size);
     int waves = chain_waves(q, max_size);
     if (q.NP > 0 && q.ntn_in_lds && !chain_rows_fit(q, max_size, waves)) waves = 4;      // (insisted on eight: not at the rows' expense)
-    if (nptc >= 8) waves = 4;                        // (chain_waves_max: such a wave needs more than half a SIMD's registers)
+    if (nptc > 4) waves = 4;                         // (the <8, ..> instances, chain_waves_max: such a wave needs more than half a SIMD's registers)
     size_t lds = chain_lds_base(q, max_size, waves);
     if (q.NP > 0 && q.ntn_in_lds) lds += ntn_bytes;
     if (q.k <= 2) {
