@@ -300,6 +300,7 @@ struct blance_ctx {
 
     // device: problem
     DevBuf node_removed, node_added, node_weight, node_has_weight, alive, zeros_nx, node_leaf_pos;
+    DevBuf alive_ids, alive_rank;   // the nodes of nodesNext in id order; a node's place in that list (-1: not in it)
     DevBuf part_order, part_weight, part_has_weight, part_in_prev, part_never_equal;
     DevBuf a_off, a_nodes, a_kind, p_off, p_nodes, p_kind;
     DevBuf load_state, load_node, load_weight, load_first;
@@ -330,6 +331,7 @@ struct blance_ctx {
         for (auto& rr : rule_regions) { rr.node_region.release(); rr.reg_lo.release(); rr.reg_hi.release(); rr.leaf_cls.release(); rr.cls_size.release(); rr.wg_region.release(); rr.wg_chunk.release(); }
         rule_regions.clear();
         topkey.release(); top_counts.release(); top_off.release(); top_order.release();
+        alive_ids.release(); alive_rank.release(); side_sums.release();
         cnt_base.release(); xbuf.release(); gath.release(); scan_sums.release(); scan_part.release(); ntn_bits.release();
         dl_off.release(); dl_nodes.release(); vres.release(); vseen.release();
         stage.release();
@@ -742,12 +744,14 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     for (int m = 0; m < M; m++)
         if (m != pb->top_state && pb->state_priority[m] <= pb->state_priority[pb->top_state]) c->top_prio_strict = false;
     std::vector<uint8_t> alive((size_t)NX + 1, 0);
+    std::vector<int32_t> alive_ids, alive_rank((size_t)NX + 1, -1);      // the nodes of nodesNext by id, and a node's place among them
     c->n_alive = 0;
     c->any_removed = 0;
     for (int n = 0; n < NX; n++) {
         if (pb->node_removed[n]) c->any_removed = 1;
-        if (n < N && !pb->node_removed[n]) { alive[n] = 1; c->n_alive++; }
+        if (n < N && !pb->node_removed[n]) { alive[n] = 1; alive_rank[n] = c->n_alive++; alive_ids.push_back(n); }
     }
+    alive_ids.push_back(-1);                                              // (never empty)
 
     Mover up(c, true);
     c->stage.used = 0;                               // (the stream is idle between calls)
@@ -761,6 +765,8 @@ static int upload_inner(blance_ctx* c, const blance_problem* pb) {
     PUT(node_weight, pb->node_weight, NX);
     PUT(node_has_weight, pb->node_has_weight, NX);
     PUT(alive, alive.data(), NX);
+    PUT(alive_ids, alive_ids.data(), alive_ids.size());
+    PUT(alive_rank, alive_rank.data(), NX);
     PUT(node_leaf_pos, pb->node_leaf_pos, NX);
     RESERVE(zeros_nx, NX + 1);
     HIPTRY(hipMemsetAsync(c->zeros_nx.p, 0, (size_t)NX + 1, c->stream));
@@ -1300,12 +1306,6 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     bool dirty = true;
     while (pos < P) {
         c->bits_stale = true;                       // (conservative: a bulk commit may have run since the last k_pass_queue)
-        if (dirty) {
-            BLANCE_LAUNCH(k_flat_prepare, 1, 1024, sizeof(RedSlot) * 32 + 64, sm, fq, c->f_tot.as<int32_t>(),
-                          c->f_g.as<double>(), c->f_top_g.as<double>(), c->f_top_n.as<int32_t>());
-            dirty = false;
-            *launches += 1;
-        }
         int32_t got[2] = {0, 0};
         // A plan from nothing: the partitions to assign hold no node and have no weights of their own -- no step of the
         // opening pass is a stay (k_flat_scan: a stay keeps the ONE node the partition holds) and every step is fresh and
@@ -1314,6 +1314,12 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
         if (known_run) {
             got[0] = 0; got[1] = P;
         } else {
+            if (dirty) {                            // the load totals and the smallest partition-independent scores: what the scan tests against
+                BLANCE_LAUNCH(k_flat_prepare, 1, 1024, sizeof(RedSlot) * 32 + 64, sm, fq, c->f_tot.as<int32_t>(),
+                              c->f_g.as<double>(), c->f_top_g.as<double>(), c->f_top_n.as<int32_t>());
+                dirty = false;
+                *launches += 1;
+            }
             const int scan_blocks = cdiv(P - pos, 256);
             fq.scan_waves = scan_blocks * 4;
             if (c->scan_part.reserve(sizeof(int32_t) * 2 * ((size_t)fq.scan_waves + 1))) return fail(BLANCE_ERR_DEVICE, "hipMalloc failed");
@@ -1344,22 +1350,31 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             const bool excl = q.NP == 0 && (q.higher_mask != 0 || q.k == 2);
             const int RS = excl ? q.k * R + q.k : R;
             if (q.NP > 0) NTNTRY();                 // (the fresh run reads and bumps row "" of the matrix)
-            BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, RS, c->f_m.as<int32_t>(),
-                          c->f_moff.as<int32_t>());
-            BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
-                                 c->f_keys_a.as<unsigned long long>(), c->f_vals_a.as<int32_t>());
             int32_t *sorted_vals = nullptr, *other_vals = nullptr;
-            // Integer keys from counters that all start at zero (known_run: step weight 1): node n's elements are 2^32 + 0, 1,
-            // 2 ..; the RS smallest take floor or ceil of RS / A from each of the A nodes in the race, so the largest key is
-            // 2^32 + ceil(RS / A) - 1 and every bit below its top one varies -- what k_sort_varbits would report.
-            unsigned long long kv = 0;
-            const bool known_keys = known_run && fq.int_keys && c->counts_start_zero;
-            if (known_keys) {
-                const long long max_c = ((long long)RS + c->n_alive - 1) / c->n_alive - 1;
-                while (kv < (unsigned long long)max_c) kv = 2 * kv + 1;
+            // Integer keys (NumPartitions == 0, no node weights) from counters that all start at zero, step weight 1
+            // (known_run): node n's elements are (0, n), (1, n), (2, n) ..; the RS smallest in (key, node) order are the A
+            // nodes of nodesNext by id, again and again -- the sorted sequence and every node's share of it without
+            // threshold search, emission and sort (the empty cluster's greedy plan is a round robin).
+            if (known_run && fq.int_keys && c->counts_start_zero) {
+                sorted_vals = c->f_vals_a.as<int32_t>();
+                other_vals = c->f_vals_b.as<int32_t>();
+                BLANCE_LAUNCH_NOSYNC(k_fresh_cycle, cdiv(RS > q.N ? RS : q.N, 256), 256, 0, sm, RS, c->n_alive, q.N,
+                                     c->alive_ids.as<int32_t>(), c->alive_rank.as<int32_t>(), sorted_vals, c->f_m.as<int32_t>());
+                *launches += 1;
+            } else {
+                if (dirty) {
+                    BLANCE_LAUNCH(k_flat_prepare, 1, 1024, sizeof(RedSlot) * 32 + 64, sm, fq, c->f_tot.as<int32_t>(),
+                                  c->f_g.as<double>(), c->f_top_g.as<double>(), c->f_top_n.as<int32_t>());
+                    dirty = false;
+                    *launches += 1;
+                }
+                BLANCE_LAUNCH(k_fresh_threshold, 1, 1024, 16384 + 64, sm, fq, pos, RS, c->f_m.as<int32_t>(),
+                              c->f_moff.as<int32_t>());
+                BLANCE_LAUNCH_NOSYNC(k_fresh_emit, cdiv(RS, 256), 256, 0, sm, fq, pos, RS, c->f_moff.as<int32_t>(),
+                                     c->f_keys_a.as<unsigned long long>(), c->f_vals_a.as<int32_t>());
+                const int e = radix_sort_pairs(c, RS, launches, &sorted_vals, &other_vals, nullptr);
+                if (e) return e;
             }
-            int e = radix_sort_pairs(c, RS, launches, &sorted_vals, &other_vals, known_keys ? &kv : nullptr);
-            if (e) return e;
             const int32_t* picks = sorted_vals;
             if (excl) {
                 int32_t bad = INT_MAX;

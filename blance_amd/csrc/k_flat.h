@@ -416,6 +416,18 @@ __global__ void k_fresh_emit(FlatParams q, int beg, int R, const int32_t* m_off,
     vals[e] = n;
 }
 
+// The sorted sequence of a fresh run when every counter starts at zero and the keys are the integers count + c w (no
+// NumPartitions, no node weights, one weight): (c, n) in (key, node) order is the nodes of nodesNext by id, again and
+// again; node n's share of the first RS elements follows from its place in that list.
+__global__ void k_fresh_cycle(int RS, int A, int N, const int32_t* alive_ids, const int32_t* alive_rank, int32_t* vals, int32_t* m) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < RS) vals[e] = alive_ids[e % A];
+    if (e < N) {
+        const int r = alive_rank[e];
+        m[e] = r < 0 ? 0 : RS / A + (r < RS % A ? 1 : 0);
+    }
+}
+
 __global__ void k_fresh_commit_steps(FlatParams q, int beg, int R, const int32_t* picks /* [k R], k per step */) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R) return;

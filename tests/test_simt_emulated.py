@@ -365,3 +365,34 @@ def test_fresh_runs_two_picks(emu_lib):
     for fp in (synth.config5_initial(400, 60), synth.config5_initial(900, 30)):
         assert pl.plan(fp).digest() == _oracle(fp).digest()
     pl.close()
+
+
+def test_plan_from_nothing_opening_pass(emu_lib, monkeypatch):
+    """A plan from nothing (round 6): the opening pass needs no scan and no sort -- the empty cluster's greedy plan is a round
+    robin over nodesNext by id.  Shapes that bend the closed form: nodes removed up front (nodesNext is not every node),
+    partition counts that are no multiple of the node count, one and two picks per step, flat and hierarchical, extra states;
+    with the host's shortcuts on and off, against the oracle."""
+    shapes = []
+    for cfg, P, N in ((2, 3000, 37), (2, 2048, 64), (3, 2500, 96), (3, 4096, 128)):
+        c = synth.config_case(cfg, P=P, N=N)
+        shapes.append((cfg, P, N, "all", c))
+        # (nodesToRemove needs the partitions in prevMap, plan.go:545: there, holding nothing -- NumPartitions > 0 then)
+        c2 = synth.config_case(cfg, P=P, N=N)
+        c2["prevMap"] = c2["partitionsToAssign"]
+        c2["aliased"] = True
+        c2["nodesToRemove"] = [n for i, n in enumerate(c2["nodesAll"]) if i % 7 == 3]
+        c2["nodesToAdd"] = [n for n in c2["nodesAll"] if n not in set(c2["nodesToRemove"])]
+        shapes.append((cfg, P, N, "removed", c2))
+    for cfg, P, N, what, c in shapes:
+        fp = synth.case_to_flat(c)
+        want = _oracle(fp)
+        for spec in ("1", "0"):
+            monkeypatch.setenv("BLANCE_SPECULATE", spec)
+            pl = hip.Planner(lib_path=emu_lib, chain_min_parts=64)
+            got = pl.plan(fp)
+            assert (got.digest(), got.iterations) == (want.digest(), want.iterations), (cfg, P, N, what, spec)
+            if spec == "1":
+                fewer = got.struct.host_syncs
+            else:
+                assert fewer < got.struct.host_syncs, (cfg, P, N, what, fewer, got.struct.host_syncs)
+            pl.close()
