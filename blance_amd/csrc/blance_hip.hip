@@ -1277,9 +1277,13 @@ static int flat_chain_prepare(blance_ctx* c, FlatChainPrep& fc, int64_t* launche
 // A flat pass (no hierarchy rule for the state): runs of certain stays and of
 // fresh identical partitions are resolved in bulk, the rest by k_pass_seq in
 // order on sub-ranges.  See the "Flat bulk engine" comment above the kernels.
-// opening: the first pass of a plan's first sweep -- what the upload knows about it needs no scan (run_flat_pass's callers)
+// opening: a pass of a plan's first sweep whose steps the host knows to be fresh and alike without looking -- the first pass
+// over partitions that hold nothing, or the second when the first gave every partition ONE node in a state of higher priority
+// and NumPartitions == 0 (k_flat_scan's test for "fresh": such a node is just not a candidate).  *whole_known: the pass was
+// such a run from its first step to its last.
 static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
-                         FlatChainPrep& fc, bool opening) {
+                         FlatChainPrep& fc, bool opening, bool* whole_known) {
+    *whole_known = false;
     hipStream_t sm = c->stream;
     c->bits_stale = true;                           // (the bulk kernels below bump nodeToNodeCounts, not k_pass_queue's bit maps)
     const int P = q.P;
@@ -1399,6 +1403,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
                 BLANCE_LAUNCH_NOSYNC(k_fresh_commit_nodes, cdiv(q.N, 256), 256, 0, sm, fq, pos, c->f_m.as<int32_t>(), q.cnt);
                 *launches += 4;
                 *batched += R;
+                if (known_run && R == P) *whole_known = true;
                 pos += R;
                 dirty = true;
                 seq_batch = 256;
@@ -2212,6 +2217,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             launches++;
         }
         int passes_this_sweep = 0;
+        int known_passes = 0, known_state = -1, known_k = 0;        // run_flat_pass's `opening`
+        bool known_broken = false;
         // The sweep's last pass, when it is a chain pass, leaves its verdict on the device (ChainRun::defer) and the words
         // come back with the convergence word: one round trip for both.  A bad verdict brings the loop back for that
         // state alone (retry says how), with everything the pass enqueued behind its gate undone by never having run.
@@ -2268,6 +2275,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 ChainRun run;
                 if (retrying) run = retry;
                 run.defer = !retrying && m == m_last;
+                known_broken = true;
                 const int e = run_chain_pass(c, ca, &launches, &batched, &n_pass, &done, &a_done, run);
                 if (!e && run.pending) pend = run;
                 if (e) {
@@ -2325,14 +2333,23 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             // the flat bulk driver: k = 1, and the first sweep of a fresh plan (NumPartitions == 0) with k = 2
             if (bulk) {
                 c->pass_kind[n_pass] = 1;
-                e = run_flat_pass(c, q, scal, &launches, &batched, fc, first && passes_this_sweep == 1 && !retrying);
+                // (what the sweep's passes so far have been: known_passes of them fresh runs known in advance, the last one
+                // of state known_state with known_k picks a step)
+                const bool opening = first && !retrying && !known_broken &&
+                                     (known_passes == 0 || (known_passes == 1 && known_k == 1 && NP == 0 && ((higher_mask >> known_state) & 1)));
+                bool whole_known = false;
+                e = run_flat_pass(c, q, scal, &launches, &batched, fc, opening, &whole_known);
+                if (whole_known) { known_passes++; known_state = m; known_k = k; }
+                else known_broken = true;
             } else if (flat_chain) {
+                known_broken = true;
                 c->pass_kind[n_pass] = 0;
                 const size_t rows = sizeof(int32_t) * (size_t)(NX + 1) * (NX + 1);
                 e = run_flat_chain(c, q, 0, P, NP > 0 && rows <= 100 * 1024, scal, &launches);
                 if (e > 0) e = fail(BLANCE_ERR_DEVICE, "flat chain refused a checked pass");
                 if (!e) batched += P;
             } else {
+                known_broken = true;
                 c->pass_kind[n_pass] = 0;
                 e = dispatch_pass(c, q);
             }
