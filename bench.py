@@ -777,13 +777,13 @@ def main():
                                        "hierarchy region; with k_period.h two periods walked and the periodic stretch copied)",
                                        ("k_pass_chain_planes", "k_pass_chain_blank", "k_period"), K_CW + 1 + kmax, acc["blank_ms"],
                                        acc["blank_launches"], zones, dense_pass, walked=bool(args.no_periodic)))
-            kernels.append(kernel_line("k_pass_chain<2,2,false> (the replica pass of a later sweep that still moves steps: one workgroup of four "
-                                       "waves per hierarchy region -- one walks the region's steps in order, all four test 256 steps for stays at a time)",
+            kernels.append(kernel_line("k_pass_chain<2,2,false> (the replica pass of a later sweep that still moves steps: one workgroup of eight "
+                                       "waves per hierarchy region -- one walks the region's steps in order, all eight test 512 steps for stays at a time)",
                                        ("k_pass_chainI",), K_CW + 1 + kmax, acc["pass_ms"] - acc["blank_ms"] - acc["stay_ms"],
                                        acc["pass_launches"] - acc["blank_launches"] - acc["stay_launches"], zones, dense_pass,
                                        waves_per_chain=8))           # (k_pass_chain.h: kChainWaves -- the walking wave and seven helpers of the stay test)
-            kernels.append(kernel_line("k_stay_by_top (the replica pass of a converged sweep: every step verified as a stay by one thread per "
-                                       "top priority node; the time includes the counting sort that groups the steps by top node)",
+            kernels.append(kernel_line("k_stay_by_top (the replica pass of a converged sweep: every step verified as a stay, a wave per top priority "
+                                       "node and a step per lane; the steps' grouping by top node is made a sweep ahead on a second stream)",
                                        ("k_stay_by_top",), K_CW + 1 + kmax, acc["stay_ms"], acc["stay_launches"], None, dense_pass))
         kernels.append(kernel_line("flat driver passes (k_flat_*, k_fresh_*, k_sort_*: several launches per pass)",
                                    ("k_flat", "k_fresh", "k_sort"), RW + 2, acc["flat_ms"], acc["flat_passes"], None, dense_flat))

@@ -30,9 +30,10 @@ for cfg in 3 2 5; do
   tail -3 "$out/profile_config$cfg.log"
 done
 bash tools/profile/gpu_profile_general.sh > "$out/profile_general.log" 2>&1; tail -4 "$out/profile_general.log"
-if [ -f devbuild/libblance_prof.so ]; then
-  timeout 300 python tools/profile/general_regime.py > "$out/phase_general_b.log" 2>&1
-  grep -c "queue\]" "$out/phase_general_b.log"
+if [ -f devbuild/libblance_prof.so ]; then     # (tools/profile/build_prof.sh tu_chain: k_pass_chain's phase clocks at config 3)
+  timeout 300 python tools/profile/chain_phases.py > "$out/phase_chain_config3.log" 2>&1
+  grep -c "phase" "$out/phase_chain_config3.log"
 fi
+bash tools/profile/ab_speculate.sh > "$out/ab_speculate.txt" 2>&1; tail -12 "$out/ab_speculate.txt"
 timeout 1500 python -m pytest tests -q -m gpu > "$out/test_gpu_full.log" 2>&1; grep -E "passed|failed" "$out/test_gpu_full.log" | tail -2
 bash tools/profile/gpu_stress.sh 150 81000 100 83000 | tail -8
