@@ -542,7 +542,7 @@ extern "C" int blance_ctx_create(const blance_options* opt, blance_ctx** out) {
     if (const char* sp = getenv("BLANCE_SPECULATE")) c->speculate = !strcmp(sp, "fail") ? 2 : atoi(sp) != 0;   // 0: every decision read back first
     if (const char* ds = getenv("BLANCE_DUMP_SWEEP")) c->dump_sweep = atoi(ds);
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || hipStreamCreate(&c->side) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->side_go) != hipSuccess || hipEventCreate(&c->side_done) != hipSuccess) {
         delete c;
         return fail(BLANCE_ERR_DEVICE, "stream/event creation failed");
@@ -1816,7 +1816,12 @@ static int run_chain_pass_once(blance_ctx* c, const ChainPassArgs& a, int64_t* l
     // regroupings still holds; and a pass that does NOT try k_stay_by_top makes it for the next sweep's on the second
     // stream, beside its own chain kernel.
     const bool group_stands = c->top_group_state == m && c->top_group_epoch == c->group_epoch;
-    const bool group_ahead = stay_fits && !try_stay && !group_stands && c->speculate > 0 && a.it + 1 < h.max_iterations;
+    // (The second stream is made when it is first wanted, and only in a process of one or two planners: a stream is a
+    // hardware queue, and with many contexts planning at once on one GPU -- bench.py's replicas: 16 contexts, 32 queues -- the
+    // planners' own streams end up sharing queues and their long kernels run one after the other.)
+    bool group_ahead = stay_fits && !try_stay && !group_stands && c->speculate > 0 && a.it + 1 < h.max_iterations &&
+                       (c->side || g_live_contexts.load() <= 2);
+    if (group_ahead && !c->side && hipStreamCreate(&c->side) != hipSuccess) { c->side = nullptr; group_ahead = false; (void)hipGetLastError(); }
     const int BL = rr.n_leaves;
     if (try_stay || group_ahead) {
         RESERVE(topkey, sizeof(int32_t) * ((size_t)P + 1));
