@@ -1282,8 +1282,9 @@ static int flat_chain_prepare(blance_ctx* c, FlatChainPrep& fc, int64_t* launche
 // and NumPartitions == 0 (k_flat_scan's test for "fresh": such a node is just not a candidate).  *whole_known: the pass was
 // such a run from its first step to its last.
 static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
-                         FlatChainPrep& fc, bool opening, bool* whole_known) {
+                         FlatChainPrep& fc, bool opening, bool* whole_known, bool settled, bool* nothing_to_apply) {
     *whole_known = false;
+    *nothing_to_apply = false;
     hipStream_t sm = c->stream;
     c->bits_stale = true;                           // (the bulk kernels below bump nodeToNodeCounts, not k_pass_queue's bit maps)
     const int P = q.P;
@@ -1339,6 +1340,15 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
             const bool whole = pos == 0 && first_nonstay == P;      // the pass is one run of stays: no one reads the matrix
             if (whole && q.s == q.top_state && q.k == 1) c->tops_moved = false;      // (k > 1: a stay may still reorder the list, plan.go:126-138 reads its first node)
             if (q.NP > 0 && !whole) NTNTRY();
+            // One run of certain stays with ONE node each, as the first pass of a sweep >= 2 (`settled`: every present list is a
+            // non-nil slice, plan.go:418): applying it (plan.go:290-299) changes nothing -- the partition keeps the node it holds,
+            // which is in no other list of the partition (k_flat_scan's test), so no list is filtered and no kind changes.
+            // Neither the outputs nor k_scatter are needed then.
+            if (whole && q.k == 1 && settled) {
+                *nothing_to_apply = true;
+                *batched += P;
+                break;
+            }
             BLANCE_LAUNCH_NOSYNC(k_flat_commit_stay, cdiv(first_nonstay - pos, 256), 256, 0, sm, fq, pos, first_nonstay, whole ? 0 : 1);
             *launches += 1;
             *batched += first_nonstay - pos;
@@ -2337,6 +2347,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             }
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass], sm));
             int e;
+            bool nothing_to_apply = false;               // (run_flat_pass: a pass of stays that leaves every list as it is)
             c->pass_kind.resize(n_pass + 1);
             // the flat bulk driver: k = 1, and the first sweep of a fresh plan (NumPartitions == 0) with k = 2
             if (bulk) {
@@ -2346,7 +2357,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 const bool opening = first && !retrying && !known_broken &&
                                      (known_passes == 0 || (known_passes == 1 && known_k == 1 && NP == 0 && ((higher_mask >> known_state) & 1)));
                 bool whole_known = false;
-                e = run_flat_pass(c, q, scal, &launches, &batched, fc, opening, &whole_known);
+                const bool settled = !first && passes_this_sweep == 1 && !retrying && c->dump_sweep < 0 && c->speculate > 0;
+                e = run_flat_pass(c, q, scal, &launches, &batched, fc, opening, &whole_known, settled, &nothing_to_apply);
                 if (whole_known) { known_passes++; known_state = m; known_k = k; }
                 else known_broken = true;
             } else if (flat_chain) {
@@ -2365,7 +2377,8 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             HIPTRY(hipEventRecord(c->pass_events[2 * n_pass + 1], sm));
             n_pass++;
             if (dump_pass(c, it, m, P, q.OW, nullptr)) return BLANCE_ERR_DEVICE;
-            BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, order, c->out.as<int32_t>(), kNoGate);
+            if (!nothing_to_apply)
+                BLANCE_LAUNCH_NOSYNC(k_scatter, cdiv(P, 256), 256, 0, sm, d, m, q.OW, order, c->out.as<int32_t>(), kNoGate);
             }
             launches += 7;
             steps += P;
