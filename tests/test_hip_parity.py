@@ -604,3 +604,27 @@ def test_config3_shapes_at_scale(planner, rack, racks_per_zone, k_rep):
     fp = synth.case_to_flat(c)
     _same(planner.plan(fp), _oracle(fp), ("config 3 at scale", rack, racks_per_zone, k_rep))
 
+
+
+@pytest.mark.gpu
+def test_host_shortcuts_on_the_device(monkeypatch):
+    """Round 6's shortcuts of the host on the device, where streams really run side by side: plans from nothing (config 2's and
+    config 3's shapes, partition counts that are no multiple of the node count) with the shortcuts on, off and forced to fail
+    -- the same map, fewer round trips with them on; k_stay_by_top's work list made a sweep ahead on the second stream and used
+    by the next sweep (the converged sweep is a k_stay_by_top pass; repeated, so that an ordering left to chance would show)."""
+    shapes = [(2, 50000, 97), (2, 65536, 256), (3, 65536, 1024), (3, 100000, 768), (3, 131072, 4096)]
+    for cfg, P, N in shapes:
+        fp = synth.config_flat(cfg, P=P, N=N)
+        want = _oracle(fp)
+        syncs = {}
+        for spec in ("1", "0", "fail"):
+            monkeypatch.setenv("BLANCE_SPECULATE", spec)
+            pl = hip.Planner(device_id=0)
+            for rep in range(3 if spec == "1" else 1):
+                got = pl.plan(fp)
+                _same(got, want, ("host shortcuts", cfg, P, N, spec, rep))
+                if cfg == 3 and spec == "1":
+                    assert got.struct.stay_pass_launches >= 1, (P, N)
+            syncs[spec] = got.struct.host_syncs
+            pl.close()
+        assert syncs["1"] < syncs["0"], (cfg, P, N, syncs)
