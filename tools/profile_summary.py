@@ -68,6 +68,30 @@ def trace(db, calls, out, title):
             lines.append("   %-92s %5d gaps, %9.3f ms in total, %7.3f ms per call" % (what, len(sel), sum(sel) / 1e6, sum(sel) / 1e6 / calls))
     except Exception as e:                                   # (older databases: no timestamps table layout we know)
         lines.append("(no gap statistics: %s)" % str(e)[:80])
+    # kernels that ran BESIDE a longer one (the second stream: k_stay_by_top's work list made beside the chain kernel)
+    try:
+        disp = cur.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id=s.id order by d.start"
+                           % (g("kernel_dispatch"), g("kernel_symbol"))).fetchall()
+        inside = {}
+        for i, (n0, s0, e0) in enumerate(disp):
+            if e0 - s0 < 100e3:
+                continue                                     # hosts of at least 0.1 ms
+            for n1, s1, e1 in disp[i + 1:]:
+                if s1 >= e0:
+                    break
+                if e1 <= e0:
+                    k = (short(n0), short(n1))
+                    v = inside.setdefault(k, [0, 0.0])
+                    v[0] += 1
+                    v[1] += e1 - s1
+        lines.append("")
+        lines.append("kernels that started and ended while a longer kernel (>= 0.1 ms) was running -- another stream of the same context:")
+        for (n0, n1), (cnt, ns) in sorted(inside.items(), key=lambda kv: -kv[1][1]):
+            lines.append("   inside %-50s %-50s %4d launches, %8.3f ms" % (n0[:50], n1[:50], cnt, ns / 1e6))
+        if not inside:
+            lines.append("   (none)")
+    except Exception as e:
+        lines.append("(no overlap statistics: %s)" % str(e)[:80])
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))
 
