@@ -1282,7 +1282,7 @@ static int flat_chain_prepare(blance_ctx* c, FlatChainPrep& fc, int64_t* launche
 // and NumPartitions == 0 (k_flat_scan's test for "fresh": such a node is just not a candidate).  *whole_known: the pass was
 // such a run from its first step to its last.
 static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* launches, int64_t* batched,
-                         FlatChainPrep& fc, bool opening, bool* whole_known, bool settled, bool* nothing_to_apply) {
+                         FlatChainPrep& fc, bool opening, bool* whole_known, bool settled, bool* nothing_to_apply, bool rows_counted) {
     *whole_known = false;
     *nothing_to_apply = false;
     hipStream_t sm = c->stream;
@@ -1298,7 +1298,7 @@ static int run_flat_pass(blance_ctx* c, PassParams q, int32_t* scal, int64_t* la
     fq.row_count = c->f_row_count.as<int32_t>();
     fq.ntn = q.ntn; fq.rec = q.rec; fq.out = q.out; fq.scan = scal + 8;
     fq.int_keys = (q.NP == 0 && !c->any_node_weight) ? 1 : 0;
-    if (q.NP > 0) {                                 // only read by the stay test when NP > 0
+    if (q.NP > 0 && !rows_counted) {                // only read by the stay test when NP > 0; (else: k_gather has counted)
         if (!c->rowcount_clean) HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)q.NX + 1), sm));
         c->rowcount_clean = false;
         BLANCE_LAUNCH(k_flat_row_count, cdiv(P, 256), 256, 0, sm, fq, c->f_row_count.as<int32_t>());
@@ -2304,8 +2304,18 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                 }
             }
             if (!done) {
+            // (what kind of pass this will be, before its records are made: the flat bulk driver's row bound rides on the gather)
+            const bool flat_state = h.hierarchy_rules_nil || r1 == r0;
+            const bool bulk = c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && (k == 1 || (k == 2 && NP == 0)) &&
+                              P >= c->chain_min_parts;
+            const bool count_rows = bulk && NP > 0 && c->f_row_count.p;
+            if (count_rows) {
+                if (!c->rowcount_clean) HIPTRY(hipMemsetAsync(c->f_row_count.p, 0, sizeof(int32_t) * ((size_t)NX + 1), sm));
+                c->rowcount_clean = false;
+            }
             BLANCE_LAUNCH(k_gather, cdiv(P, 256), 256, sizeof(int32_t) * 256 * (RW | 1) + 64, sm, d, m, h.top_state, RW, order,
-                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>());
+                                 c->state_stick.as<int32_t>(), c->state_has_stick.as<uint8_t>(), c->rec.as<int32_t>(),
+                                 count_rows ? c->f_row_count.as<int32_t>() : (int32_t*)nullptr, NX);
             PassParams q;
             memset(&q, 0, sizeof q);
             q.N = N; q.NX = NX; q.M = M; q.L = L; q.P = P; q.s = m; q.k = k; q.top_state = h.top_state;
@@ -2332,14 +2342,11 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
             q.spec_count = (long long*)(scal + 12);
             q.beg = 0; q.end = P;
             // a flat pass (no rule for the state) of a small cluster can run on one wave64
-            const bool flat_state = h.hierarchy_rules_nil || r1 == r0;
             bool flat_chain = c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && c->flat_chain_ok && k <= 4 &&
                               P >= c->chain_min_parts;
             c->no_fast_keys = false;
             FlatChainPrep fc;
             fc.possible = flat_chain; fc.d = d; fc.m = m; fc.higher_mask = higher_mask; fc.order = order;
-            const bool bulk = c->engine != BLANCE_ENGINE_SEQUENTIAL && flat_state && (k == 1 || (k == 2 && NP == 0)) &&
-                              P >= c->chain_min_parts;
             if (flat_chain && !bulk) {               // (the bulk driver asks for the records when a sub-range needs them)
                 const int pe = flat_chain_prepare(c, fc, &launches);
                 if (pe) return pe;
@@ -2358,7 +2365,7 @@ static int plan_locked(blance_ctx* c, blance_result* res) {
                                      (known_passes == 0 || (known_passes == 1 && known_k == 1 && NP == 0 && ((higher_mask >> known_state) & 1)));
                 bool whole_known = false;
                 const bool settled = !first && passes_this_sweep == 1 && !retrying && c->dump_sweep < 0 && c->speculate > 0;
-                e = run_flat_pass(c, q, scal, &launches, &batched, fc, opening, &whole_known, settled, &nothing_to_apply);
+                e = run_flat_pass(c, q, scal, &launches, &batched, fc, opening, &whole_known, settled, &nothing_to_apply, count_rows);
                 if (whole_known) { known_passes++; known_state = m; known_k = k; }
                 else known_broken = true;
             } else if (flat_chain) {

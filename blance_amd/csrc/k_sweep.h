@@ -523,13 +523,25 @@ __global__ void k_result_gather(DevProblem d, const int32_t* off, int32_t* nodes
 // Step records in pass order: what findBestNodes needs to know about its partition.  A thread builds its record in
 // LDS (row stride RW | 1: no bank conflicts), the workgroup writes its 256 records as one contiguous block (per-thread
 // rows written straight to HBM cost 3.6 times their bytes in write traffic, rocprofv3 WRITE_SIZE).
+// (row_count, or null: the flat bulk driver's bound of a nodeToNodeCounts row -- the steps of the pass per top priority node,
+// k_flat.h: k_flat_row_count -- counted here, where the record is made anyway; row NX is the "" row)
 __global__ void k_gather(DevProblem d, int m, int top_state, int RW, const int32_t* order,
                          const int32_t* state_stickiness, const uint8_t* state_has_stickiness,
-                         int32_t* rec) {
+                         int32_t* rec, int32_t* row_count, int NX) {
     BLANCE_DYN_LDS(lds);
     const int tid = threadIdx.x, ST = RW | 1;
     const int oi = blockIdx.x * blockDim.x + tid;
     int32_t* r = (int32_t*)lds + tid * ST;
+    if (row_count) {
+        int top = -1;
+        if (oi < d.P) {
+            const int idxT = order[oi] * d.M + top_state;
+            if (d.live_kind[idxT] != kListAbsent && d.live_len[idxT] > 0) top = d.live[(size_t)idxT * d.L];
+            if (top >= 0) atomicAdd(&row_count[top], 1);
+        }
+        const unsigned long long none = __ballot(oi < d.P && top < 0);      // the "" row: one atomic per wave
+        if (none && (int)(tid & 63) == __ffsll((long long)none) - 1) atomicAdd(&row_count[NX], __popcll(none));
+    }
     if (oi < d.P) {
         int p = order[oi];
         int w = 1;                                         // plan.go:269-275
